@@ -1,0 +1,274 @@
+/*
+ * sdr_hip.h -- C ABI of libsdr_hip.so: the MI355X (gfx950) implementation of the
+ * streaming FIR / decimate / polyphase-resample / FM-demod / u8->cfloat hot path
+ * of adamwalker/sdr.
+ *
+ * Three layers, all `extern "C"`, plain pointers and sizes only:
+ *
+ *  (1) DROP-IN SYMBOLS -- the reference's own native entry points, same names and
+ *      signatures as c_sources/{convert,decimate,filter,resample,scale}.c, so the
+ *      reference's `foreign import ccall unsafe "<sym>"` declarations
+ *      (hs_sources/SDR/FilterInternal.hs:80-150,179-249,346-391; SDR/Util.hs:100-125)
+ *      resolve against this library unchanged.  HOST pointers in, HOST pointers
+ *      out, synchronous; results are bit-identical to the reference's x86 build
+ *      (each variant keeps its own summation order).
+ *
+ *  (2) DEVICE STREAM API (sdrhip_*) -- descriptors that own prepared taps in HBM
+ *      (the reference's Filter/Decimator/Resampler records, Filter.hs:116-144) and
+ *      `_run` calls on DEVICE pointers, asynchronous on a caller-supplied HIP
+ *      stream, addressed by GLOBAL stream index so that a contiguous sample
+ *      stream can be cut into launches / shards anywhere without changing a bit.
+ *
+ *  (3) PIPE OPERATORS (sdrhip_pipe_*) -- the host-block push interface mirroring
+ *      firFilter / firDecimator / firResampler / fmDemod /
+ *      interleavedIQUnsignedByteToFloat (Filter.hs:532-727, Demod.hs:40-46,
+ *      Util.hs:104-138): feed host blocks, receive host blocks of exactly
+ *      blockSizeOut elements, pinned double-buffered hipMemcpyAsync inside.
+ *
+ * Stream semantics shared by (2) and (3).  Let a stage have interpolation I
+ * (1 for filters/decimators), decimation D, and Pipe-visible length Lp
+ * (numCoeffsF / numCoeffsD / numCoeffsR, i.e. the PADDED length).  Output m of
+ * the whole stream has virtual window [m*D, m*D + Lp) in the I-times upsampled
+ * input index space.  With `seam_block` = B > 0 (the size of the input blocks
+ * the reference Pipe would have been fed), output m is
+ *    "One"   (computed by the C SIMD kernel, lane order of `order`)  when its
+ *            virtual window lies inside one input block, and
+ *    "Cross" (computed by the pure-Haskell sequential kernel,
+ *            FilterInternal.hs:397-423) when it straddles a multiple of B*I
+ * -- exactly the split Filter.hs:536-727 makes.  seam_block = 0 means one
+ * contiguous buffer: every output is "One" (what a single FFI call computes).
+ *
+ * Errors: drop-in symbols cannot report (void returns): on a HIP failure they
+ * print to stderr and abort().  sdrhip_* return SDRHIP_OK (0) or a negative code;
+ * sdrhip_last_error() returns a thread-local message.
+ */
+#ifndef SDR_HIP_H
+#define SDR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* (1) Drop-in symbols.  Signatures are the reference's, verbatim.          */
+/* ------------------------------------------------------------------------ */
+
+/* c_sources/convert.c:15,22,37 -- num = number of BYTES (= floats out). */
+void convertC(int num, uint8_t *in, float *out);
+void convertCSSE(int num, uint8_t *in, float *out);
+void convertCAVX(int num, uint8_t *in, float *out);
+/* c_sources/convert.c:52,59,72 (BladeRF i16 -> f32) and :87 (f32 -> i16 TX) */
+void convertCBladeRF(int num, int16_t *in, float *out);
+void convertCSSEBladeRF(int num, int16_t *in, float *out);
+void convertCAVXBladeRF(int num, int16_t *in, float *out);
+void convertBladeRFTransmit(int num, float *in, int16_t *out);
+
+/* c_sources/scale.c:15,22,30 */
+void scale(int num, float factor, float *in_buf, float *out_buf);
+void scaleSSE(int num, float factor, float *in_buf, float *out_buf);
+void scaleAVX(int num, float factor, float *in_buf, float *out_buf);
+
+/* c_sources/filter.c:16-68 -- real taps, real data.  num = outputs. */
+void filterRR(int num, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void filterSSERR(int num, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void filterAVXRR(int num, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+/* numCoeffs = HALF length (filter.c:50-68) */
+void filterSSESymmetricRR(int num, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void filterAVXSymmetricRR(int num, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+/* c_sources/filter.c:73-147 -- real taps, complex data.  RC: SSE/AVX take
+ * DUPLICATED taps (numCoeffs = 2P floats); RC2 / SymmetricRC take plain taps. */
+void filterRC(int num, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void filterSSERC(int num, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void filterSSERC2(int num, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void filterAVXRC(int num, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void filterAVXRC2(int num, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void filterSSESymmetricRC(int num, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void filterAVXSymmetricRC(int num, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+/* c_sources/filter.c:152-161 */
+void dcBlocker(int num, float lastSample, float lastOutput, float *finalSample, float *finalOutput,
+               float *inBuf, float *outBuf);
+
+/* c_sources/decimate.c:16-146 */
+void decimateRR(int num, int factor, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void decimateSSERR(int num, int factor, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void decimateAVXRR(int num, int factor, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void decimateSSESymmetricRR(int num, int factor, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void decimateAVXSymmetricRR(int num, int factor, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void decimateRC(int num, int factor, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void decimateSSERC(int num, int factor, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void decimateSSERC2(int num, int factor, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void decimateAVXRC(int num, int factor, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void decimateAVXRC2(int num, int factor, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void decimateSSESymmetricRC(int num, int factor, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+void decimateAVXSymmetricRC(int num, int factor, int numCoeffs, float *coeffs, float *inBuf, float *outBuf);
+
+/* c_sources/resample.c:16-142.  coeffs = table of num_groups HOST pointers to
+ * zero-padded polyphase groups (FilterInternal.hs:335-342); returns end group. */
+void resampleRR(int buf_size, int coeff_size, int interpolation, int decimation, int filter_offset,
+                float *coeffs, float *in_buf, float *out_buf);
+int resample2RR(int buf_size, int num_coeffs, int starting_group, int num_groups, int *increments,
+                float **coeffs, float *in_buf, float *out_buf);
+int resampleSSERR(int buf_size, int num_coeffs, int starting_group, int num_groups, int *increments,
+                  float **coeffs, float *in_buf, float *out_buf);
+int resampleAVXRR(int buf_size, int num_coeffs, int starting_group, int num_groups, int *increments,
+                  float **coeffs, float *in_buf, float *out_buf);
+int resample2RC(int buf_size, int num_coeffs, int starting_group, int num_groups, int *increments,
+                float **coeffs, float *in_buf, float *out_buf);
+int resampleSSERC(int buf_size, int num_coeffs, int starting_group, int num_groups, int *increments,
+                  float **coeffs, float *in_buf, float *out_buf);
+int resampleAVXRC(int buf_size, int num_coeffs, int starting_group, int num_groups, int *increments,
+                  float **coeffs, float *in_buf, float *out_buf);
+
+/* NEW seam (the reference's fmDemod is pure Haskell, Demod.hs:21-46; SURVEY.md
+ * 8(b) defines this FFI entry): out[i] = phase(in[i] * conj(in[i-1])), in[-1] =
+ * (last_re,last_im).  HOST pointers. */
+void fmDemodF(int num, float last_re, float last_im, const float *in_iq, float *out);
+
+/* ------------------------------------------------------------------------ */
+/* (2) Device stream API                                                    */
+/* ------------------------------------------------------------------------ */
+
+#define SDRHIP_OK            0
+#define SDRHIP_ERR_ARG      (-1)  /* precondition violated (the reference's `assert` -> error) */
+#define SDRHIP_ERR_HIP      (-2)  /* a HIP runtime call failed */
+#define SDRHIP_ERR_NOMEM    (-3)
+#define SDRHIP_ERR_STATE    (-4)
+
+/* Summation order = which of the reference's variants is reproduced
+ * (SDR.CPUID.featureSelect picks AVX on any host that has it, CPUID.hs:100-104). */
+#define SDRHIP_ORDER_SCALAR  0    /* filterRR / decimateRC / resample2RR ...      */
+#define SDRHIP_ORDER_SSE     1    /* 4 real / 2 complex lanes                     */
+#define SDRHIP_ORDER_AVX     2    /* 8 real / 4 complex lanes                     */
+
+const char *sdrhip_version(void);
+const char *sdrhip_last_error(void);
+int sdrhip_device_count(void);
+int sdrhip_set_device(int dev);
+int sdrhip_device_name(char *buf, int buflen);
+
+/* Thin memory / stream helpers so a non-C++ host (Haskell, ctypes) needs no HIP
+ * bindings of its own.  `stream` arguments are hipStream_t passed as void*
+ * (NULL = the default stream). */
+int sdrhip_malloc(void **dptr, size_t bytes);
+int sdrhip_free(void *dptr);
+int sdrhip_malloc_host(void **hptr, size_t bytes);   /* pinned */
+int sdrhip_free_host(void *hptr);
+int sdrhip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int sdrhip_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int sdrhip_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+int sdrhip_stream_create(void **stream);
+int sdrhip_stream_destroy(void *stream);
+int sdrhip_stream_sync(void *stream);
+
+/* ---- Filter (Filter.hs:116-120; constructors :163-261) ------------------- */
+typedef struct sdrhip_filter sdrhip_filter;
+/* fastFilter{C,SSE,AVX}{R,C}: zero-pads to the order's SIMD multiple
+ * (mkFilter Filter.hs:167-175 / mkFilterC :196-209). data_complex: 0 real, 1 complex. */
+int sdrhip_filter_create(sdrhip_filter **f, int order, int data_complex, const float *coeffs, int ncoeffs);
+/* fastFilterSym{SSE,AVX}R (mkFilterSymR Filter.hs:234-245): half = first half of an
+ * even-length linear-phase filter; nhalf must be a multiple of 4 (SSE) / 8 (AVX). */
+int sdrhip_filter_sym_create(sdrhip_filter **f, int order, const float *half, int nhalf);
+int sdrhip_filter_num_coeffs(const sdrhip_filter *f);            /* numCoeffsF */
+void sdrhip_filter_destroy(sdrhip_filter *f);
+/* out[k - k_begin] = stream output k, k in [k_begin,k_end); d_in[0] is stream input
+ * element in_base (floats for real data, (re,im) pairs for complex).  The caller
+ * guarantees d_in covers inputs [k_begin, k_end - 1 + numCoeffsF). */
+int sdrhip_filter_run(const sdrhip_filter *f, void *stream, const float *d_in, int64_t in_base,
+                      float *d_out, int64_t k_begin, int64_t k_end, int64_t seam_block);
+
+/* ---- Decimator (Filter.hs:126-131; constructors :277-371) ---------------- */
+typedef struct sdrhip_decimator sdrhip_decimator;
+int sdrhip_decimator_create(sdrhip_decimator **d, int order, int data_complex, int factor,
+                            const float *coeffs, int ncoeffs);
+int sdrhip_decimator_sym_create(sdrhip_decimator **d, int order, int factor, const float *half, int nhalf);
+int sdrhip_decimator_num_coeffs(const sdrhip_decimator *d);      /* numCoeffsD */
+int sdrhip_decimator_factor(const sdrhip_decimator *d);
+void sdrhip_decimator_destroy(sdrhip_decimator *d);
+/* needs inputs [k_begin*factor, (k_end-1)*factor + numCoeffsD) */
+int sdrhip_decimator_run(const sdrhip_decimator *d, void *stream, const float *d_in, int64_t in_base,
+                         float *d_out, int64_t k_begin, int64_t k_end, int64_t seam_block);
+/* same, reading interleaved u8 IQ (the u8->cfloat conversion of convert.c:37-50
+ * fused into the loader; complex decimators only) */
+int sdrhip_decimator_run_u8(const sdrhip_decimator *d, void *stream, const uint8_t *d_in_iq, int64_t in_base,
+                            float *d_out, int64_t k_begin, int64_t k_end, int64_t seam_block);
+
+/* ---- Resampler (Filter.hs:137-144; constructors :408-502) ---------------- */
+typedef struct sdrhip_resampler sdrhip_resampler;
+int sdrhip_resampler_create(sdrhip_resampler **r, int order, int data_complex, int interpolation,
+                            int decimation, const float *coeffs, int ncoeffs);
+int sdrhip_resampler_num_coeffs(const sdrhip_resampler *r);      /* numCoeffsR */
+int sdrhip_resampler_num_groups(const sdrhip_resampler *r);
+void sdrhip_resampler_destroy(sdrhip_resampler *r);
+/* Closed form of the phase recurrence (Filter.hs:613-641): first input element and
+ * filter offset of stream output m (stream starting at phase 0). */
+int64_t sdrhip_resampler_in_offset(const sdrhip_resampler *r, int64_t m);
+int sdrhip_resampler_filter_offset(const sdrhip_resampler *r, int64_t m);
+int sdrhip_resampler_group(const sdrhip_resampler *r, int64_t m);
+int sdrhip_resampler_run(const sdrhip_resampler *r, void *stream, const float *d_in, int64_t in_base,
+                         float *d_out, int64_t k_begin, int64_t k_end, int64_t seam_block);
+
+/* ---- element-wise stages -------------------------------------------------- */
+/* interleavedIQUnsignedByteToFloat (Util.hs:104-138 / convert.c): n_bytes u8 -> n_bytes f32 */
+int sdrhip_convert_u8_run(void *stream, const uint8_t *d_in, float *d_out, int64_t n_bytes);
+int sdrhip_convert_i16_run(void *stream, const int16_t *d_in, float *d_out, int64_t n);
+int sdrhip_scale_run(void *stream, float factor, const float *d_in, float *d_out, int64_t n);
+/* fmDemod (Demod.hs:40-46).  y[k] for k in [k_begin,k_end); the sample preceding
+ * k_begin is d_in[k_begin-1-in_base] when k_begin > in_base, else (last_re,last_im)
+ * (the Pipe's carried state; (0,0) at stream start, Demod.hs:41). */
+int sdrhip_fm_demod_run(void *stream, const float *d_in_iq, int64_t in_base, float *d_out,
+                        int64_t k_begin, int64_t k_end, float last_re, float last_im);
+
+/* ---- the FM receiver chain (examples/fm/fm.hs:34-41) ----------------------- */
+/* u8 IQ -> [convert] -> decimator -> fmDemod -> resampler -> symmetric filter
+ * [-> * gain].  All four Pipes of fm.hs run with blockSizeOut = block, and the
+ * source delivers `block`-sample buffers, so every stage's seams sit at
+ * multiples of `block` of its own input index (block = 0: contiguous). */
+typedef struct sdrhip_fm_chain sdrhip_fm_chain;
+int sdrhip_fm_chain_create(sdrhip_fm_chain **c, int order, int decim_factor, const float *decim_taps,
+                           int n_decim_taps, int interpolation, int decimation, const float *resamp_taps,
+                           int n_resamp_taps, const float *audio_half_taps, int n_audio_half, float gain,
+                           int64_t block);
+void sdrhip_fm_chain_destroy(sdrhip_fm_chain *c);
+/* Ownership rule for sharding: audio output q is owned by the shard in which its
+ * receptive field STARTS.  Given a shard of input samples [s0,s1) of the global
+ * stream (plus a right halo), report the owned range [*q0,*q1), and *halo = how
+ * many samples past s1 the owned outputs read (the ntaps-1 overlap of every
+ * stage composed).  total_in = length of the whole stream (outputs needing data
+ * past it do not exist), or -1 for unbounded. */
+int sdrhip_fm_chain_plan(const sdrhip_fm_chain *c, int64_t s0, int64_t s1, int64_t total_in,
+                         int64_t *q0, int64_t *q1, int64_t *halo);
+int64_t sdrhip_fm_chain_max_halo(const sdrhip_fm_chain *c);
+size_t sdrhip_fm_chain_workspace_bytes(const sdrhip_fm_chain *c, int64_t n_in);
+/* d_in_iq[0] is stream sample s0; n_in samples (shard + halo) are readable.
+ * Writes audio outputs [q0,q1) to d_audio[0..q1-q0).  Asynchronous on `stream`. */
+int sdrhip_fm_chain_run(sdrhip_fm_chain *c, void *stream, const uint8_t *d_in_iq, int64_t s0, int64_t n_in,
+                        float *d_audio, int64_t q0, int64_t q1, void *d_workspace, size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------ */
+/* (3) Pipe operators on host blocks                                        */
+/* ------------------------------------------------------------------------ */
+typedef struct sdrhip_pipe sdrhip_pipe;
+/* The constructors take ownership of nothing: the descriptor must outlive the pipe. */
+int sdrhip_pipe_fir_filter(sdrhip_pipe **p, const sdrhip_filter *f, int block_size_out);          /* firFilter   */
+int sdrhip_pipe_fir_decimator(sdrhip_pipe **p, const sdrhip_decimator *d, int block_size_out);    /* firDecimator */
+int sdrhip_pipe_fir_resampler(sdrhip_pipe **p, const sdrhip_resampler *r, int block_size_out);    /* firResampler */
+int sdrhip_pipe_fm_demod(sdrhip_pipe **p);                                                         /* fmDemod      */
+/* Feed one upstream block (n elements: floats, or complex pairs for complex
+ * stages).  Returns the number of complete output blocks now ready (>= 0) or a
+ * negative error.  A block shorter than numCoeffs is the reference's
+ * `assert "filter 1"` failure -> SDRHIP_ERR_ARG. */
+int sdrhip_pipe_push(sdrhip_pipe *p, const float *block, int n);
+/* Transfers are double-buffered, so results lag one push behind: flush waits for
+ * the in-flight block and returns the number of complete output blocks ready. */
+int sdrhip_pipe_flush(sdrhip_pipe *p);
+/* Pop one ready block into out (capacity in elements); returns its length, 0 if none. */
+int sdrhip_pipe_pop(sdrhip_pipe *p, float *out, int capacity);
+void sdrhip_pipe_destroy(sdrhip_pipe *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDR_HIP_H */

@@ -1,0 +1,78 @@
+"""Build libsdr_hip.so (gfx950) in-tree with hipcc.
+
+    python -m sdr_amd.build [--force] [--save-temps]
+
+Every translation unit is compiled with -ffp-contract=off: the library's parity
+with the reference depends on unfused multiply/add.
+hipcc cross-compiles gfx950 without a GPU, so this runs in the CPU container.
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libsdr_hip.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result", f"-I{INCLUDE}", f"-I{CSRC}"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    hs.append(os.path.join(INCLUDE, "sdr_hip.h"))
+    return hs
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src, obj, extra):
+    cmd = [HIPCC] + FLAGS + extra + ["-x", "hip", "-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    return r.stderr
+
+
+def build(force=False, save_temps=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdrs = headers()
+    jobs = []
+    objs = []
+    extra = ["-save-temps=obj"] if save_temps else []
+    for src in sources():
+        obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append((src, obj))
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for warn in ex.map(lambda j: _compile(j[0], j[1], extra), jobs):
+                if verbose and warn:
+                    sys.stderr.write(warn)
+    if jobs or force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True)
+    print(path)

@@ -1,0 +1,105 @@
+// common.hpp -- error plumbing and small RAII helpers shared by the ABI layers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+
+#include "../../include/sdr_hip.h"
+
+namespace sdrhip {
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define SDRHIP_CHECK_HIP(expr)                                                                  \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            ::sdrhip::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SDRHIP_ERR_HIP;                                                              \
+        }                                                                                       \
+    } while (0)
+
+#define SDRHIP_REQUIRE(cond, msg)                                        \
+    do {                                                                 \
+        if (!(cond)) {                                                   \
+            ::sdrhip::set_error("%s: requirement `%s` violated", msg, #cond); \
+            return SDRHIP_ERR_ARG;                                       \
+        }                                                                \
+    } while (0)
+
+// abort()-style check for the void-returning drop-in symbols
+#define SDRHIP_DIE_HIP(expr)                                                                         \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            fprintf(stderr, "libsdr_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            abort();                                                                                 \
+        }                                                                                            \
+    } while (0)
+
+inline int round_up(int n, int d) { return ((n + d - 1) / d) * d; }
+inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }  // a >= 0, b > 0
+
+// Grow-only device buffer.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return SDRHIP_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return SDRHIP_ERR_NOMEM;
+        }
+        cap = want;
+        return SDRHIP_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+// Grow-only pinned host buffer.
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return SDRHIP_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return SDRHIP_ERR_NOMEM;
+        }
+        cap = want;
+        return SDRHIP_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    ~PinBuf() { release(); }
+};
+
+int upload_floats(float** d, const std::vector<float>& h);
+
+}  // namespace sdrhip

@@ -1,0 +1,86 @@
+// kernels.hpp -- host-callable launchers of the gfx950 kernels (internal header).
+//
+// Every launcher is asynchronous on `stream` and works on DEVICE pointers.  The
+// arithmetic contract (summation orders, no FMA) is documented per kernel in
+// kernels_generic.hip / kernels_fast.hip; the file is compiled with
+// -ffp-contract=off, which the parity of every result depends on.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sdrhip {
+
+// Which reference variant's summation order is reproduced.
+//  real data:    lanes 1 (scalar), 4 (SSE), 8 (AVX)            common.h:34-72
+//  complex data: CO_SEQ   scalar                                common.h:95-106
+//                CO_L2/L4 "RC":  duplicated taps, 2/4 complex lanes  (decimate.c:84-113)
+//                CO_X2/X4 "RC2": plain taps, 4/8 complex partials folded (common.h:108-155)
+enum ComplexOrder { CO_SEQ = 0, CO_L2 = 1, CO_L4 = 2, CO_X2 = 3, CO_X4 = 4 };
+
+// Stream geometry of one launch (see include/sdr_hip.h "Stream semantics").
+struct Geom {
+    int64_t in_base;   // global index of in[0]
+    int64_t k_begin;   // global index of out[0]
+    int     count;     // outputs in this launch
+    int     I;         // interpolation (1 for filter / decimator)
+    int     D;         // decimation
+    int     Lp;        // Pipe-visible (padded) length in upsampled units
+    int64_t seamBI;    // seam_block * I; 0 = contiguous (all One); < 0 = every output Cross
+};
+
+// Real data ------------------------------------------------------------------
+// taps: `ntaps` floats (multiple of lanes).  sym: taps are the HALF filter.
+// cross_taps: Lp floats used by the sequential "Cross" outputs (may be null when seamBI == 0).
+void launch_fir_real(hipStream_t s, const Geom& g, int lanes, bool sym, const float* d_taps, int ntaps,
+                     const float* d_cross_taps, const float* d_in, float* d_out);
+
+// Complex data, real taps.  For CO_L2/CO_L4 d_taps holds 2*P interleaved
+// (duplicated) floats and ntaps = 2P; otherwise P plain taps.  sym => half taps
+// (only with CO_X2/CO_X4: the reference's SymmetricRC kernels).
+void launch_fir_cplx(hipStream_t s, const Geom& g, ComplexOrder order, bool sym, const float* d_taps, int ntaps,
+                     const float* d_cross_taps, const float* d_in, float* d_out);
+// same with interleaved u8 IQ input (convert fused into the load)
+void launch_fir_cplx_u8(hipStream_t s, const Geom& g, ComplexOrder order, const float* d_taps, int ntaps,
+                        const float* d_cross_taps, const uint8_t* d_in, float* d_out);
+
+// Polyphase resampler.  Output i of the launch uses group (group0 + i) % ngroups
+// and starts at input  pos0 + (i / ngroups) * period + pre[i % ngroups]  (relative
+// to d_in).  groups: ngroups rows of `row_stride` floats; the dot product runs
+// over nloop floats (roundUp(num_coeffs, lanes)).
+struct ResampTable {
+    int ngroups;
+    int group0;
+    int64_t pos0;
+    int period;       // inputs consumed by one full cycle of groups
+    int pre[64];      // prefix of increments starting at group0
+    int row_stride;
+    int nloop;
+    // for Cross outputs (seams) and the legacy sequential resampler: plain taps,
+    // filter offset of each group, and force_seq = every output sequential
+    int ntaps_plain;
+    int fo[64];
+    int force_seq;
+};
+void launch_resample_real(hipStream_t s, const Geom& g, int lanes, const ResampTable& t, const float* d_groups,
+                          const float* d_plain_taps, const float* d_in, float* d_out);
+void launch_resample_cplx(hipStream_t s, const Geom& g, ComplexOrder order, const ResampTable& t,
+                          const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out);
+
+// Element-wise ----------------------------------------------------------------
+void launch_convert_u8(hipStream_t s, const uint8_t* d_in, float* d_out, int64_t n);
+void launch_convert_i16(hipStream_t s, const int16_t* d_in, float* d_out, int64_t n);
+void launch_convert_f32_to_i16_bladerf(hipStream_t s, const float* d_in, int16_t* d_out, int64_t n);
+void launch_scale(hipStream_t s, float factor, const float* d_in, float* d_out, int64_t n);
+// y[i] = phase(x[i] * conj(x[i-1])), i < count; x[-1] = d_in[-1] if has_prev else (last_re,last_im)
+void launch_fm_demod(hipStream_t s, const float* d_in_iq, float* d_out, int64_t count, bool has_prev,
+                     float last_re, float last_im);
+// filter.c:152-161 (sequential one-pole IIR; d_final receives {finalSample, finalOutput})
+void launch_dc_blocker(hipStream_t s, int64_t num, float last_sample, float last_output, const float* d_in,
+                       float* d_out, float* d_final);
+
+// Fast paths (kernels_fast.hip).  Return false when the configuration is not one
+// they are specialised for; the caller then uses the generic kernel.
+bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps,
+                             const void* d_in, bool in_is_u8, float* d_out);
+
+}  // namespace sdrhip

@@ -1,0 +1,257 @@
+// kernels_fast.hip -- LDS-tiled kernels for the hot configurations.
+//
+// K2: complex FIR decimator, real taps, the AVX "RC" summation order
+//     (decimateAVXRC, c_sources/decimate.c:105-113 -> avx_dotprod_R common.h:58-72 on
+//     duplicated taps -> avx_hadd_C common.h:82-90):
+//        out[o] = (L0 + L1) + (L2 + L3),   L_k = sum_{j = k, k+4, ..} h[j] * x[o*D + j]
+//     each L_k accumulated from +0 in increasing j, separate mul and add.
+//
+// Design (CDNA4, not a translation of the AVX loop):
+//   * one workgroup = NT threads = a tile of NT*R consecutive outputs; the tile's
+//     input span ((NT*R-1)*D + P samples) is staged ONCE in LDS as float2, loaded
+//     from HBM with 16-byte coalesced loads (u8 IQ input: 8 samples per load,
+//     converted on the way in -- convert.c's (u-128)/128 is exact, so fusing it
+//     cannot change a bit);
+//   * each thread produces R consecutive outputs, so one LDS read of a sample
+//     feeds up to R MACs (R = 4: 38 sample reads per output instead of 128) --
+//     register-level reuse keeps the LDS pipe at ~30 % while the VALU does the work;
+//   * per-thread LDS stride is padded (2 float2 per D*R samples) so ds_read_b128
+//     is bank-conflict free;
+//   * the 4 complex lane partials of every output live in registers: 4*R float2
+//     accumulators = 8*R independent dependency chains, no cross-lane traffic;
+//   * taps are wave-uniform -> scalar loads / SGPR operands.
+//   "Cross" outputs (seam straddlers, sequential order) are rewritten afterwards by
+//   a tiny fix-up kernel on the same stream: ~1.5 % of outputs.
+#include "kernels.hpp"
+
+namespace sdrhip {
+
+namespace {
+
+template <int D, int P, int R, int NT>
+struct Tile {
+    static constexpr int OUTS = NT * R;                   // outputs per workgroup
+    static constexpr int SPAN = (OUTS - 1) * D + P;       // input samples per workgroup
+    static constexpr int CHUNK = D * R;                   // samples between adjacent threads' windows
+    static constexpr int WIN = (R - 1) * D + P;           // samples one thread reads
+    static_assert(CHUNK % 2 == 0, "chunk must hold whole float4s");
+    // padded LDS layout: 2 float2 of padding after every CHUNK samples
+    __host__ __device__ static constexpr int lds_idx(int s) { return s + 2 * (s / CHUNK); }
+    static constexpr int LDS_F2 = SPAN + 2 * (SPAN / CHUNK) + 2;
+    static constexpr size_t LDS_BYTES = (size_t)LDS_F2 * 8;
+};
+
+// stage the tile's samples [0, SPAN) into LDS; `avail` = how many of them exist
+template <class T, bool U8>
+__device__ __forceinline__ void stage_tile(float2* __restrict__ lds, const void* __restrict__ src_v, int64_t src_sample0,
+                                           int avail)
+{
+    const int tid = threadIdx.x;
+    if constexpr (!U8) {
+        // float4 = 2 samples
+        const float* src = reinterpret_cast<const float*>(src_v) + 2 * src_sample0;
+        constexpr int NV = (T::SPAN + 1) / 2;
+        const int nthreads = blockDim.x;
+        for (int v = tid; v < NV; v += nthreads) {
+            int s = 2 * v;
+            float4 val;
+            if (s + 1 < avail) {
+                val = *reinterpret_cast<const float4*>(src + 2 * s);
+            } else {
+                val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (s < avail) { val.x = src[2 * s]; val.y = src[2 * s + 1]; }
+            }
+            // CHUNK is even, so the two samples of a float4 never straddle a pad
+            *reinterpret_cast<float4*>(&lds[T::lds_idx(s)]) = val;
+        }
+    } else {
+        // uint4 = 16 bytes = 8 samples
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(src_v) + 2 * src_sample0;
+        constexpr int NV = (T::SPAN + 7) / 8;
+        const int nthreads = blockDim.x;
+        for (int v = tid; v < NV; v += nthreads) {
+            int s = 8 * v;
+            uint32_t w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};  // 128 -> 0.0f
+            if (s + 7 < avail) {
+                uint4 q = *reinterpret_cast<const uint4*>(src + 2 * s);
+                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+            } else {
+                for (int e = 0; e < 8; e++) {
+                    if (s + e < avail) {
+                        uint32_t lo = src[2 * (s + e)], hi = src[2 * (s + e) + 1];
+                        uint32_t sh = (e & 1) * 16;
+                        w[e >> 1] = (w[e >> 1] & ~(0xffffu << sh)) | ((lo | (hi << 8)) << sh);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float4 f;
+                f.x = ((float)(w[k] & 0xff) - 128.0f) * (1.0f / 128.0f);
+                f.y = ((float)((w[k] >> 8) & 0xff) - 128.0f) * (1.0f / 128.0f);
+                f.z = ((float)((w[k] >> 16) & 0xff) - 128.0f) * (1.0f / 128.0f);
+                f.w = ((float)(w[k] >> 24) - 128.0f) * (1.0f / 128.0f);
+                int ss = s + 2 * k;
+                if (ss < T::SPAN + 1) *reinterpret_cast<float4*>(&lds[T::lds_idx(ss)]) = f;
+            }
+        }
+    }
+}
+
+template <int D, int P, int R, int NT, bool U8>
+__global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in, int64_t x0 /* sample index of output 0's window in `in` */,
+                                                    int count, const float* __restrict__ taps, float* __restrict__ out)
+{
+    using T = Tile<D, P, R, NT>;
+    static_assert(D % 4 == 0, "lane of a tap must not depend on the output within a thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+
+    const int tile = blockIdx.x;
+    const int out0 = tile * T::OUTS;
+    const int64_t s0 = (int64_t)out0 * D;                     // first sample of the tile, relative to x0
+    const int64_t total_avail = (int64_t)(count - 1) * D + P; // samples that exist from x0 on
+    int64_t av = total_avail - s0;
+    int avail = av > T::SPAN ? T::SPAN : (int)av;
+
+    stage_tile<T, U8>(lds, in, x0 + s0, avail);
+    __syncthreads();
+
+    // per-thread window starts at sample tid*CHUNK of the tile
+    const float2* win = lds + T::lds_idx(threadIdx.x * T::CHUNK);
+    float2 acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[r][k] = make_float2(0.0f, 0.0f);
+
+#pragma unroll
+    for (int s = 0; s < T::WIN; s += 2) {
+        // two samples per ds_read_b128; within the window the pad offset is compile-time
+        float4 v2 = *reinterpret_cast<const float4*>(&win[s + 2 * (s / T::CHUNK)]);
+        float2 v[2] = {make_float2(v2.x, v2.y), make_float2(v2.z, v2.w)};
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int ss = s + e;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int j = ss - r * D;
+                if (j >= 0 && j < P) {
+                    const float h = taps[j];
+                    acc[r][j & 3].x = acc[r][j & 3].x + h * v[e].x;
+                    acc[r][j & 3].y = acc[r][j & 3].y + h * v[e].y;
+                }
+            }
+        }
+    }
+
+    const int o = out0 + threadIdx.x * R;
+    float2 res[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        res[r].x = (acc[r][0].x + acc[r][1].x) + (acc[r][2].x + acc[r][3].x);
+        res[r].y = (acc[r][0].y + acc[r][1].y) + (acc[r][2].y + acc[r][3].y);
+    }
+    if (o + R <= count) {
+        float4* dst = reinterpret_cast<float4*>(out + 2 * (int64_t)o);
+#pragma unroll
+        for (int r = 0; r < R; r += 2) dst[r / 2] = make_float4(res[r].x, res[r].y, res[r + 1].x, res[r + 1].y);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (o + r < count) *reinterpret_cast<float2*>(out + 2 * (int64_t)(o + r)) = res[r];
+    }
+}
+
+// Cross outputs: sequential order over the Lp plain taps (decimateCrossHighLevel,
+// FilterInternal.hs:397-402).  One thread per (seam, candidate).
+template <bool U8>
+__global__ void __launch_bounds__(256) k_decimate_c_crossfix(Geom g, const float* __restrict__ xtaps,
+                                                             const void* __restrict__ in, float* __restrict__ out,
+                                                             int64_t first_seam, int nseams, int per_seam)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseams * per_seam) return;
+    int si = t / per_seam, ci = t - si * per_seam;
+    int64_t edge = (first_seam + si) * g.seamBI;      // input index of the block boundary
+    // outputs with m*D < edge < m*D + Lp  <=>  m in (ceil((edge-Lp+1)/D) .. ceil(edge/D)-1]
+    int64_t m_hi = (edge + g.D - 1) / g.D - 1;
+    int64_t m = m_hi - ci;
+    if (m < g.k_begin || m >= g.k_begin + g.count) return;
+    int64_t v = m * g.D;
+    if (!(v < edge && v + g.Lp > edge)) return;
+    int64_t x = v - g.in_base;
+    float re = 0.0f, im = 0.0f;
+    for (int j = 0; j < g.Lp; j++) {
+        float a, b;
+        if constexpr (U8) {
+            const uint8_t* p = reinterpret_cast<const uint8_t*>(in) + 2 * (x + j);
+            a = ((float)p[0] - 128.0f) * (1.0f / 128.0f);
+            b = ((float)p[1] - 128.0f) * (1.0f / 128.0f);
+        } else {
+            const float* p = reinterpret_cast<const float*>(in) + 2 * (x + j);
+            a = p[0];
+            b = p[1];
+        }
+        re = re + a * xtaps[j];
+        im = im + b * xtaps[j];
+    }
+    *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
+}
+
+template <int D, int P, int R, int NT, bool U8>
+void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, float* out)
+{
+    using T = Tile<D, P, R, NT>;
+    static bool attr_set = false;
+    auto kern = k_decimate_c4<D, P, R, NT, U8>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)T::LDS_BYTES);
+        attr_set = true;
+    }
+    int tiles = (g.count + T::OUTS - 1) / T::OUTS;
+    int64_t x0 = g.k_begin * D - g.in_base;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, taps, out);
+}
+
+}  // namespace
+
+bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps,
+                             const void* d_in, bool in_is_u8, float* d_out)
+{
+    if (g.I != 1 || g.count <= 0 || g.seamBI < 0) return false;
+    if (!(g.D == 8 && P == 128)) return false;
+    if (g.seamBI != 0 && d_cross_taps == nullptr) return false;
+    int64_t x0 = g.k_begin * g.D - g.in_base;
+    // vector loads need 16-byte aligned tile starts (tiles begin at multiples of 8 samples from x0)
+    uintptr_t base = reinterpret_cast<uintptr_t>(d_in);
+    if (in_is_u8) {
+        if (((base + 2 * (uintptr_t)x0) & 15) != 0) return false;
+    } else {
+        if (((base + 8 * (uintptr_t)x0) & 15) != 0) return false;
+    }
+    if ((reinterpret_cast<uintptr_t>(d_out) & 15) != 0) return false;
+    if (in_is_u8) launch_c4<8, 128, 4, 256, true>(s, g, d_plain_taps, d_in, d_out);
+    else launch_c4<8, 128, 4, 256, false>(s, g, d_plain_taps, d_in, d_out);
+
+    if (g.seamBI != 0) {
+        // seams whose straddling outputs may fall in [k_begin, k_end)
+        int64_t v_lo = g.k_begin * g.D, v_hi = (g.k_begin + g.count - 1) * g.D + g.Lp;
+        int64_t first = v_lo / g.seamBI + 1;          // first boundary strictly above v_lo
+        int64_t last = (v_hi - 1) / g.seamBI;         // last boundary strictly below v_hi
+        if (last >= first) {
+            int nseams = (int)(last - first + 1);
+            int per = (g.Lp + g.D - 2) / g.D;          // ceil((Lp-1)/D) candidates per seam
+            int total = nseams * per;
+            dim3 grid((total + 255) / 256), block(256);
+            if (in_is_u8)
+                hipLaunchKernelGGL(k_decimate_c_crossfix<true>, grid, block, 0, s, g, d_cross_taps, d_in, d_out, first, nseams, per);
+            else
+                hipLaunchKernelGGL(k_decimate_c_crossfix<false>, grid, block, 0, s, g, d_cross_taps, d_in, d_out, first, nseams, per);
+        }
+    }
+    return true;
+}
+
+}  // namespace sdrhip

@@ -1,0 +1,320 @@
+// pipes.cpp -- layer (3): the reference's Pipes operators on HOST blocks.
+//
+//   firFilter    Filter.hs:532-569      firDecimator  Filter.hs:574-611
+//   firResampler Filter.hs:679-727      fmDemod       Demod.hs:40-46
+//
+// The reference's state machines alternate `simple` (outputs whose window fits in
+// the current input buffer: the C SIMD kernel) and `crossover` (outputs straddling
+// two buffers: the sequential Haskell kernel), re-blocking the outputs into vectors
+// of exactly blockSizeOut (advanceOutBuf, Filter.hs:516-523: a block is yielded only
+// when exactly full).  Here each pushed block triggers at most two launches on the
+// pipe's stream -- the Cross outputs straddling the boundary with the previous
+// block, then the One outputs inside the new block -- over a device buffer that
+// holds [carried tail | new block].  Block sizes may vary from push to push.
+//
+// Transfers are pinned and double-buffered over three HIP streams: push(i) enqueues
+// H2D(i) on the upload stream, kernels(i) on the compute stream (after H2D(i)'s
+// event) and D2H(i) on the download stream (after the kernels' event), and only
+// then harvests slot i-1 -- so the upload of block i and the download of block i-1
+// overlap the compute between them.  Results therefore lag by one push;
+// sdrhip_pipe_flush() drains the in-flight slot.
+#include <string.h>
+
+#include <deque>
+
+#include "descriptors.hpp"
+
+using namespace sdrhip;
+
+enum PipeKind { PK_FILTER, PK_DECIMATOR, PK_RESAMPLER, PK_DEMOD };
+
+struct sdrhip_pipe {
+    PipeKind kind;
+    const FirDesc* fir = nullptr;
+    const ResampDesc* rs = nullptr;
+    int block_out = 0;
+    bool cplx_in = false, cplx_out = false;
+    int I = 1, D = 1, Lp = 1;
+
+    hipStream_t stream = nullptr;   // compute
+    hipStream_t up = nullptr;       // H2D
+    hipStream_t down = nullptr;     // D2H
+    hipEvent_t ev_tail = nullptr;   // last tail copy (reads the buffer the NEXT upload overwrites)
+    bool tail_pending = false;
+    // device input: two buffers, alternating, each holding [tail | block]
+    DevBuf din[2];
+    int cur = 0;
+    int64_t base = 0;       // global index of din[cur][0]
+    int64_t have = 0;       // elements valid in din[cur]
+    int64_t E_prev = 0;     // global end of the previous block
+    int64_t m_done = 0;     // outputs computed so far
+    float last_re = 0.0f, last_im = 0.0f;  // fmDemod carry (Demod.hs:41,46)
+
+    struct Slot {
+        PinBuf hin, hout;
+        DevBuf dout;
+        hipEvent_t ev = nullptr;      // D2H complete
+        hipEvent_t ev_up = nullptr;   // H2D complete
+        hipEvent_t ev_k = nullptr;    // kernels complete
+        int64_t n_out = 0;   // elements produced by the in-flight work
+        bool busy = false;
+    } slot[2];
+    int64_t pushes = 0;
+
+    std::deque<float> fifo;            // produced output floats not yet popped
+    std::deque<int> demod_blocks;      // fmDemod: output block lengths (one per input block)
+
+    int esz_in() const { return cplx_in ? 2 : 1; }
+    int esz_out() const { return cplx_out ? 2 : 1; }
+    int64_t in_offset(int64_t m) const { return ceil_div64(m * (int64_t)D, I); }
+
+    ~sdrhip_pipe()
+    {
+        for (hipStream_t st : {up, stream, down})
+            if (st) (void)hipStreamSynchronize(st);
+        for (auto& s : slot)
+            for (hipEvent_t e : {s.ev, s.ev_up, s.ev_k})
+                if (e) (void)hipEventDestroy(e);
+        if (ev_tail) (void)hipEventDestroy(ev_tail);
+        for (hipStream_t st : {up, stream, down})
+            if (st) (void)hipStreamDestroy(st);
+    }
+};
+
+static int pipe_new(sdrhip_pipe** out, PipeKind kind)
+{
+    sdrhip_pipe* p = new sdrhip_pipe();
+    p->kind = kind;
+    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking);
+    for (auto& sl : p->slot)
+        for (hipEvent_t* ev : {&sl.ev, &sl.ev_up, &sl.ev_k})
+            if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_tail, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        set_error("pipe: stream/event creation failed: %s", hipGetErrorString(e));
+        delete p;
+        return SDRHIP_ERR_HIP;
+    }
+    *out = p;
+    return SDRHIP_OK;
+}
+
+static int harvest(sdrhip_pipe* p, int si)
+{
+    sdrhip_pipe::Slot& s = p->slot[si];
+    if (!s.busy) return SDRHIP_OK;
+    SDRHIP_CHECK_HIP(hipEventSynchronize(s.ev));
+    const float* h = (const float*)s.hout.p;
+    p->fifo.insert(p->fifo.end(), h, h + s.n_out);
+    s.busy = false;
+    return SDRHIP_OK;
+}
+
+static int ready_blocks(const sdrhip_pipe* p)
+{
+    if (p->kind == PK_DEMOD) {
+        // complete blocks = those whose floats have all been harvested
+        size_t have = p->fifo.size(), n = 0;
+        for (int len : p->demod_blocks) {
+            if (have < (size_t)len) break;
+            have -= len;
+            n++;
+        }
+        return (int)n;
+    }
+    return (int)(p->fifo.size() / ((size_t)p->block_out * p->esz_out()));
+}
+
+extern "C" {
+
+int sdrhip_pipe_fir_filter(sdrhip_pipe** pp, const sdrhip_filter* f, int block_size_out)
+{
+    SDRHIP_REQUIRE(pp && f && block_size_out > 0, "sdrhip_pipe_fir_filter");
+    int rc = pipe_new(pp, PK_FILTER);
+    if (rc != SDRHIP_OK) return rc;
+    sdrhip_pipe* p = *pp;
+    p->fir = f;
+    p->block_out = block_size_out;
+    p->cplx_in = p->cplx_out = f->cplx;
+    p->I = 1;
+    p->D = 1;
+    p->Lp = f->Lp;
+    return SDRHIP_OK;
+}
+
+int sdrhip_pipe_fir_decimator(sdrhip_pipe** pp, const sdrhip_decimator* d, int block_size_out)
+{
+    SDRHIP_REQUIRE(pp && d && block_size_out > 0, "sdrhip_pipe_fir_decimator");
+    int rc = pipe_new(pp, PK_DECIMATOR);
+    if (rc != SDRHIP_OK) return rc;
+    sdrhip_pipe* p = *pp;
+    p->fir = d;
+    p->block_out = block_size_out;
+    p->cplx_in = p->cplx_out = d->cplx;
+    p->I = 1;
+    p->D = d->factor;
+    p->Lp = d->Lp;
+    return SDRHIP_OK;
+}
+
+int sdrhip_pipe_fir_resampler(sdrhip_pipe** pp, const sdrhip_resampler* r, int block_size_out)
+{
+    SDRHIP_REQUIRE(pp && r && block_size_out > 0, "sdrhip_pipe_fir_resampler");
+    int rc = pipe_new(pp, PK_RESAMPLER);
+    if (rc != SDRHIP_OK) return rc;
+    sdrhip_pipe* p = *pp;
+    p->rs = r;
+    p->block_out = block_size_out;
+    p->cplx_in = p->cplx_out = r->cplx;
+    p->I = r->I;
+    p->D = r->D;
+    p->Lp = r->Lp;
+    return SDRHIP_OK;
+}
+
+int sdrhip_pipe_fm_demod(sdrhip_pipe** pp)
+{
+    SDRHIP_REQUIRE(pp != nullptr, "sdrhip_pipe_fm_demod");
+    int rc = pipe_new(pp, PK_DEMOD);
+    if (rc != SDRHIP_OK) return rc;
+    sdrhip_pipe* p = *pp;
+    p->cplx_in = true;
+    p->cplx_out = false;
+    return SDRHIP_OK;
+}
+
+int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
+{
+    SDRHIP_REQUIRE(p != nullptr && block != nullptr && n > 0, "sdrhip_pipe_push");
+    const int si = (int)(p->pushes & 1);
+    sdrhip_pipe::Slot& sl = p->slot[si];
+    int rc;
+    // slot si was last used by push i-2 and harvested during push i-1
+    if ((rc = harvest(p, si)) != SDRHIP_OK) return rc;
+
+    const size_t ein = (size_t)p->esz_in() * 4, eout = (size_t)p->esz_out() * 4;
+    if ((rc = sl.hin.ensure((size_t)n * ein)) != SDRHIP_OK) return rc;
+    memcpy(sl.hin.p, block, (size_t)n * ein);
+
+    if (p->kind == PK_DEMOD) {
+        // fmDemodVec last dat (Demod.hs:32-36,43-46): one output vector per input vector
+        DevBuf& d = p->din[p->cur];
+        if ((rc = d.ensure((size_t)n * ein)) != SDRHIP_OK) return rc;
+        if ((rc = sl.dout.ensure((size_t)n * eout)) != SDRHIP_OK) return rc;
+        if ((rc = sl.hout.ensure((size_t)n * eout)) != SDRHIP_OK) return rc;
+        SDRHIP_CHECK_HIP(hipMemcpyAsync(d.p, sl.hin.p, (size_t)n * ein, hipMemcpyHostToDevice, p->up));
+        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, p->up));
+        SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->stream, sl.ev_up, 0));
+        launch_fm_demod(p->stream, (const float*)d.p, (float*)sl.dout.p, n, false, p->last_re, p->last_im);
+        SDRHIP_CHECK_HIP(hipGetLastError());
+        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, p->stream));
+        SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->down, sl.ev_k, 0));
+        SDRHIP_CHECK_HIP(hipMemcpyAsync(sl.hout.p, sl.dout.p, (size_t)n * eout, hipMemcpyDeviceToHost, p->down));
+        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, p->down));
+        p->last_re = block[2 * (n - 1)];
+        p->last_im = block[2 * (n - 1) + 1];
+        sl.n_out = n;
+        sl.busy = true;
+        p->demod_blocks.push_back(n);
+        p->cur ^= 1;  // the next push must not overwrite an input still being read
+        p->pushes++;
+        if ((rc = harvest(p, si ^ 1)) != SDRHIP_OK) return rc;
+        return ready_blocks(p);
+    }
+
+    // ---- FIR-like stages --------------------------------------------------------
+    const int64_t E_prev = p->E_prev, E = E_prev + n;
+    // outputs computable once this block is in: window end <= E*I
+    int64_t m_end = (E * p->I >= p->Lp) ? (E * p->I - p->Lp) / p->D + 1 : 0;
+    // first output starting at/after the previous boundary: everything before it
+    // that is not yet done straddles that boundary (Cross)
+    int64_t m_split = ceil_div64(E_prev * p->I, p->D);
+    if (m_split < p->m_done) m_split = p->m_done;
+    // the reference's `assert "filter 1" / "decimate 1" / "resample 1"`: after the
+    // crossover the rest of the new buffer must still hold one whole filter
+    if (m_end <= m_split) {
+        set_error("pipe: input block of %d elements is shorter than the filter (numCoeffs %d): the reference asserts "
+                  "(Filter.hs:544,586,691)", n, p->Lp);
+        return SDRHIP_ERR_ARG;
+    }
+    // device input = [tail of previous | new block]
+    const int64_t keep_from = p->in_offset(p->m_done);  // first input any pending output needs
+    const int64_t tail = E_prev - keep_from > 0 ? E_prev - keep_from : 0;
+    DevBuf& prev = p->din[p->cur];
+    DevBuf& next = p->din[p->cur ^ 1];
+    if ((rc = next.ensure((size_t)(tail + n) * ein)) != SDRHIP_OK) return rc;
+    // the previous push's tail copy READ `next` (it was that push's `prev`): the upload
+    // below must not overwrite it first
+    if (p->tail_pending) SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->up, p->ev_tail, 0));
+    p->tail_pending = false;
+    if (tail > 0) {
+        SDRHIP_CHECK_HIP(hipMemcpyAsync(next.p, (const char*)prev.p + (size_t)(keep_from - p->base) * ein,
+                                        (size_t)tail * ein, hipMemcpyDeviceToDevice, p->stream));
+        SDRHIP_CHECK_HIP(hipEventRecord(p->ev_tail, p->stream));
+        p->tail_pending = true;
+    }
+    // `next` was last read by the kernels of push i-2, which has been harvested, so the
+    // upload may start while push i-1's kernels are still running on the compute stream
+    SDRHIP_CHECK_HIP(hipMemcpyAsync((char*)next.p + (size_t)tail * ein, sl.hin.p, (size_t)n * ein,
+                                    hipMemcpyHostToDevice, p->up));
+    SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, p->up));
+    SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->stream, sl.ev_up, 0));
+    p->cur ^= 1;
+    p->base = tail > 0 ? keep_from : E_prev;
+    p->have = tail + n;
+
+    const int64_t n_out = m_end - p->m_done;
+    if ((rc = sl.dout.ensure((size_t)n_out * eout)) != SDRHIP_OK) return rc;
+    if ((rc = sl.hout.ensure((size_t)n_out * eout)) != SDRHIP_OK) return rc;
+    float* dout = (float*)sl.dout.p;
+    const float* din = (const float*)next.p;
+    const int64_t ncross = m_split - p->m_done;
+    if (p->kind == PK_RESAMPLER) {
+        if (ncross > 0 && (rc = resamp_run(p->rs, p->stream, din, p->base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
+        if ((rc = resamp_run(p->rs, p->stream, din, p->base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
+    } else {
+        if (ncross > 0 && (rc = fir_run(p->fir, p->stream, din, false, p->base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
+        if ((rc = fir_run(p->fir, p->stream, din, false, p->base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
+    }
+    SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, p->stream));
+    SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->down, sl.ev_k, 0));
+    SDRHIP_CHECK_HIP(hipMemcpyAsync(sl.hout.p, sl.dout.p, (size_t)n_out * eout, hipMemcpyDeviceToHost, p->down));
+    SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, p->down));
+    sl.n_out = n_out * p->esz_out();
+    sl.busy = true;
+    p->m_done = m_end;
+    p->E_prev = E;
+    p->pushes++;
+    if ((rc = harvest(p, si ^ 1)) != SDRHIP_OK) return rc;
+    return ready_blocks(p);
+}
+
+int sdrhip_pipe_flush(sdrhip_pipe* p)
+{
+    SDRHIP_REQUIRE(p != nullptr, "sdrhip_pipe_flush");
+    int rc;
+    // oldest first
+    int first = (int)(p->pushes & 1);
+    if ((rc = harvest(p, first)) != SDRHIP_OK) return rc;
+    if ((rc = harvest(p, first ^ 1)) != SDRHIP_OK) return rc;
+    return ready_blocks(p);
+}
+
+int sdrhip_pipe_pop(sdrhip_pipe* p, float* out, int capacity)
+{
+    SDRHIP_REQUIRE(p != nullptr && out != nullptr, "sdrhip_pipe_pop");
+    if (ready_blocks(p) <= 0) return 0;
+    int len = p->kind == PK_DEMOD ? p->demod_blocks.front() : p->block_out;
+    SDRHIP_REQUIRE(capacity >= len, "sdrhip_pipe_pop: capacity smaller than the block");
+    size_t nf = (size_t)len * p->esz_out();
+    for (size_t i = 0; i < nf; i++) out[i] = p->fifo[i];
+    p->fifo.erase(p->fifo.begin(), p->fifo.begin() + nf);
+    if (p->kind == PK_DEMOD) p->demod_blocks.pop_front();
+    return len;
+}
+
+void sdrhip_pipe_destroy(sdrhip_pipe* p) { delete p; }
+
+}  // extern "C"

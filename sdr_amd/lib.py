@@ -1,0 +1,406 @@
+"""ctypes binding of libsdr_hip.so -- the ONLY way Python reaches the product.
+
+There is no CPU fallback: if the HIP library is missing or fails to load, import
+of this module raises.  (The CPU oracle lives under oracle/ and is never imported
+from here.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libsdr_hip.so")
+
+ORDER_SCALAR, ORDER_SSE, ORDER_AVX = 0, 1, 2
+
+_f32p = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+_i16p = C.POINTER(C.c_int16)
+_i32p = C.POINTER(C.c_int)
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+
+class SdrHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise SdrHipError(
+            f"{LIB_PATH} not found: build it with `python -m sdr_amd.build` "
+            "(there is deliberately no CPU fallback)")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+# ---- signatures -----------------------------------------------------------------
+lib.sdrhip_version.restype = C.c_char_p
+lib.sdrhip_last_error.restype = C.c_char_p
+lib.sdrhip_device_name.argtypes = [C.c_char_p, C.c_int]
+lib.sdrhip_malloc.argtypes = [C.POINTER(_vp), C.c_size_t]
+lib.sdrhip_free.argtypes = [_vp]
+lib.sdrhip_malloc_host.argtypes = [C.POINTER(_vp), C.c_size_t]
+lib.sdrhip_free_host.argtypes = [_vp]
+for _n in ("sdrhip_memcpy_h2d", "sdrhip_memcpy_d2h", "sdrhip_memcpy_d2d"):
+    getattr(lib, _n).argtypes = [_vp, _vp, C.c_size_t, _vp]
+lib.sdrhip_stream_create.argtypes = [C.POINTER(_vp)]
+lib.sdrhip_stream_destroy.argtypes = [_vp]
+lib.sdrhip_stream_sync.argtypes = [_vp]
+
+lib.sdrhip_filter_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, _f32p, C.c_int]
+lib.sdrhip_filter_sym_create.argtypes = [C.POINTER(_vp), C.c_int, _f32p, C.c_int]
+lib.sdrhip_filter_num_coeffs.argtypes = [_vp]
+lib.sdrhip_filter_destroy.argtypes = [_vp]
+lib.sdrhip_filter_destroy.restype = None
+lib.sdrhip_filter_run.argtypes = [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64]
+
+lib.sdrhip_decimator_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _f32p, C.c_int]
+lib.sdrhip_decimator_sym_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, _f32p, C.c_int]
+lib.sdrhip_decimator_num_coeffs.argtypes = [_vp]
+lib.sdrhip_decimator_factor.argtypes = [_vp]
+lib.sdrhip_decimator_destroy.argtypes = [_vp]
+lib.sdrhip_decimator_destroy.restype = None
+lib.sdrhip_decimator_run.argtypes = [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64]
+lib.sdrhip_decimator_run_u8.argtypes = [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64]
+
+lib.sdrhip_resampler_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]
+lib.sdrhip_resampler_num_coeffs.argtypes = [_vp]
+lib.sdrhip_resampler_num_groups.argtypes = [_vp]
+lib.sdrhip_resampler_destroy.argtypes = [_vp]
+lib.sdrhip_resampler_destroy.restype = None
+lib.sdrhip_resampler_in_offset.argtypes = [_vp, _i64]
+lib.sdrhip_resampler_in_offset.restype = _i64
+lib.sdrhip_resampler_filter_offset.argtypes = [_vp, _i64]
+lib.sdrhip_resampler_group.argtypes = [_vp, _i64]
+lib.sdrhip_resampler_run.argtypes = [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64]
+
+lib.sdrhip_convert_u8_run.argtypes = [_vp, _vp, _vp, _i64]
+lib.sdrhip_convert_i16_run.argtypes = [_vp, _vp, _vp, _i64]
+lib.sdrhip_scale_run.argtypes = [_vp, C.c_float, _vp, _vp, _i64]
+lib.sdrhip_fm_demod_run.argtypes = [_vp, _vp, _i64, _vp, _i64, _i64, C.c_float, C.c_float]
+
+lib.sdrhip_fm_chain_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, _f32p,
+                                       C.c_int, _f32p, C.c_int, C.c_float, _i64]
+lib.sdrhip_fm_chain_destroy.argtypes = [_vp]
+lib.sdrhip_fm_chain_destroy.restype = None
+lib.sdrhip_fm_chain_plan.argtypes = [_vp, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
+lib.sdrhip_fm_chain_max_halo.argtypes = [_vp]
+lib.sdrhip_fm_chain_max_halo.restype = _i64
+lib.sdrhip_fm_chain_workspace_bytes.argtypes = [_vp, _i64]
+lib.sdrhip_fm_chain_workspace_bytes.restype = C.c_size_t
+lib.sdrhip_fm_chain_run.argtypes = [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, C.c_size_t]
+
+lib.sdrhip_pipe_fir_filter.argtypes = [C.POINTER(_vp), _vp, C.c_int]
+lib.sdrhip_pipe_fir_decimator.argtypes = [C.POINTER(_vp), _vp, C.c_int]
+lib.sdrhip_pipe_fir_resampler.argtypes = [C.POINTER(_vp), _vp, C.c_int]
+lib.sdrhip_pipe_fm_demod.argtypes = [C.POINTER(_vp)]
+lib.sdrhip_pipe_push.argtypes = [_vp, _f32p, C.c_int]
+lib.sdrhip_pipe_flush.argtypes = [_vp]
+lib.sdrhip_pipe_pop.argtypes = [_vp, _f32p, C.c_int]
+lib.sdrhip_pipe_destroy.argtypes = [_vp]
+lib.sdrhip_pipe_destroy.restype = None
+
+lib.scale.argtypes = [C.c_int, C.c_float, _f32p, _f32p]
+lib.scaleSSE.argtypes = [C.c_int, C.c_float, _f32p, _f32p]
+lib.scaleAVX.argtypes = [C.c_int, C.c_float, _f32p, _f32p]
+lib.fmDemodF.argtypes = [C.c_int, C.c_float, C.c_float, _f32p, _f32p]
+lib.dcBlocker.argtypes = [C.c_int, C.c_float, C.c_float, _f32p, _f32p, _f32p, _f32p]
+for _n in ("resample2RR", "resampleSSERR", "resampleAVXRR", "resample2RC", "resampleSSERC", "resampleAVXRC"):
+    getattr(lib, _n).restype = C.c_int
+
+
+def check(rc, what="sdrhip call"):
+    if rc < 0:
+        raise SdrHipError(f"{what} failed ({rc}): {lib.sdrhip_last_error().decode()}")
+    return rc
+
+
+def version():
+    return lib.sdrhip_version().decode()
+
+
+def device_count():
+    return lib.sdrhip_device_count()
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    check(lib.sdrhip_device_name(buf, 256), "sdrhip_device_name")
+    return buf.value.decode()
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p)
+
+
+# ---- drop-in symbols on numpy host arrays (what the Haskell FFI would call) ----------
+class DropIn:
+    """Calls the reference-named symbols exactly as FilterInternal.hs's wrappers do."""
+
+    @staticmethod
+    def convert(sym, u8):
+        u8 = np.ascontiguousarray(u8, dtype=np.uint8)
+        out = np.empty(u8.size, np.float32)
+        getattr(lib, sym)(C.c_int(u8.size), u8.ctypes.data_as(_u8p), _fp(out))
+        return out
+
+    @staticmethod
+    def convert_i16(sym, i16):
+        i16 = np.ascontiguousarray(i16, dtype=np.int16)
+        out = np.empty(i16.size, np.float32)
+        getattr(lib, sym)(C.c_int(i16.size), i16.ctypes.data_as(_i16p), _fp(out))
+        return out
+
+    @staticmethod
+    def convert_tx(x):
+        x = _f32(x)
+        out = np.empty(x.size, np.int16)
+        lib.convertBladeRFTransmit(C.c_int(x.size), _fp(x), out.ctypes.data_as(_i16p))
+        return out
+
+    @staticmethod
+    def scale(sym, factor, x):
+        x = _f32(x)
+        out = np.empty_like(x)
+        getattr(lib, sym)(x.size, C.c_float(factor), _fp(x), _fp(out))
+        return out
+
+    @staticmethod
+    def filt(sym, num, coeffs_as_passed, x, complex_=False):
+        c, x = _f32(coeffs_as_passed), _f32(x)
+        out = np.empty(num * (2 if complex_ else 1), np.float32)
+        getattr(lib, sym)(C.c_int(num), C.c_int(c.size), _fp(c), _fp(x), _fp(out))
+        return out
+
+    @staticmethod
+    def decim(sym, num, factor, coeffs_as_passed, x, complex_=False):
+        c, x = _f32(coeffs_as_passed), _f32(x)
+        out = np.empty(num * (2 if complex_ else 1), np.float32)
+        getattr(lib, sym)(C.c_int(num), C.c_int(factor), C.c_int(c.size), _fp(c), _fp(x), _fp(out))
+        return out
+
+    @staticmethod
+    def resample(sym, buf_size, num_coeffs, starting_group, increments, groups, x, complex_=False):
+        x = _f32(x)
+        out = np.empty(buf_size * (2 if complex_ else 1), np.float32)
+        rows = [np.ascontiguousarray(g, dtype=np.float32) for g in groups]
+        arr = (_f32p * len(rows))(*[_fp(r) for r in rows])
+        inc = np.ascontiguousarray(increments, np.int32)
+        g = getattr(lib, sym)(C.c_int(buf_size), C.c_int(num_coeffs), C.c_int(starting_group), C.c_int(len(rows)),
+                              inc.ctypes.data_as(_i32p), arr, _fp(x), _fp(out))
+        return out, g
+
+    @staticmethod
+    def resample_legacy(buf_size, interp, decim, filter_offset, coeffs, x):
+        coeffs, x = _f32(coeffs), _f32(x)
+        out = np.empty(buf_size, np.float32)
+        lib.resampleRR(C.c_int(buf_size), C.c_int(coeffs.size), C.c_int(interp), C.c_int(decim),
+                       C.c_int(filter_offset), _fp(coeffs), _fp(x), _fp(out))
+        return out
+
+    @staticmethod
+    def fm_demod(x_iq, last=(0.0, 0.0)):
+        x = _f32(x_iq)
+        n = x.size // 2
+        out = np.empty(n, np.float32)
+        lib.fmDemodF(n, C.c_float(last[0]), C.c_float(last[1]), _fp(x), _fp(out))
+        return out
+
+    @staticmethod
+    def dc_blocker(x, last_sample=0.0, last_output=0.0):
+        x = _f32(x)
+        out = np.empty_like(x)
+        fs, fo = C.c_float(), C.c_float()
+        lib.dcBlocker(x.size, C.c_float(last_sample), C.c_float(last_output), C.byref(fs), C.byref(fo), _fp(x), _fp(out))
+        return out, fs.value, fo.value
+
+
+# ---- descriptors ----------------------------------------------------------------------
+class _Handle:
+    _destroy = None
+
+    def __init__(self):
+        self.h = _vp()
+
+    def close(self):
+        if self.h:
+            type(self)._destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Filter(_Handle):
+    """fastFilter{C,SSE,AVX}{R,C} / fastFilterSym{SSE,AVX}R (Filter.hs:163-261)."""
+    _destroy = lib.sdrhip_filter_destroy
+
+    def __init__(self, coeffs, order=ORDER_AVX, complex_=False, sym=False):
+        super().__init__()
+        c = _f32(coeffs)
+        if sym:
+            check(lib.sdrhip_filter_sym_create(C.byref(self.h), order, _fp(c), c.size), "sdrhip_filter_sym_create")
+        else:
+            check(lib.sdrhip_filter_create(C.byref(self.h), order, int(complex_), _fp(c), c.size), "sdrhip_filter_create")
+        self.complex = complex_
+        self.num_coeffs = lib.sdrhip_filter_num_coeffs(self.h)
+
+    def run(self, d_in, in_base, d_out, k_begin, k_end, seam_block=0, stream=None):
+        check(lib.sdrhip_filter_run(self.h, stream, d_in, in_base, d_out, k_begin, k_end, seam_block), "sdrhip_filter_run")
+
+
+class Decimator(_Handle):
+    """fastDecimator{C,SSE,AVX}{R,C} / fastDecimatorSym{SSE,AVX}R (Filter.hs:277-387)."""
+    _destroy = lib.sdrhip_decimator_destroy
+
+    def __init__(self, factor, coeffs, order=ORDER_AVX, complex_=False, sym=False):
+        super().__init__()
+        c = _f32(coeffs)
+        if sym:
+            check(lib.sdrhip_decimator_sym_create(C.byref(self.h), order, factor, _fp(c), c.size), "sdrhip_decimator_sym_create")
+        else:
+            check(lib.sdrhip_decimator_create(C.byref(self.h), order, int(complex_), factor, _fp(c), c.size), "sdrhip_decimator_create")
+        self.complex = complex_
+        self.factor = factor
+        self.num_coeffs = lib.sdrhip_decimator_num_coeffs(self.h)
+
+    def run(self, d_in, in_base, d_out, k_begin, k_end, seam_block=0, stream=None):
+        check(lib.sdrhip_decimator_run(self.h, stream, d_in, in_base, d_out, k_begin, k_end, seam_block), "sdrhip_decimator_run")
+
+    def run_u8(self, d_in, in_base, d_out, k_begin, k_end, seam_block=0, stream=None):
+        check(lib.sdrhip_decimator_run_u8(self.h, stream, d_in, in_base, d_out, k_begin, k_end, seam_block), "sdrhip_decimator_run_u8")
+
+
+class Resampler(_Handle):
+    """fastResampler{C,SSE,AVX}{R,C} (Filter.hs:408-502)."""
+    _destroy = lib.sdrhip_resampler_destroy
+
+    def __init__(self, interpolation, decimation, coeffs, order=ORDER_AVX, complex_=False):
+        super().__init__()
+        c = _f32(coeffs)
+        check(lib.sdrhip_resampler_create(C.byref(self.h), order, int(complex_), interpolation, decimation, _fp(c), c.size),
+              "sdrhip_resampler_create")
+        self.complex = complex_
+        self.I, self.D = interpolation, decimation
+        self.num_coeffs = lib.sdrhip_resampler_num_coeffs(self.h)
+        self.num_groups = lib.sdrhip_resampler_num_groups(self.h)
+
+    def in_offset(self, m):
+        return lib.sdrhip_resampler_in_offset(self.h, m)
+
+    def filter_offset(self, m):
+        return lib.sdrhip_resampler_filter_offset(self.h, m)
+
+    def group(self, m):
+        return lib.sdrhip_resampler_group(self.h, m)
+
+    def run(self, d_in, in_base, d_out, k_begin, k_end, seam_block=0, stream=None):
+        check(lib.sdrhip_resampler_run(self.h, stream, d_in, in_base, d_out, k_begin, k_end, seam_block), "sdrhip_resampler_run")
+
+
+class FmChain(_Handle):
+    """The FM receiver of examples/fm/fm.hs:34-41 as one device-resident object."""
+    _destroy = lib.sdrhip_fm_chain_destroy
+
+    def __init__(self, decim_factor, decim_taps, interpolation, decimation, resamp_taps, audio_half_taps,
+                 gain=1.0, block=8192, order=ORDER_AVX):
+        super().__init__()
+        a, b, c = _f32(decim_taps), _f32(resamp_taps), _f32(audio_half_taps)
+        check(lib.sdrhip_fm_chain_create(C.byref(self.h), order, decim_factor, _fp(a), a.size, interpolation,
+                                         decimation, _fp(b), b.size, _fp(c), c.size, C.c_float(gain), block),
+              "sdrhip_fm_chain_create")
+
+    def plan(self, s0, s1, total_in=-1):
+        q0, q1, halo = _i64(), _i64(), _i64()
+        check(lib.sdrhip_fm_chain_plan(self.h, s0, s1, total_in, C.byref(q0), C.byref(q1), C.byref(halo)), "sdrhip_fm_chain_plan")
+        return q0.value, q1.value, halo.value
+
+    def max_halo(self):
+        return lib.sdrhip_fm_chain_max_halo(self.h)
+
+    def workspace_bytes(self, n_in):
+        return lib.sdrhip_fm_chain_workspace_bytes(self.h, n_in)
+
+    def run(self, d_in_u8, s0, n_in, d_audio, q0, q1, d_ws, ws_bytes, stream=None):
+        check(lib.sdrhip_fm_chain_run(self.h, stream, d_in_u8, s0, n_in, d_audio, q0, q1, d_ws, ws_bytes), "sdrhip_fm_chain_run")
+
+
+class Pipe(_Handle):
+    """firFilter / firDecimator / firResampler / fmDemod on host blocks (Filter.hs:532-727, Demod.hs:40-46)."""
+    _destroy = lib.sdrhip_pipe_destroy
+
+    def __init__(self, kind, desc=None, block_size_out=8192):
+        super().__init__()
+        self.desc = desc  # keep the descriptor alive
+        self.block_size_out = block_size_out
+        self.complex_in = bool(getattr(desc, "complex", False)) or kind == "fm_demod"
+        self.complex_out = bool(getattr(desc, "complex", False))
+        if kind == "filter":
+            check(lib.sdrhip_pipe_fir_filter(C.byref(self.h), desc.h, block_size_out), "sdrhip_pipe_fir_filter")
+        elif kind == "decimator":
+            check(lib.sdrhip_pipe_fir_decimator(C.byref(self.h), desc.h, block_size_out), "sdrhip_pipe_fir_decimator")
+        elif kind == "resampler":
+            check(lib.sdrhip_pipe_fir_resampler(C.byref(self.h), desc.h, block_size_out), "sdrhip_pipe_fir_resampler")
+        elif kind == "fm_demod":
+            check(lib.sdrhip_pipe_fm_demod(C.byref(self.h)), "sdrhip_pipe_fm_demod")
+        else:
+            raise ValueError(kind)
+        self.kind = kind
+
+    def push(self, block):
+        """block: float32 array (interleaved for complex stages).  Returns list of output blocks."""
+        b = _f32(block)
+        n = b.size // (2 if self.complex_in else 1)
+        self._cap = max(getattr(self, "_cap", 0), self.block_size_out, n)
+        ready = check(lib.sdrhip_pipe_push(self.h, _fp(b), n), "sdrhip_pipe_push")
+        return self._pop(ready)
+
+    def flush(self):
+        ready = check(lib.sdrhip_pipe_flush(self.h), "sdrhip_pipe_flush")
+        return self._pop(ready)
+
+    def _pop(self, ready):
+        outs = []
+        cap = max(getattr(self, "_cap", 0), self.block_size_out) * (2 if self.complex_out else 1)
+        for _ in range(ready):
+            o = np.empty(cap, np.float32)
+            got = check(lib.sdrhip_pipe_pop(self.h, _fp(o), cap // (2 if self.complex_out else 1)), "sdrhip_pipe_pop")
+            outs.append(o[: got * (2 if self.complex_out else 1)].copy())
+        return outs
+
+
+# Operator-surface aliases with the reference's names (SDR.Filter / SDR.Demod / SDR.Util)
+def firFilter(filt, block_size_out):
+    return Pipe("filter", filt, block_size_out)
+
+
+def firDecimator(decimator, block_size_out):
+    return Pipe("decimator", decimator, block_size_out)
+
+
+def firResampler(resampler, block_size_out):
+    return Pipe("resampler", resampler, block_size_out)
+
+
+def fmDemod():
+    return Pipe("fm_demod")
+
+
+def interleavedIQUnsignedByteToFloat(u8):
+    """Util.hs:104-110: u8 IQ -> complex64 (length len/2)."""
+    return DropIn.convert("convertC", u8).view(np.complex64)
+
+
+def interleavedIQUnsignedByteToFloatFast(u8):
+    """Util.hs:137-138 (featureSelect -> AVX2 variant)."""
+    return DropIn.convert("convertCAVX", u8).view(np.complex64)

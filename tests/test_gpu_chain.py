@@ -1,0 +1,116 @@
+"""GPU parity: the whole FM receiver (examples/fm/fm.hs:34-41) as one device-resident
+chain vs the restated Pipes, single launch and sharded with a right halo."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from oracle import pipes_model as PM
+import signals as S
+from gpu_util import to_dev, dev_empty_f32, ptr, to_host
+import torch
+
+pytestmark = pytest.mark.gpu
+
+B = 8192
+
+
+def _chain(hip, gain=0.2, block=B, order=None):
+    return hip.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), gain, block,
+                       hip.ORDER_AVX if order is None else order)
+
+
+def _model(oracle, u8, nblk, gain=0.2, block=B, order=PM.ORDER_AVX):
+    blocks = [u8[2 * i * block:2 * (i + 1) * block] for i in range(nblk)]
+    out = PM.fm_receiver(oracle, blocks, S.taps_decim127(), 8, S.taps_resamp191(), 3, 10, S.taps_audio_half64(),
+                         gain, block, order)
+    return np.concatenate(out) if out else np.zeros(0, np.float32)
+
+
+def _run(hip, chain, u8_dev, s0, n_in, q0, q1):
+    ws_bytes = chain.workspace_bytes(n_in)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    out = dev_empty_f32(q1 - q0)
+    chain.run(ptr(u8_dev), s0, n_in, ptr(out), q0, q1, ptr(ws), ws_bytes)
+    return to_host(out)
+
+
+@pytest.mark.parametrize("fm_signal", [False, True])
+def test_chain_matches_pipes(hip, oracle, fm_signal):
+    # 8192 audio samples need 8192*80/3 ~ 218k input samples = 27 blocks; use 60 -> 2 audio blocks
+    nblk = 60
+    u8 = (S.iq_u8_fm if fm_signal else S.iq_u8)(nblk * B)
+    exp = _model(oracle, u8, nblk)
+    assert exp.size == 2 * B
+    chain = _chain(hip)
+    total = nblk * B
+    q0, q1, halo = chain.plan(0, total, total)
+    assert q0 == 0 and halo == 0 and q1 >= exp.size
+    got = _run(hip, chain, to_dev(u8), 0, total, 0, q1)
+    assert_bit_equal(got[: exp.size], exp, "chain vs pipes")
+
+
+def test_chain_sharded_equals_single(hip, oracle):
+    """Shards + right halo (what each GPU does after the halo exchange) reproduce the single stream."""
+    nblk = 40
+    total = nblk * B
+    u8 = S.iq_u8(total)
+    chain = _chain(hip)
+    Q0, Q1, _ = chain.plan(0, total, total)
+    full = _run(hip, chain, to_dev(u8), 0, total, Q0, Q1)
+    max_halo = chain.max_halo()
+    assert 0 < max_halo < 8192
+    for nshards in (2, 4, 5):
+        S_len = total // nshards // 8 * 8
+        pieces = []
+        for r in range(nshards):
+            s0 = r * S_len
+            s1 = total if r == nshards - 1 else (r + 1) * S_len
+            q0, q1, halo = chain.plan(s0, s1, total)
+            assert halo <= max_halo
+            n_in = min(total, s1 + halo) - s0
+            shard = to_dev(u8[2 * s0: 2 * (s0 + n_in)])
+            pieces.append((q0, q1, _run(hip, chain, shard, s0, n_in, q0, q1)))
+        assert pieces[0][0] == Q0 and pieces[-1][1] == Q1
+        for (a0, a1, _), (b0, b1, _) in zip(pieces[:-1], pieces[1:]):
+            assert a1 == b0
+        got = np.concatenate([p[2] for p in pieces])
+        assert_bit_equal(got, full, f"{nshards} shards")
+
+
+def test_chain_contiguous_and_orders(hip, oracle):
+    """block = 0 (no seams) and the SSE order."""
+    total = 30 * B
+    u8 = S.iq_u8(total)
+    # SSE order with seams vs the model
+    exp = _model(oracle, u8, 30, gain=None, order=PM.ORDER_SSE)
+    chain = _chain(hip, gain=1.0, order=hip.ORDER_SSE)
+    q0, q1, _ = chain.plan(0, total, total)
+    got = _run(hip, chain, to_dev(u8), 0, total, q0, q1)
+    assert_bit_equal(got[: exp.size], exp, "SSE chain")
+    # contiguous: equals the stage-by-stage C kernels on whole buffers
+    chain0 = _chain(hip, gain=1.0, block=0)
+    q0, q1, _ = chain0.plan(0, total, total)
+    got = _run(hip, chain0, to_dev(u8), 0, total, q0, q1)
+    x = oracle.convert_u8(u8)
+    h = np.concatenate([S.taps_decim127(), np.zeros(1, np.float32)])
+    K = (total - 128) // 8 + 1
+    d = oracle.decimate_rc(4, K, 8, np.repeat(h, 2), x)
+    y = oracle.fm_demod(d)
+    prep = oracle.prepare_coeffs(8, 3, 10, S.taps_resamp191())
+    M = (K * 3 - 192) // 10 + 1
+    z, _ = oracle.resample_rr(8, M, prep, 0, y)
+    a = oracle.filter_sym_rr(8, M - 127, S.taps_audio_half64(), z)
+    assert q1 == a.size
+    assert_bit_equal(got, a, "contiguous chain")
+
+
+def test_chain_rejects_missing_halo(hip):
+    chain = _chain(hip)
+    total = 20 * B
+    u8 = to_dev(S.iq_u8(total))
+    q0, q1, halo = chain.plan(0, total // 2, total)
+    assert halo > 0
+    ws = torch.empty(chain.workspace_bytes(total), dtype=torch.uint8, device="cuda")
+    out = dev_empty_f32(q1 - q0)
+    with pytest.raises(hip.SdrHipError):
+        chain.run(ptr(u8), 0, total // 2, ptr(out), q0, q1, ptr(ws), ws.numel())  # halo not provided

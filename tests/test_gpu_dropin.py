@@ -1,0 +1,190 @@
+"""GPU parity, layer (1): every drop-in symbol against the CPU oracle, bit for bit.
+
+Mirrors the reference's QuickCheck differential properties (tests/TestSuite.hs:32-50:
+every variant on the same random input must agree) with the oracle as the first
+element -- but with bit equality instead of the reference's 0.01 tolerance, because
+each variant keeps its own summation order.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from oracle.oracle import duplicate
+import signals as S
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1024, 8192]
+FACTORS = [1, 2, 3, 5, 7, 8, 11, 13, 17, 23]   # TestSuite.hs:57 (+ the FM chain's 8)
+
+
+def test_convert_u8_all_bytes(hip, oracle):
+    u8 = np.arange(256, dtype=np.uint8).repeat(3)
+    for sym in ("convertC", "convertCSSE", "convertCAVX"):
+        assert_bit_equal(hip.DropIn.convert(sym, u8), oracle.convert_u8(u8), sym)
+
+
+@pytest.mark.parametrize("n", [1, 7, 15, 16, 17, 255, 4096, 16384, 16391])
+def test_convert_u8_ragged(hip, oracle, n):
+    u8 = S.iq_u8(n)[:n]
+    assert_bit_equal(hip.DropIn.convert("convertCAVX", u8), oracle.convert_u8(u8), f"convertCAVX n={n}")
+
+
+def test_convert_bladerf_and_scale(hip, oracle):
+    rng = np.random.default_rng(5)
+    i16 = rng.integers(-2048, 2048, 5000, dtype=np.int16)
+    for sym in ("convertCBladeRF", "convertCSSEBladeRF", "convertCAVXBladeRF"):
+        assert_bit_equal(hip.DropIn.convert_i16(sym, i16), oracle.convert_i16(i16), sym)
+    x = S.real_block(5001)
+    for sym in ("scale", "scaleSSE", "scaleAVX"):
+        assert_bit_equal(hip.DropIn.scale(sym, 0.2, x), oracle.scale(0.2, x), sym)
+    tx = hip.DropIn.convert_tx(x)
+    exp = (np.floor((x + np.float32(1)) * np.float32(2048)).astype(np.int32) - 2048).clip(-2048, 2047).astype(np.int16)
+    assert np.array_equal(tx, exp)
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("ntaps", [32, 128, 512])
+def test_filters_real(hip, oracle, n, ntaps):
+    x = S.real_block(n, lo=-10, hi=10)
+    h = np.random.default_rng(ntaps).uniform(-10, 10, ntaps).astype(np.float32)
+    num = n - ntaps + 1
+    for L, sym in ((1, "filterRR"), (4, "filterSSERR"), (8, "filterAVXRR")):
+        assert_bit_equal(hip.DropIn.filt(sym, num, h, x), oracle.filter_rr(L, num, h, x), sym)
+    half = h[: ntaps // 2]
+    for L, sym in ((4, "filterSSESymmetricRR"), (8, "filterAVXSymmetricRR")):
+        assert_bit_equal(hip.DropIn.filt(sym, num, half, x), oracle.filter_sym_rr(L, num, half, x), sym)
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("ntaps", [32, 128])
+def test_filters_complex(hip, oracle, n, ntaps):
+    x = S.cfloat_block(n, lo=-10, hi=10)
+    h = np.random.default_rng(ntaps + 1).uniform(-10, 10, ntaps).astype(np.float32)
+    num = n - ntaps + 1
+    hd = duplicate(h)
+    assert_bit_equal(hip.DropIn.filt("filterRC", num, h, x, True), oracle.filter_rc(1, num, h, x), "filterRC")
+    for CL, sym in ((2, "filterSSERC"), (4, "filterAVXRC")):
+        assert_bit_equal(hip.DropIn.filt(sym, num, hd, x, True), oracle.filter_rc(CL, num, hd, x), sym)
+    for CL, sym in ((2, "filterSSERC2"), (4, "filterAVXRC2")):
+        assert_bit_equal(hip.DropIn.filt(sym, num, h, x, True), oracle.decimate_rc2(CL, num, 1, h, x), sym)
+    half = h[: ntaps // 2]
+    for CL, sym in ((2, "filterSSESymmetricRC"), (4, "filterAVXSymmetricRC")):
+        assert_bit_equal(hip.DropIn.filt(sym, num, half, x, True), oracle.decimate_sym_rc(CL, num, 1, half, x), sym)
+
+
+@pytest.mark.parametrize("factor", FACTORS)
+def test_decimators_real(hip, oracle, factor):
+    n, ntaps = 8192, 128
+    x = S.real_block(n, lo=-10, hi=10)
+    h = np.random.default_rng(factor).uniform(-10, 10, ntaps).astype(np.float32)
+    num = (n - ntaps) // factor + 1
+    for L, sym in ((1, "decimateRR"), (4, "decimateSSERR"), (8, "decimateAVXRR")):
+        assert_bit_equal(hip.DropIn.decim(sym, num, factor, h, x), oracle.decimate_rr(L, num, factor, h, x), sym)
+    half = h[:64]
+    for L, sym in ((4, "decimateSSESymmetricRR"), (8, "decimateAVXSymmetricRR")):
+        assert_bit_equal(hip.DropIn.decim(sym, num, factor, half, x), oracle.decimate_sym_rr(L, num, factor, half, x), sym)
+
+
+@pytest.mark.parametrize("factor", FACTORS)
+@pytest.mark.parametrize("ntaps", [64, 128])
+def test_decimators_complex(hip, oracle, factor, ntaps):
+    n = 8192
+    x = S.cfloat_block(n, lo=-10, hi=10)
+    h = np.random.default_rng(factor * 7 + ntaps).uniform(-10, 10, ntaps).astype(np.float32)
+    num = (n - ntaps) // factor + 1
+    hd = duplicate(h)
+    assert_bit_equal(hip.DropIn.decim("decimateRC", num, factor, h, x, True), oracle.decimate_rc(1, num, factor, h, x), "decimateRC")
+    for CL, sym in ((2, "decimateSSERC"), (4, "decimateAVXRC")):
+        assert_bit_equal(hip.DropIn.decim(sym, num, factor, hd, x, True), oracle.decimate_rc(CL, num, factor, hd, x), sym)
+    for CL, sym in ((2, "decimateSSERC2"), (4, "decimateAVXRC2")):
+        assert_bit_equal(hip.DropIn.decim(sym, num, factor, h, x, True), oracle.decimate_rc2(CL, num, factor, h, x), sym)
+    half = h[: ntaps // 2]
+    for CL, sym in ((2, "decimateSSESymmetricRC"), (4, "decimateAVXSymmetricRC")):
+        assert_bit_equal(hip.DropIn.decim(sym, num, factor, half, x, True), oracle.decimate_sym_rc(CL, num, factor, half, x), sym)
+
+
+def test_decimate_avxrc_config2(hip, oracle, ref):
+    """BASELINE configs[1]: 127 taps -> 128, /8, one 8192-sample block -> 1009 outputs;
+    also against the reference's own compiled decimateAVXRC when oracle/_ref exists."""
+    x = S.cfloat_block(8192)
+    h = np.concatenate([S.taps_decim127(), np.zeros(1, np.float32)])
+    hd = duplicate(h)
+    got = hip.DropIn.decim("decimateAVXRC", 1009, 8, hd, x, True)
+    assert_bit_equal(got, oracle.decimate_rc(4, 1009, 8, hd, x), "vs oracle")
+    assert_bit_equal(got, ref.decim("decimateAVXRC", 1009, 8, hd, x, True), "vs reference build")
+
+
+def test_decimate_avxrc_non_duplicated_taps(hip, oracle):
+    """The 'duplicated' array is honoured as passed (re uses even, im uses odd entries)."""
+    x = S.cfloat_block(2048)
+    c = S.gauss_taps(256, 9)  # 128 complex taps with DIFFERENT re/im coefficients
+    num = (2048 - 128) // 8 + 1
+    assert_bit_equal(hip.DropIn.decim("decimateAVXRC", num, 8, c, x, True), oracle.decimate_rc(4, num, 8, c, x), "odd taps")
+
+
+@pytest.mark.parametrize("I,D", [(3, 10), (2, 3), (1, 2), (5, 7), (7, 11), (3, 23), (13, 17), (2, 4)])
+@pytest.mark.parametrize("ntaps", [32, 191, 512])
+def test_resamplers(hip, oracle, I, D, ntaps):
+    n = 8192
+    h = np.random.default_rng(I * 100 + D + ntaps).uniform(-10, 10, ntaps).astype(np.float32)
+    x = S.real_block(n, lo=-10, hi=10)
+    xc = S.cfloat_block(n, lo=-10, hi=10)
+    for L, sym, csym, CL in ((1, "resample2RR", "resample2RC", 1), (4, "resampleSSERR", "resampleSSERC", 2),
+                             (8, "resampleAVXRR", "resampleAVXRC", 4)):
+        prep = oracle.prepare_coeffs(L, I, D, h)
+        ng = prep["num_groups"]
+        period = int(prep["increments"].sum())
+        count = ((n - prep["padded_len"] - period) // period) * ng
+        for start in sorted({0, ng - 1}):
+            a, ga = oracle.resample_rr(L, count, prep, start, x)
+            b, gb = hip.DropIn.resample(sym, count, prep["num_coeffs"], start, prep["increments"], prep["groups"], x)
+            assert_bit_equal(b, a, f"{sym} start={start}")
+            assert ga == gb
+            a, ga = oracle.resample_rc(CL, count, prep, start, xc)
+            b, gb = hip.DropIn.resample(csym, count, prep["num_coeffs"], start, prep["increments"], prep["groups"], xc, True)
+            assert_bit_equal(b, a, f"{csym} start={start}")
+            assert ga == gb
+    cnt = (n * I - ntaps) // D - 2
+    for fo in range(min(I, 3)):
+        assert_bit_equal(hip.DropIn.resample_legacy(cnt, I, D, fo, h, x), oracle.resample_legacy_rr(cnt, I, D, fo, h, x), "resampleRR")
+
+
+def test_resample_config4(hip, oracle, ref):
+    """BASELINE configs[3]: 3/10, 191 taps, one 65536-float block -> 19642 outputs, end group 1."""
+    h = S.taps_resamp191()
+    x = S.real_block(65536)
+    prep = oracle.prepare_coeffs(8, 3, 10, h)
+    assert list(prep["increments"]) == [4, 3, 3] and list(prep["offsets"]) == [0, 2, 1]
+    got, g = hip.DropIn.resample("resampleAVXRR", 19642, prep["num_coeffs"], 0, prep["increments"], prep["groups"], x)
+    exp, ge = ref.resample("resampleAVXRR", 19642, prep, 0, x)
+    assert g == ge == 1
+    assert_bit_equal(got, exp, "resampleAVXRR vs reference build")
+
+
+def test_fm_demod(hip, oracle):
+    rng = np.random.default_rng(77)
+    x = rng.uniform(-1, 1, 2 * 100000).astype(np.float32)
+    # special values: zeros, negative zeros, axes, repeated samples, denormals, huge ratios
+    sp = np.array([0, 0, -0.0, 0, 0, -0.0, -0.0, -0.0, 1, 0, -1, 0, 0, 1, 0, -1, -1, -0.0, 1e-40, 1e-40,
+                   1e-30, 1, 1, 1e-30, 1e30, 1e-8, -1e-8, 1e30, 0.5, 0.5, 0.5, 0.5, -0.5, 0.5, 3, -4],
+                  np.float32)
+    x[: sp.size] = sp
+    assert_bit_equal(hip.DropIn.fm_demod(x), oracle.fm_demod(x), "fmDemodF")
+    assert_bit_equal(hip.DropIn.fm_demod(x, (0.3, -0.7)), oracle.fm_demod(x, (0.3, -0.7)), "fmDemodF carried")
+    iq = oracle.convert_u8(S.iq_u8_fm(50000))
+    assert_bit_equal(hip.DropIn.fm_demod(iq), oracle.fm_demod(iq), "fmDemodF fm signal")
+
+
+def test_dc_blocker(hip, ref):
+    x = S.real_block(4096)
+    out, fs, fo = hip.DropIn.dc_blocker(x, 0.25, -0.5)
+    import ctypes as C
+    exp = np.empty_like(x)
+    efs, efo = C.c_float(), C.c_float()
+    ref.lib.dcBlocker.argtypes = [C.c_int, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                  C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    ref.lib.dcBlocker(x.size, 0.25, -0.5, C.byref(efs), C.byref(efo), x.ctypes.data_as(C.POINTER(C.c_float)),
+                      exp.ctypes.data_as(C.POINTER(C.c_float)))
+    assert_bit_equal(out, exp, "dcBlocker")
+    assert fs == efs.value and fo == efo.value

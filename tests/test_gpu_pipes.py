@@ -1,0 +1,135 @@
+"""GPU parity, layer (3): the host-block Pipe operators (firFilter / firDecimator /
+firResampler / fmDemod) against the restated reference Pipes, including ragged block
+sizes and the reference's assert on too-short blocks."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from oracle import pipes_model as PM
+import signals as S
+
+pytestmark = pytest.mark.gpu
+
+B = 8192
+
+
+def _drive(pipe, blocks):
+    outs = []
+    for b in blocks:
+        outs += pipe.push(b)
+    outs += pipe.flush()
+    return outs
+
+
+def _cmp(got, exp, what):
+    assert len(got) == len(exp), f"{what}: {len(got)} blocks vs {len(exp)}"
+    for i, (g, e) in enumerate(zip(got, exp)):
+        assert_bit_equal(g, e, f"{what} block {i}")
+
+
+def _cut(x, width, sizes):
+    out, pos = [], 0
+    for s in sizes:
+        out.append(x[pos * width:(pos + s) * width])
+        pos += s
+    return out
+
+
+def test_fir_decimator_pipe(hip, oracle):
+    x = oracle.convert_u8(S.iq_u8(10 * B))
+    blocks = _cut(x, 2, [B] * 10)
+    taps = S.taps_decim127()
+    exp, _ = PM.fir_decimator_pipe(PM.FilterModel(oracle, taps, PM.ORDER_AVX, complex_=True, factor=8), blocks, B)
+    dec = hip.Decimator(8, taps, hip.ORDER_AVX, complex_=True)
+    _cmp(_drive(hip.firDecimator(dec, B), blocks), exp, "firDecimator")
+    assert len(exp) == 1 and exp[0].size == 2 * B
+
+
+def test_fir_decimator_pipe_ragged(hip, oracle):
+    sizes = [4096, 8192, 1000, 20000, 777, 8192, 129, 5000]
+    x = S.cfloat_block(sum(sizes))
+    blocks = _cut(x, 2, sizes)
+    taps = S.gauss_taps(100, 11)
+    for order in (PM.ORDER_AVX, PM.ORDER_SCALAR):
+        exp, _ = PM.fir_decimator_pipe(PM.FilterModel(oracle, taps, order, complex_=True, factor=5), blocks, 700)
+        dec = hip.Decimator(5, taps, order, complex_=True)
+        _cmp(_drive(hip.firDecimator(dec, 700), blocks), exp, "ragged firDecimator")
+
+
+def test_fir_filter_pipe(hip, oracle):
+    x = S.real_block(6 * B)
+    blocks = _cut(x, 1, [B] * 6)
+    half = S.taps_audio_half64()
+    exp, _ = PM.fir_filter_pipe(PM.FilterModel(oracle, half, PM.ORDER_AVX, sym=True), blocks, B)
+    f = hip.Filter(half, hip.ORDER_AVX, sym=True)
+    _cmp(_drive(hip.firFilter(f, B), blocks), exp, "firFilter sym")
+    taps = S.gauss_taps(51, 2)
+    exp, _ = PM.fir_filter_pipe(PM.FilterModel(oracle, taps, PM.ORDER_SSE), blocks, 1000)
+    f = hip.Filter(taps, hip.ORDER_SSE)
+    _cmp(_drive(hip.firFilter(f, 1000), blocks), exp, "firFilter SSE")
+
+
+def test_fir_resampler_pipe(hip, oracle):
+    x = S.real_block(8 * B)
+    taps = S.taps_resamp191()
+    for sizes, bo in (([B] * 8, B), ([3000, 9000, 200, 8192, 8192, 65, 4000, 12000], 999)):
+        blocks = _cut(x, 1, sizes)
+        exp, _ = PM.fir_resampler_pipe(PM.ResamplerModel(oracle, 3, 10, taps, PM.ORDER_AVX), blocks, bo)
+        r = hip.Resampler(3, 10, taps, hip.ORDER_AVX)
+        _cmp(_drive(hip.firResampler(r, bo), blocks), exp, f"firResampler {sizes[0]}")
+
+
+def test_fm_demod_pipe(hip, oracle):
+    x = oracle.convert_u8(S.iq_u8_fm(3 * B + 100))
+    blocks = _cut(x, 2, [B, 100, B, B])
+    exp = PM.fm_demod_pipe(oracle, blocks)
+    _cmp(_drive(hip.fmDemod(), blocks), exp, "fmDemod")
+
+
+def test_convert_operator(hip, oracle):
+    u8 = S.iq_u8(B)
+    got = hip.interleavedIQUnsignedByteToFloatFast(u8)
+    assert got.dtype == np.complex64 and got.size == B
+    assert_bit_equal(got.view(np.float32), oracle.convert_u8(u8), "interleavedIQUnsignedByteToFloatFast")
+
+
+def test_pipe_short_block_asserts(hip, oracle):
+    """Filter.hs:544 `assert "filter 1"`: a buffer shorter than the filter is an error."""
+    f = hip.Filter(S.gauss_taps(128, 1), hip.ORDER_AVX)
+    p = hip.firFilter(f, 256)
+    with pytest.raises(hip.SdrHipError):
+        p.push(S.real_block(100))
+    with pytest.raises(PM.PipeAssert):
+        PM.fir_filter_pipe(PM.FilterModel(oracle, S.gauss_taps(128, 1), PM.ORDER_AVX), [S.real_block(100)], 256)
+
+
+def test_fm_receiver_as_composed_pipes(hip, oracle):
+    """fm.hs:34-41 composed from the four Pipe operators, host blocks end to end."""
+    nblk = 60
+    u8 = S.iq_u8_fm(nblk * B)
+    blocks = [u8[2 * i * B:2 * (i + 1) * B] for i in range(nblk)]
+    exp = PM.fm_receiver(oracle, blocks, S.taps_decim127(), 8, S.taps_resamp191(), 3, 10, S.taps_audio_half64(), 0.2)
+    assert len(exp) >= 1
+    deci = hip.firDecimator(hip.Decimator(8, S.taps_decim127(), hip.ORDER_AVX, complex_=True), B)
+    demod = hip.fmDemod()
+    resp = hip.firResampler(hip.Resampler(3, 10, S.taps_resamp191(), hip.ORDER_AVX), B)
+    filt = hip.firFilter(hip.Filter(S.taps_audio_half64(), hip.ORDER_AVX, sym=True), B)
+    audio = []
+
+    def feed(stage_idx, blk, stages):
+        if stage_idx == len(stages):
+            audio.append(hip.DropIn.scale("scaleAVX", 0.2, blk))
+            return
+        for o in stages[stage_idx](blk):
+            feed(stage_idx + 1, o, stages)
+
+    stages = [lambda b: deci.push(hip.interleavedIQUnsignedByteToFloatFast(b).view(np.float32)),
+              demod.push, resp.push, filt.push]
+    for b in blocks:
+        feed(0, b, stages)
+    # drain the double-buffer lag, upstream first
+    flushers = [deci.flush, demod.flush, resp.flush, filt.flush]
+    for i, fl in enumerate(flushers):
+        for o in fl():
+            feed(i + 1, o, stages)
+    _cmp(audio, exp, "composed FM receiver")

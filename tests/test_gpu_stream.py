@@ -1,0 +1,156 @@
+"""GPU parity, layer (2): the device stream API against the restated Pipes
+(oracle/pipes_model.py): One outputs in SIMD lane order, Cross outputs (seam
+straddlers) in sequential order, independent of how the stream is cut into launches."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from oracle import pipes_model as PM
+import signals as S
+from gpu_util import to_dev, dev_empty_f32, ptr, to_host
+
+pytestmark = pytest.mark.gpu
+
+B = 8192
+
+
+def _split(x, width, block):
+    n = x.size // width
+    return [x[i * block * width:(i + 1) * block * width] for i in range(n // block)]
+
+
+def _run_ranges(desc, d_in, in_total, out_width, K, seam, cuts, u8=False):
+    """Run [0,K) as several launches cut at `cuts`, each with its own in_base/slice of the input."""
+    out = dev_empty_f32(K * out_width)
+    edges = [0] + list(cuts) + [K]
+    for a, b in zip(edges[:-1], edges[1:]):
+        if b <= a:
+            continue
+        (desc.run_u8 if u8 else desc.run)(ptr(d_in), 0, ptr(out) + 4 * out_width * a, a, b, seam)
+    return to_host(out)
+
+
+@pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE, PM.ORDER_SCALAR])
+def test_decimator_complex_stream(hip, oracle, order):
+    nblk = 5
+    u8 = S.iq_u8(nblk * B)
+    x = oracle.convert_u8(u8)
+    taps = S.taps_decim127()
+    model = PM.FilterModel(oracle, taps, order, complex_=True, factor=8)
+    blocks, trace = PM.fir_decimator_pipe(model, _split(x, 2, B), 512)
+    if order == PM.ORDER_AVX:
+        assert trace[:4] == [("one", 512), ("one", 497), ("cross", 15), ("one", 512)]
+    exp = np.concatenate(blocks)
+    K = exp.size // 2
+    dec = hip.Decimator(8, taps, order, complex_=True)
+    assert dec.num_coeffs == model.num_coeffs
+    got = _run_ranges(dec, to_dev(x), nblk * B, 2, K, B, [])
+    assert_bit_equal(got, exp, "contiguous launch")
+    got = _run_ranges(dec, to_dev(x), nblk * B, 2, K, B, [1, 1000, 1009, 1024, 3000])
+    assert_bit_equal(got, exp, "cut into launches")
+    got = _run_ranges(dec, to_dev(u8), nblk * B, 2, K, B, [1024], u8=True)
+    assert_bit_equal(got, exp, "u8 input (convert fused)")
+
+
+def test_decimator_lone_block_is_all_one(hip, oracle):
+    """seam_block = 0: what one FFI call on one buffer computes (BASELINE configs[1])."""
+    x = S.cfloat_block(B)
+    taps = S.taps_decim127()
+    dec = hip.Decimator(8, taps, hip.ORDER_AVX, complex_=True)
+    got = _run_ranges(dec, to_dev(x), B, 2, 1009, 0, [])
+    h = np.concatenate([taps, np.zeros(1, np.float32)])
+    assert_bit_equal(got, oracle.decimate_rc(4, 1009, 8, np.repeat(h, 2), x), "lone block")
+
+
+@pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE])
+def test_filter_sym_stream(hip, oracle, order):
+    x = S.real_block(4 * B)
+    half = S.taps_audio_half64()
+    model = PM.FilterModel(oracle, half, order, sym=True)
+    blocks, trace = PM.fir_filter_pipe(model, _split(x, 1, B), 1024)
+    exp = np.concatenate(blocks)
+    f = hip.Filter(half, order, sym=True)
+    assert f.num_coeffs == 128
+    got = _run_ranges(f, to_dev(x), 4 * B, 1, exp.size, B, [8065, 8192, 9000])
+    assert_bit_equal(got, exp, "sym filter stream")
+
+
+@pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE, PM.ORDER_SCALAR])
+@pytest.mark.parametrize("complex_", [False, True])
+def test_filter_decimator_generic_stream(hip, oracle, order, complex_):
+    w = 2 if complex_ else 1
+    x = S.cfloat_block(3 * 4096) if complex_ else S.real_block(3 * 4096)
+    taps = S.gauss_taps(77, 3)
+    for factor in (1, 3, 7):
+        model = PM.FilterModel(oracle, taps, order, complex_=complex_, factor=factor)
+        blocks, _ = PM.fir_decimator_pipe(model, _split(x, w, 4096), 256)
+        exp = np.concatenate(blocks)
+        d = hip.Decimator(factor, taps, order, complex_=complex_)
+        got = _run_ranges(d, to_dev(x), 3 * 4096, w, exp.size // w, 4096, [100])
+        assert_bit_equal(got, exp, f"factor {factor}")
+
+
+@pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE, PM.ORDER_SCALAR])
+@pytest.mark.parametrize("complex_", [False, True])
+def test_resampler_stream(hip, oracle, order, complex_):
+    w = 2 if complex_ else 1
+    x = S.cfloat_block(4 * B) if complex_ else S.real_block(4 * B)
+    taps = S.taps_resamp191()
+    model = PM.ResamplerModel(oracle, 3, 10, taps, order, complex_)
+    blocks, trace = PM.fir_resampler_pipe(model, _split(x, w, B), 512)
+    if order == PM.ORDER_AVX and not complex_:
+        per_block = sum(c for k, c in trace[:12] if True)
+        assert ("cross", 19) in trace
+    exp = np.concatenate(blocks)
+    r = hip.Resampler(3, 10, taps, order, complex_)
+    assert r.num_coeffs == model.num_coeffs
+    got = _run_ranges(r, to_dev(x), 4 * B, w, exp.size // w, B, [])
+    assert_bit_equal(got, exp, "contiguous")
+    got = _run_ranges(r, to_dev(x), 4 * B, w, exp.size // w, B, [1, 2, 2439, 2458, 5000])
+    assert_bit_equal(got, exp, "cut into launches")
+
+
+@pytest.mark.parametrize("I,D", [(2, 3), (5, 7), (7, 11), (3, 23)])
+def test_resampler_other_ratios(hip, oracle, I, D):
+    x = S.real_block(3 * 4096)
+    taps = S.gauss_taps(150, I + D)
+    model = PM.ResamplerModel(oracle, I, D, taps, PM.ORDER_AVX)
+    blocks, _ = PM.fir_resampler_pipe(model, _split(x, 1, 4096), 128)
+    exp = np.concatenate(blocks)
+    r = hip.Resampler(I, D, taps, hip.ORDER_AVX)
+    for m in (0, 1, 5, 1000):
+        assert r.in_offset(m) == -((-m * D) // I)
+    got = _run_ranges(r, to_dev(x), 3 * 4096, 1, exp.size, 4096, [77])
+    assert_bit_equal(got, exp, f"{I}/{D}")
+
+
+def test_fm_demod_stream(hip, oracle):
+    x = oracle.convert_u8(S.iq_u8_fm(3 * B))
+    exp = np.concatenate(PM.fm_demod_pipe(oracle, _split(x, 2, B)))
+    d_in = to_dev(x)
+    out = dev_empty_f32(3 * B)
+    hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, 1000, 0.0, 0.0))
+    hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out) + 4000, 1000, 3 * B, 0.0, 0.0))
+    assert_bit_equal(to_host(out), exp, "fmDemod stream")
+
+
+def test_convert_device(hip, oracle):
+    u8 = S.iq_u8(100003)[:200001]
+    d_in = to_dev(u8)
+    out = dev_empty_f32(u8.size)
+    hip.check(hip.lib.sdrhip_convert_u8_run(None, ptr(d_in), ptr(out), u8.size))
+    assert_bit_equal(to_host(out), oracle.convert_u8(u8), "convert device")
+
+
+def test_argument_errors(hip):
+    taps = S.taps_decim127()
+    dec = hip.Decimator(8, taps, hip.ORDER_AVX, complex_=True)
+    d = dev_empty_f32(1024)
+    with pytest.raises(hip.SdrHipError):
+        dec.run(ptr(d), 100, ptr(d), 0, 10, 0)          # window starts before the buffer
+    with pytest.raises(hip.SdrHipError):
+        dec.run(ptr(d), 0, ptr(d), 0, 10, 64)           # seam block shorter than the filter
+    with pytest.raises(hip.SdrHipError):
+        hip.Filter(taps[:30], hip.ORDER_AVX, sym=True)  # half taps not a multiple of 8
+    with pytest.raises(hip.SdrHipError):
+        hip.Resampler(10, 3, taps)                      # needs decimation > interpolation
