@@ -22,11 +22,14 @@
 //   * taps are wave-uniform -> scalar loads / SGPR operands.
 //   "Cross" outputs (seam straddlers, sequential order) are rewritten afterwards by
 //   a tiny fix-up kernel on the same stream: ~1.5 % of outputs.
+#include <stdlib.h>
+
 #include "kernels.hpp"
 
 namespace sdrhip {
 
 namespace {
+
 
 template <int D, int P, int R, int NT>
 struct Tile {
@@ -40,6 +43,54 @@ struct Tile {
     static constexpr int LDS_F2 = SPAN + 2 * (SPAN / CHUNK) + 2;
     static constexpr size_t LDS_BYTES = (size_t)LDS_F2 * 8;
 };
+
+// One scalar load of TC taps, pinned in program order: the empty volatile asm makes
+// the address opaque (the load cannot be hoisted above it, nor out of a loop) and
+// fences memory operations, so neither the tap loads nor the LDS reads of later
+// sample blocks can pile up at the top of the unrolled code.  Constant address
+// space + an SGPR-resident address => s_load_dwordx8.
+typedef float tap8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ tap8 load_tap_chunk(const float* taps, int c)
+{
+    typedef const __attribute__((address_space(4))) tap8* ctapp;
+    uint64_t a = reinterpret_cast<uint64_t>(taps) + 32u * (uint32_t)c;
+    asm volatile("" : "+s"(a));
+    return *reinterpret_cast<ctapp>(a);
+}
+
+// The MAC loop of one thread: WIN samples from LDS (two per ds_read_b128), each
+// feeding up to R outputs; fully unrolled.  Taps are wave-uniform and live in SGPRs.
+// They arrive 8 at a time, one chunk ahead of first use: a scalar-load wait is a
+// full lgkmcnt(0) drain (SMEM returns out of order) that also stalls the LDS
+// pipeline, so there must be few of them -- P/8 per tile instead of one per tap pair.
+template <int D, int P, int R, class T>
+__device__ __forceinline__ void mac_window(const float2* __restrict__ win, const float* __restrict__ taps, float2 (&acc)[R][4])
+{
+    constexpr int TC = 8;
+    static_assert(P % TC == 0, "taps are fetched in chunks of 8");
+    constexpr int NCH = P / TC;
+    tap8 tc[NCH];
+    tc[0] = load_tap_chunk(taps, 0);
+#pragma unroll
+    for (int s = 0; s < T::WIN; s += 2) {
+        if (s % TC == 0 && s / TC + 1 < NCH) tc[s / TC + 1] = load_tap_chunk(taps, s / TC + 1);
+        const float4 v2 = *reinterpret_cast<const float4*>(&win[s + 2 * (s / T::CHUNK)]);
+        const float2 v[2] = {make_float2(v2.x, v2.y), make_float2(v2.z, v2.w)};
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int ss = s + e;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int j = ss - r * D;
+                if (j >= 0 && j < P) {
+                    const float h = tc[j / TC][j % TC];
+                    acc[r][j & 3].x = acc[r][j & 3].x + h * v[e].x;
+                    acc[r][j & 3].y = acc[r][j & 3].y + h * v[e].y;
+                }
+            }
+        }
+    }
+}
 
 // stage the tile's samples [0, SPAN) into LDS; `avail` = how many of them exist
 template <class T, bool U8>
@@ -98,6 +149,70 @@ __device__ __forceinline__ void stage_tile(float2* __restrict__ lds, const void*
     }
 }
 
+template <class T, bool U8, int NT>
+struct Stage {
+    static constexpr int SPV = U8 ? 8 : 2;                       // samples per 16-byte vector
+    static constexpr int NV = (T::SPAN + SPV - 1) / SPV;         // vectors per tile
+    static constexpr int PER = (NV + NT - 1) / NT;               // vectors per thread
+    uint4 r[PER];
+
+    __device__ __forceinline__ void load(const void* __restrict__ src_v, int64_t sample0, int avail)
+    {
+        const char* src = reinterpret_cast<const char*>(src_v) + (U8 ? 2 : 8) * sample0;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int v = threadIdx.x + i * NT;
+            const int s = v * SPV;
+            if (v < NV) {
+                if (s + SPV <= avail) {
+                    r[i] = *reinterpret_cast<const uint4*>(src + 16 * (int64_t)v);
+                } else {
+                    // ragged end of the stream: element-wise, zero-filled (u8 128 == 0.0f)
+                    uint32_t w[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) w[k] = U8 ? 0x80808080u : 0u;
+                    if constexpr (U8) {
+                        const uint8_t* b = reinterpret_cast<const uint8_t*>(src) + 16 * (int64_t)v;
+                        for (int e = 0; e < 16; e++)
+                            if (s + e / 2 < avail) w[e >> 2] = (w[e >> 2] & ~(0xffu << (8 * (e & 3)))) | ((uint32_t)b[e] << (8 * (e & 3)));
+                    } else {
+                        const uint32_t* f = reinterpret_cast<const uint32_t*>(src) + 4 * (int64_t)v;
+                        for (int e = 0; e < 4; e++)
+                            if (s + e / 2 < avail) w[e] = f[e];
+                    }
+                    r[i] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float2* __restrict__ lds) const
+    {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int v = threadIdx.x + i * NT;
+            const int s = v * SPV;
+            if (v < NV) {
+                if constexpr (!U8) {
+                    *reinterpret_cast<uint4*>(&lds[T::lds_idx(s)]) = r[i];
+                } else {
+                    const uint32_t w[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float4 f;
+                        f.x = ((float)(w[k] & 0xff) - 128.0f) * (1.0f / 128.0f);
+                        f.y = ((float)((w[k] >> 8) & 0xff) - 128.0f) * (1.0f / 128.0f);
+                        f.z = ((float)((w[k] >> 16) & 0xff) - 128.0f) * (1.0f / 128.0f);
+                        f.w = ((float)(w[k] >> 24) - 128.0f) * (1.0f / 128.0f);
+                        const int ss = s + 2 * k;
+                        if (ss < T::SPAN + 1) *reinterpret_cast<float4*>(&lds[T::lds_idx(ss)]) = f;
+                    }
+                }
+            }
+        }
+    }
+};
+
 template <int D, int P, int R, int NT, bool U8>
 __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in, int64_t x0 /* sample index of output 0's window in `in` */,
                                                     int count, const float* __restrict__ taps, float* __restrict__ out)
@@ -114,7 +229,12 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
     int64_t av = total_avail - s0;
     int avail = av > T::SPAN ? T::SPAN : (int)av;
 
-    stage_tile<T, U8>(lds, in, x0 + s0, avail);
+    {
+        // all of the tile's global loads in flight at once, then one wait
+        Stage<T, U8, NT> st;
+        st.load(in, x0 + s0, avail);
+        st.store(lds);
+    }
     __syncthreads();
 
     // per-thread window starts at sample tid*CHUNK of the tile
@@ -125,25 +245,7 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
 #pragma unroll
         for (int k = 0; k < 4; k++) acc[r][k] = make_float2(0.0f, 0.0f);
 
-#pragma unroll
-    for (int s = 0; s < T::WIN; s += 2) {
-        // two samples per ds_read_b128; within the window the pad offset is compile-time
-        float4 v2 = *reinterpret_cast<const float4*>(&win[s + 2 * (s / T::CHUNK)]);
-        float2 v[2] = {make_float2(v2.x, v2.y), make_float2(v2.z, v2.w)};
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const int ss = s + e;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int j = ss - r * D;
-                if (j >= 0 && j < P) {
-                    const float h = taps[j];
-                    acc[r][j & 3].x = acc[r][j & 3].x + h * v[e].x;
-                    acc[r][j & 3].y = acc[r][j & 3].y + h * v[e].y;
-                }
-            }
-        }
-    }
+    mac_window<D, P, R, T>(win, taps, acc);
 
     const int o = out0 + threadIdx.x * R;
     float2 res[R];
@@ -152,14 +254,82 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
         res[r].x = (acc[r][0].x + acc[r][1].x) + (acc[r][2].x + acc[r][3].x);
         res[r].y = (acc[r][0].y + acc[r][1].y) + (acc[r][2].y + acc[r][3].y);
     }
-    if (o + R <= count) {
+    if (R % 2 == 0 && o + R <= count) {
         float4* dst = reinterpret_cast<float4*>(out + 2 * (int64_t)o);
 #pragma unroll
-        for (int r = 0; r < R; r += 2) dst[r / 2] = make_float4(res[r].x, res[r].y, res[r + 1].x, res[r + 1].y);
+        for (int r = 0; r + 1 < R; r += 2) dst[r / 2] = make_float4(res[r].x, res[r].y, res[r + 1].x, res[r + 1].y);
     } else {
 #pragma unroll
         for (int r = 0; r < R; r++)
             if (o + r < count) *reinterpret_cast<float2*>(out + 2 * (int64_t)(o + r)) = res[r];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Persistent, software-pipelined variant: each workgroup walks tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ...  While the VALU works through tile i out
+// of LDS, the global loads of tile i+1 are already in flight into registers; they
+// are written to LDS only after every wave has finished reading tile i.  This takes
+// the HBM latency off the critical path (the one-shot kernel above exposes a full
+// load phase per tile) without needing a second LDS buffer -- LDS capacity is what
+// bounds occupancy here (64 B of window per in-flight output).
+// ---------------------------------------------------------------------------
+template <int D, int P, int R, int NT, bool U8, int WPS>
+__global__ void __launch_bounds__(NT, WPS) k_decimate_c4_pipe(const void* __restrict__ in, int64_t x0, int count, int ntiles,
+                                                         const float* __restrict__ taps, float* __restrict__ out)
+{
+    using T = Tile<D, P, R, NT>;
+    static_assert(D % 4 == 0, "lane of a tap must not depend on the output within a thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    const int64_t total_avail = (int64_t)(count - 1) * D + P;
+
+    Stage<T, U8, NT> st;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    {
+        const int64_t s0 = (int64_t)tile * T::OUTS * D;
+        const int64_t av = total_avail - s0;
+        st.load(in, x0 + s0, av > T::SPAN ? T::SPAN : (int)av);
+        st.store(lds);
+    }
+    __syncthreads();
+
+    const float2* win = lds + T::lds_idx(threadIdx.x * T::CHUNK);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) {
+            const int64_t s0 = (int64_t)next * T::OUTS * D;
+            const int64_t av = total_avail - s0;
+            st.load(in, x0 + s0, av > T::SPAN ? T::SPAN : (int)av);   // in flight during the MACs below
+        }
+
+        float2 acc[R][4];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[r][k] = make_float2(0.0f, 0.0f);
+        mac_window<D, P, R, T>(win, taps, acc);
+        const int o = tile * T::OUTS + threadIdx.x * R;
+        float2 res[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            res[r].x = (acc[r][0].x + acc[r][1].x) + (acc[r][2].x + acc[r][3].x);
+            res[r].y = (acc[r][0].y + acc[r][1].y) + (acc[r][2].y + acc[r][3].y);
+        }
+        if (R % 2 == 0 && o + R <= count) {
+            float4* dst = reinterpret_cast<float4*>(out + 2 * (int64_t)o);
+#pragma unroll
+            for (int r = 0; r + 1 < R; r += 2) dst[r / 2] = make_float4(res[r].x, res[r].y, res[r + 1].x, res[r + 1].y);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (o + r < count) *reinterpret_cast<float2*>(out + 2 * (int64_t)(o + r)) = res[r];
+        }
+
+        __syncthreads();                       // every wave is done reading this tile
+        if (next < ntiles) st.store(lds);
+        __syncthreads();
     }
 }
 
@@ -199,6 +369,37 @@ __global__ void __launch_bounds__(256) k_decimate_c_crossfix(Geom g, const float
     *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
 }
 
+int num_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int D, int P, int R, int NT, bool U8, int WGS_PER_CU>
+void launch_c4_pipe(hipStream_t s, const Geom& g, const float* taps, const void* in, float* out)
+{
+    using T = Tile<D, P, R, NT>;
+    constexpr int wgs_per_cu = WGS_PER_CU;
+    static bool attr_set = false;
+    auto kern = k_decimate_c4_pipe<D, P, R, NT, U8, (WGS_PER_CU * NT / 64 + 3) / 4>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)T::LDS_BYTES);
+        attr_set = true;
+    }
+    int tiles = (g.count + T::OUTS - 1) / T::OUTS;
+    int grid = num_cus() * wgs_per_cu;
+    if (grid > tiles) grid = tiles;
+    int64_t x0 = g.k_begin * D - g.in_base;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, tiles, taps, out);
+}
+
 template <int D, int P, int R, int NT, bool U8>
 void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, float* out)
 {
@@ -232,8 +433,32 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
         if (((base + 8 * (uintptr_t)x0) & 15) != 0) return false;
     }
     if ((reinterpret_cast<uintptr_t>(d_out) & 15) != 0) return false;
-    if (in_is_u8) launch_c4<8, 128, 4, 256, true>(s, g, d_plain_taps, d_in, d_out);
-    else launch_c4<8, 128, 4, 256, false>(s, g, d_plain_taps, d_in, d_out);
+    static const int variant = getenv("SDRHIP_K2_VARIANT") ? atoi(getenv("SDRHIP_K2_VARIANT")) : 3;
+    if (variant == 0) {
+        if (in_is_u8) launch_c4<8, 128, 4, 256, true>(s, g, d_plain_taps, d_in, d_out);
+        else launch_c4<8, 128, 4, 256, false>(s, g, d_plain_taps, d_in, d_out);
+    } else if (variant == 1) {
+        if (in_is_u8) launch_c4_pipe<8, 128, 4, 256, true, 2>(s, g, d_plain_taps, d_in, d_out);
+        else launch_c4_pipe<8, 128, 4, 256, false, 2>(s, g, d_plain_taps, d_in, d_out);
+    } else if (variant == 2) {
+        if (in_is_u8) launch_c4_pipe<8, 128, 2, 256, true, 4>(s, g, d_plain_taps, d_in, d_out);
+        else launch_c4_pipe<8, 128, 2, 256, false, 4>(s, g, d_plain_taps, d_in, d_out);
+    } else if (variant == 7) {
+        if (in_is_u8) launch_c4_pipe<8, 128, 2, 512, true, 2>(s, g, d_plain_taps, d_in, d_out);
+        else launch_c4_pipe<8, 128, 2, 512, false, 2>(s, g, d_plain_taps, d_in, d_out);
+    } else if (variant == 3) {
+        if (in_is_u8) launch_c4<8, 128, 2, 256, true>(s, g, d_plain_taps, d_in, d_out);
+        else launch_c4<8, 128, 2, 256, false>(s, g, d_plain_taps, d_in, d_out);
+    } else if (variant == 4) {
+        if (in_is_u8) launch_c4<8, 128, 3, 256, true>(s, g, d_plain_taps, d_in, d_out);
+        else launch_c4<8, 128, 3, 256, false>(s, g, d_plain_taps, d_in, d_out);
+    } else if (variant == 5) {
+        if (in_is_u8) launch_c4<8, 128, 2, 512, true>(s, g, d_plain_taps, d_in, d_out);
+        else launch_c4<8, 128, 2, 512, false>(s, g, d_plain_taps, d_in, d_out);
+    } else {
+        if (in_is_u8) launch_c4<8, 128, 2, 128, true>(s, g, d_plain_taps, d_in, d_out);
+        else launch_c4<8, 128, 2, 128, false>(s, g, d_plain_taps, d_in, d_out);
+    }
 
     if (g.seamBI != 0) {
         // seams whose straddling outputs may fall in [k_begin, k_end)

@@ -36,8 +36,8 @@ def _run(hip, chain, u8_dev, s0, n_in, q0, q1):
 
 @pytest.mark.parametrize("fm_signal", [False, True])
 def test_chain_matches_pipes(hip, oracle, fm_signal):
-    # 8192 audio samples need 8192*80/3 ~ 218k input samples = 27 blocks; use 60 -> 2 audio blocks
-    nblk = 60
+    # every Pipe only yields full 8192-blocks: 90 input blocks -> 11 decimator blocks -> 3 resampler blocks -> 2 audio blocks
+    nblk = 90
     u8 = (S.iq_u8_fm if fm_signal else S.iq_u8)(nblk * B)
     exp = _model(oracle, u8, nblk)
     assert exp.size == 2 * B

@@ -72,7 +72,7 @@ def test_fir_filter_pipe(hip, oracle):
 def test_fir_resampler_pipe(hip, oracle):
     x = S.real_block(8 * B)
     taps = S.taps_resamp191()
-    for sizes, bo in (([B] * 8, B), ([3000, 9000, 200, 8192, 8192, 65, 4000, 12000], 999)):
+    for sizes, bo in (([B] * 8, B), ([3000, 9000, 200, 8192, 8192, 300, 4000, 12000], 999)):
         blocks = _cut(x, 1, sizes)
         exp, _ = PM.fir_resampler_pipe(PM.ResamplerModel(oracle, 3, 10, taps, PM.ORDER_AVX), blocks, bo)
         r = hip.Resampler(3, 10, taps, hip.ORDER_AVX)
