@@ -247,6 +247,13 @@ size_t sdrhip_fm_chain_workspace_bytes(const sdrhip_fm_chain *c, int64_t n_in);
 int sdrhip_fm_chain_run(sdrhip_fm_chain *c, void *stream, const uint8_t *d_in_iq, int64_t s0, int64_t n_in,
                         float *d_audio, int64_t q0, int64_t q1, void *d_workspace, size_t workspace_bytes);
 
+/* Per-stage timing with HIP events recorded on the run's own stream between the
+ * stages {decimate(+seam fix-up), fmDemod, resample, filter, gain}.  read_timing waits
+ * for the recorded runs, returns the SUM of elapsed ms per stage over `*runs` runs
+ * and resets the recorder. */
+int sdrhip_fm_chain_enable_timing(sdrhip_fm_chain *c, int enable);
+int sdrhip_fm_chain_read_timing(sdrhip_fm_chain *c, double ms_sum[5], int *runs);
+
 /* ------------------------------------------------------------------------ */
 /* (3) Pipe operators on host blocks                                        */
 /* ------------------------------------------------------------------------ */

@@ -29,11 +29,26 @@ int upload_floats(float** d, const std::vector<float>& h)
     return SDRHIP_OK;
 }
 
+int FirDesc::ensure_device() const
+{
+    if (d_taps) return SDRHIP_OK;
+    int rc;
+    if ((rc = upload_floats(&d_cross, h_plain)) != SDRHIP_OK) return rc;
+    d_plain = d_cross;
+    return upload_floats(&d_taps, h_kernel);
+}
+int ResampDesc::ensure_device() const
+{
+    if (d_groups) return SDRHIP_OK;
+    int rc;
+    if ((rc = upload_floats(&d_groups, h_groups)) != SDRHIP_OK) return rc;
+    return upload_floats(&d_plain, h_plain);
+}
+
 FirDesc::~FirDesc()
 {
     if (d_taps) (void)hipFree(d_taps);
     if (d_cross) (void)hipFree(d_cross);
-    if (d_plain && d_plain != d_cross) (void)hipFree(d_plain);
 }
 ResampDesc::~ResampDesc()
 {
@@ -67,17 +82,15 @@ int fir_create(FirDesc* d, int order, bool cplx, int factor, const float* coeffs
     d->corder = order == SDRHIP_ORDER_SCALAR ? CO_SEQ : order == SDRHIP_ORDER_SSE ? CO_L2 : CO_L4;
     d->h_plain.assign(d->Lp, 0.0f);
     memcpy(d->h_plain.data(), coeffs, ncoeffs * sizeof(float));
-    int rc;
-    if ((rc = upload_floats(&d->d_cross, d->h_plain)) != SDRHIP_OK) return rc;
-    d->d_plain = d->d_cross;
     if (cplx && order != SDRHIP_ORDER_SCALAR) {
-        std::vector<float> dup(2 * d->Lp);
-        for (int i = 0; i < d->Lp; i++) dup[2 * i] = dup[2 * i + 1] = d->h_plain[i];
+        d->h_kernel.resize(2 * d->Lp);
+        for (int i = 0; i < d->Lp; i++) d->h_kernel[2 * i] = d->h_kernel[2 * i + 1] = d->h_plain[i];
         d->ntaps_kernel = 2 * d->Lp;
-        return upload_floats(&d->d_taps, dup);
+    } else {
+        d->h_kernel = d->h_plain;
+        d->ntaps_kernel = d->Lp;
     }
-    d->ntaps_kernel = d->Lp;
-    return upload_floats(&d->d_taps, d->h_plain);
+    return SDRHIP_OK;
 }
 
 // mkFilterSymR / mkDecimatorSymR (Filter.hs:234-245, 358-371): One kernel gets the
@@ -95,16 +108,12 @@ int fir_sym_create(FirDesc* d, int order, int factor, const float* half, int nha
     d->lanes = lanes;
     d->Lp = 2 * nhalf;
     d->ntaps_kernel = nhalf;
-    std::vector<float> h(half, half + nhalf);
+    d->h_kernel.assign(half, half + nhalf);
     d->h_plain.resize(2 * nhalf);
     for (int i = 0; i < nhalf; i++) {
         d->h_plain[i] = half[i];
         d->h_plain[2 * nhalf - 1 - i] = half[i];
     }
-    int rc;
-    if ((rc = upload_floats(&d->d_taps, h)) != SDRHIP_OK) return rc;
-    if ((rc = upload_floats(&d->d_cross, d->h_plain)) != SDRHIP_OK) return rc;
-    d->d_plain = d->d_cross;
     return SDRHIP_OK;
 }
 
@@ -117,6 +126,10 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
     SDRHIP_REQUIRE(seam_block <= 0 || seam_block >= d->Lp, "fir_run: seam block shorter than the filter (Filter.hs:544,586)");
     if (k_end == k_begin) return SDRHIP_OK;
     SDRHIP_REQUIRE(d_in != nullptr && d_out != nullptr, "fir_run");
+    {
+        int rc = d->ensure_device();
+        if (rc != SDRHIP_OK) return rc;
+    }
     Geom g;
     g.in_base = in_base;
     g.k_begin = k_begin;
@@ -186,10 +199,8 @@ int resamp_create(ResampDesc* r, int order, bool cplx, int I, int D, const float
     r->nloop = round_up(r->num_coeffs, simd);
     r->lut.assign(I, -1);
     for (int g = 0; g < r->num_groups; g++) r->lut[r->offsets[g]] = g;
-    int rc;
-    if ((rc = upload_floats(&r->d_groups, r->h_groups)) != SDRHIP_OK) return rc;
-    std::vector<float> plain(coeffs, coeffs + ncoeffs);
-    return upload_floats(&r->d_plain, plain);
+    r->h_plain.assign(coeffs, coeffs + ncoeffs);
+    return SDRHIP_OK;
 }
 
 int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in_base, float* d_out,
@@ -201,6 +212,10 @@ int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in
     SDRHIP_REQUIRE(seam_block <= 0 || seam_block * r->I >= r->Lp, "resamp_run: seam block shorter than the filter (Filter.hs:691)");
     if (k_end == k_begin) return SDRHIP_OK;
     SDRHIP_REQUIRE(d_in != nullptr && d_out != nullptr, "resamp_run");
+    {
+        int rc = r->ensure_device();
+        if (rc != SDRHIP_OK) return rc;
+    }
     int64_t p0 = r->in_offset(k_begin);
     SDRHIP_REQUIRE(p0 >= in_base, "resamp_run: first window starts before d_in");
     Geom g;

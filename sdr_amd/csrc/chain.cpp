@@ -9,9 +9,13 @@
 //   inOff(m) = ceil(m*D2/I2)) -> q audio outputs (window [q, q+L3)).
 // Seams: all four Pipes of fm.hs run with blockSizeOut = `block` and the source
 // delivers `block`-sample buffers, so each stage's input blocks are `block` long.
+#include <vector>
+
 #include "descriptors.hpp"
 
 using namespace sdrhip;
+
+static const int kStages = 5;  // decimate(+seam fix-up), fmDemod, resample, filter, gain
 
 struct sdrhip_fm_chain {
     FirDesc decim;     // complex, factor D1
@@ -19,6 +23,17 @@ struct sdrhip_fm_chain {
     FirDesc audio;     // symmetric real
     float gain = 1.0f;
     int64_t block = 0;
+
+    // optional per-stage timing: one set of kStages+1 events per run, on the run's stream
+    bool timing = false;
+    struct EvSet { hipEvent_t e[kStages + 1]; };
+    std::vector<EvSet> pool;   // allocated sets
+    size_t used = 0;           // sets recorded since the last read
+    ~sdrhip_fm_chain()
+    {
+        for (auto& es : pool)
+            for (auto ev : es.e) (void)hipEventDestroy(ev);
+    }
 
     // reach of resampler output m in y: the One kernel walks nloop floats, the Cross
     // kernel at most ceil(ntaps/I) <= nloop
@@ -163,17 +178,59 @@ int sdrhip_fm_chain_run(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
     float* d_y = (float*)(ws + off_y);
     float* d_z = (float*)(ws + off_z);
     int rc;
+    sdrhip_fm_chain::EvSet* es = nullptr;
+    if (c->timing) {
+        if (c->used == c->pool.size()) {
+            sdrhip_fm_chain::EvSet n;
+            for (auto& ev : n.e) SDRHIP_CHECK_HIP(hipEventCreate(&ev));
+            c->pool.push_back(n);
+        }
+        es = &c->pool[c->used++];
+        SDRHIP_CHECK_HIP(hipEventRecord(es->e[0], s));
+    }
+#define STAGE_DONE(i) do { if (es) SDRHIP_CHECK_HIP(hipEventRecord(es->e[(i) + 1], s)); } while (0)
     // K1+K2: u8 -> cfloat -> decimate (convert.c:37-50 fused into decimate.c:105-113)
     if ((rc = fir_run(&c->decim, s, d_in_iq, true, s0, d_d, kd0, kd1, c->block)) != SDRHIP_OK) return rc;
+    STAGE_DONE(0);
     // K3: fmDemod; at stream start the carried sample is 0 (Demod.hs:41)
     launch_fm_demod(s, d_d + 2 * (ky0 - kd0), d_y, ky1 - ky0, ky0 > kd0, 0.0f, 0.0f);
+    STAGE_DONE(1);
     // K4: polyphase resample
     if ((rc = resamp_run(&c->resamp, s, d_y, ky0, d_z, m0, m1, c->block)) != SDRHIP_OK) return rc;
+    STAGE_DONE(2);
     // K5: symmetric audio filter
     if ((rc = fir_run(&c->audio, s, d_z, false, m0, d_audio, q0, q1, c->block)) != SDRHIP_OK) return rc;
+    STAGE_DONE(3);
     // fm.hs:40  P.map (VG.map (* 0.2))
     if (c->gain != 1.0f) launch_scale(s, c->gain, d_audio, d_audio, q1 - q0);
+    STAGE_DONE(4);
+#undef STAGE_DONE
     SDRHIP_CHECK_HIP(hipGetLastError());
+    return SDRHIP_OK;
+}
+
+int sdrhip_fm_chain_enable_timing(sdrhip_fm_chain* c, int enable)
+{
+    SDRHIP_REQUIRE(c != nullptr, "sdrhip_fm_chain_enable_timing");
+    c->timing = enable != 0;
+    c->used = 0;
+    return SDRHIP_OK;
+}
+
+int sdrhip_fm_chain_read_timing(sdrhip_fm_chain* c, double* ms_sum, int* runs)
+{
+    SDRHIP_REQUIRE(c != nullptr && ms_sum != nullptr && runs != nullptr, "sdrhip_fm_chain_read_timing");
+    for (int i = 0; i < kStages; i++) ms_sum[i] = 0.0;
+    for (size_t r = 0; r < c->used; r++) {
+        SDRHIP_CHECK_HIP(hipEventSynchronize(c->pool[r].e[kStages]));
+        for (int i = 0; i < kStages; i++) {
+            float ms = 0.0f;
+            SDRHIP_CHECK_HIP(hipEventElapsedTime(&ms, c->pool[r].e[i], c->pool[r].e[i + 1]));
+            ms_sum[i] += ms;
+        }
+    }
+    *runs = (int)c->used;
+    c->used = 0;
     return SDRHIP_OK;
 }
 

@@ -19,10 +19,14 @@ struct FirDesc {
     int lanes = 8;        // real data lane count
     ComplexOrder corder = CO_L4;
     int ntaps_kernel = 0; // length of d_taps as the kernel consumes it
-    float* d_taps = nullptr;   // real: padded plain (or half for sym); complex RC: duplicated
-    float* d_cross = nullptr;  // Lp plain taps for the sequential Cross outputs
-    float* d_plain = nullptr;  // padded plain taps (aliases d_cross when !sym)
-    std::vector<float> h_plain;
+    // Device copies are made on first use (ensure_device), so descriptors -- and the
+    // planning arithmetic built on them -- can be created on a host without a GPU.
+    mutable float* d_taps = nullptr;   // real: padded plain (or half for sym); complex RC: duplicated
+    mutable float* d_cross = nullptr;  // Lp plain taps for the sequential Cross outputs
+    mutable float* d_plain = nullptr;  // padded plain taps (aliases d_cross)
+    std::vector<float> h_plain;        // Lp plain taps (sym: c ++ reverse c)
+    std::vector<float> h_kernel;       // what d_taps holds
+    int ensure_device() const;
     ~FirDesc();
 };
 
@@ -39,9 +43,10 @@ struct ResampDesc {
     int row_stride = 0;   // padded group length
     int nloop = 0;        // floats the SIMD loop actually walks
     std::vector<int> increments, offsets, lut;  // lut: filter offset -> group
-    std::vector<float> h_groups;
-    float* d_groups = nullptr;
-    float* d_plain = nullptr;
+    std::vector<float> h_groups, h_plain;
+    mutable float* d_groups = nullptr;
+    mutable float* d_plain = nullptr;
+    int ensure_device() const;
     int64_t in_offset(int64_t m) const { return ceil_div64(m * (int64_t)D, I); }
     int filter_offset(int64_t m) const { return (int)(in_offset(m) * I - m * (int64_t)D); }
     int group(int64_t m) const { return lut[filter_offset(m)]; }

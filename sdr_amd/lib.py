@@ -93,6 +93,9 @@ lib.sdrhip_fm_chain_workspace_bytes.argtypes = [_vp, _i64]
 lib.sdrhip_fm_chain_workspace_bytes.restype = C.c_size_t
 lib.sdrhip_fm_chain_run.argtypes = [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, C.c_size_t]
 
+lib.sdrhip_fm_chain_enable_timing.argtypes = [_vp, C.c_int]
+lib.sdrhip_fm_chain_read_timing.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+
 lib.sdrhip_pipe_fir_filter.argtypes = [C.POINTER(_vp), _vp, C.c_int]
 lib.sdrhip_pipe_fir_decimator.argtypes = [C.POINTER(_vp), _vp, C.c_int]
 lib.sdrhip_pipe_fir_resampler.argtypes = [C.POINTER(_vp), _vp, C.c_int]
@@ -330,6 +333,19 @@ class FmChain(_Handle):
 
     def workspace_bytes(self, n_in):
         return lib.sdrhip_fm_chain_workspace_bytes(self.h, n_in)
+
+    STAGES = ("decimate", "fm_demod", "resample", "filter", "gain")
+
+    def enable_timing(self, on=True):
+        check(lib.sdrhip_fm_chain_enable_timing(self.h, int(on)), "sdrhip_fm_chain_enable_timing")
+
+    def read_timing(self):
+        """-> (dict stage -> mean ms per run, runs)"""
+        ms = (C.c_double * 5)()
+        runs = C.c_int()
+        check(lib.sdrhip_fm_chain_read_timing(self.h, ms, C.byref(runs)), "sdrhip_fm_chain_read_timing")
+        n = max(runs.value, 1)
+        return {k: ms[i] / n for i, k in enumerate(self.STAGES)}, runs.value
 
     def run(self, d_in_u8, s0, n_in, d_audio, q0, q1, d_ws, ws_bytes, stream=None):
         check(lib.sdrhip_fm_chain_run(self.h, stream, d_in_u8, s0, n_in, d_audio, q0, q1, d_ws, ws_bytes), "sdrhip_fm_chain_run")
