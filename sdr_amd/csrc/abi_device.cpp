@@ -118,7 +118,7 @@ int fir_sym_create(FirDesc* d, int order, int factor, const float* half, int nha
 }
 
 int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64_t in_base, float* d_out,
-            int64_t k_begin, int64_t k_end, int64_t seam_block)
+            int64_t k_begin, int64_t k_end, int64_t seam_block, float gain)
 {
     SDRHIP_REQUIRE(d != nullptr, "fir_run");
     SDRHIP_REQUIRE(k_end >= k_begin && k_end - k_begin < (int64_t)0x7fffffff, "fir_run");
@@ -147,9 +147,16 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
         } else {
             launch_fir_cplx(s, g, d->corder, false, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out);
         }
+        if (gain != 1.0f) launch_scale(s, gain, d_out, d_out, 2 * (int64_t)g.count);
     } else {
         SDRHIP_REQUIRE(!in_u8, "fir_run: u8 input is IQ data, complex stages only");
-        launch_fir_real(s, g, d->lanes, d->sym, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out);
+        if (d->sym && d->lanes == 8 &&
+            launch_fir_sym8_fast(s, g, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out, gain, gain != 1.0f)) {
+            // LDS-tiled kernel took it (gain fused)
+        } else {
+            launch_fir_real(s, g, d->lanes, d->sym, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out);
+            if (gain != 1.0f) launch_scale(s, gain, d_out, d_out, g.count);
+        }
     }
     SDRHIP_CHECK_HIP(hipGetLastError());
     return SDRHIP_OK;
@@ -242,7 +249,9 @@ int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in
     t.force_seq = 0;
     for (int q = 0; q < r->num_groups; q++) t.fo[q] = r->offsets[q];
     if (r->cplx) launch_resample_cplx(s, g, r->corder, t, r->d_groups, r->d_plain, d_in, d_out);
-    else launch_resample_real(s, g, r->lanes, t, r->d_groups, r->d_plain, d_in, d_out);
+    else if (r->lanes == 8 && launch_resample_3_10_fast(s, g, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
+        // specialised 3-group kernel took it
+    } else launch_resample_real(s, g, r->lanes, t, r->d_groups, r->d_plain, d_in, d_out);
     SDRHIP_CHECK_HIP(hipGetLastError());
     return SDRHIP_OK;
 }
@@ -459,8 +468,8 @@ int sdrhip_fm_demod_run(void* stream, const float* d_in_iq, int64_t in_base, flo
 {
     SDRHIP_REQUIRE(k_end >= k_begin && k_begin >= in_base, "sdrhip_fm_demod_run");
     bool has_prev = k_begin > in_base;
-    launch_fm_demod((hipStream_t)stream, d_in_iq + 2 * (k_begin - in_base), d_out, k_end - k_begin, has_prev, last_re,
-                    last_im);
+    launch_fm_demod_fast((hipStream_t)stream, d_in_iq + 2 * (k_begin - in_base), d_out, k_end - k_begin, has_prev, last_re,
+                         last_im);
     SDRHIP_CHECK_HIP(hipGetLastError());
     return SDRHIP_OK;
 }

@@ -333,7 +333,7 @@ void fmDemodF(int num, float last_re, float last_im, const float* in_iq, float* 
 {
     if (num <= 0) return;
     elementwise(in_iq, (size_t)num * 8, out, (size_t)num * 4, [&](hipStream_t s, void* di, void* dout) {
-        launch_fm_demod(s, (const float*)di, (float*)dout, num, false, last_re, last_im);
+        launch_fm_demod_fast(s, (const float*)di, (float*)dout, num, false, last_re, last_im);
     });
 }
 

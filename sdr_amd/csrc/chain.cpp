@@ -193,16 +193,15 @@ int sdrhip_fm_chain_run(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
     if ((rc = fir_run(&c->decim, s, d_in_iq, true, s0, d_d, kd0, kd1, c->block)) != SDRHIP_OK) return rc;
     STAGE_DONE(0);
     // K3: fmDemod; at stream start the carried sample is 0 (Demod.hs:41)
-    launch_fm_demod(s, d_d + 2 * (ky0 - kd0), d_y, ky1 - ky0, ky0 > kd0, 0.0f, 0.0f);
+    launch_fm_demod_fast(s, d_d + 2 * (ky0 - kd0), d_y, ky1 - ky0, ky0 > kd0, 0.0f, 0.0f);
     STAGE_DONE(1);
     // K4: polyphase resample
     if ((rc = resamp_run(&c->resamp, s, d_y, ky0, d_z, m0, m1, c->block)) != SDRHIP_OK) return rc;
     STAGE_DONE(2);
     // K5: symmetric audio filter
-    if ((rc = fir_run(&c->audio, s, d_z, false, m0, d_audio, q0, q1, c->block)) != SDRHIP_OK) return rc;
+    // (+ fm.hs:40  P.map (VG.map (* 0.2)) as the kernel's epilogue: a separate f32 multiply of the rounded output)
+    if ((rc = fir_run(&c->audio, s, d_z, false, m0, d_audio, q0, q1, c->block, c->gain)) != SDRHIP_OK) return rc;
     STAGE_DONE(3);
-    // fm.hs:40  P.map (VG.map (* 0.2))
-    if (c->gain != 1.0f) launch_scale(s, c->gain, d_audio, d_audio, q1 - q0);
     STAGE_DONE(4);
 #undef STAGE_DONE
     SDRHIP_CHECK_HIP(hipGetLastError());

@@ -59,8 +59,10 @@ void prepare_coeffs(int n, int I, int D, const float* coeffs, int ncoeffs, int& 
 
 int fir_create(FirDesc* d, int order, bool cplx, int factor, const float* coeffs, int ncoeffs);
 int fir_sym_create(FirDesc* d, int order, int factor, const float* half, int nhalf);
+// gain: applied to every output after the filter's own rounding (a separate f32 multiply,
+// exactly what `P.map (VG.map (* g))` after the Pipe computes); 1.0f = none.
 int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64_t in_base, float* d_out,
-            int64_t k_begin, int64_t k_end, int64_t seam_block);
+            int64_t k_begin, int64_t k_end, int64_t seam_block, float gain = 1.0f);
 
 int resamp_create(ResampDesc* r, int order, bool cplx, int I, int D, const float* coeffs, int ncoeffs);
 int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in_base, float* d_out,

@@ -80,6 +80,13 @@ void launch_dc_blocker(hipStream_t s, int64_t num, float last_sample, float last
 
 // Fast paths (kernels_fast.hip).  Return false when the configuration is not one
 // they are specialised for; the caller then uses the generic kernel.
+// kernels_chain.hip: fast paths of the low-rate stages
+void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int64_t count, bool has_prev,
+                          float last_re, float last_im);
+bool launch_fir_sym8_fast(hipStream_t s, const Geom& g, const float* d_half_taps, int nhalf, const float* d_cross_taps,
+                          const float* d_in, float* d_out, float gain, bool apply_gain);
+bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& t, const int* increments,
+                               const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out);
 bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps,
                              const void* d_in, bool in_is_u8, float* d_out);
 

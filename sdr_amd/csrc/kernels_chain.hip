@@ -1,0 +1,390 @@
+// kernels_chain.hip -- fast paths for the low-rate stages of the FM chain (they run
+// at 1/8 .. 3/80 of the input rate, so they are latency/HBM-bound little kernels: the
+// job here is to keep them off the critical path, not to chase a roofline).
+//
+//   K3  fmDemod             branch-free atan/atan2, 4 samples per thread
+//   K4  3/10 resampler      LDS tile, one full polyphase cycle (3 outputs) per thread,
+//                            taps wave-uniform (scalar loads)
+//   K5  symmetric real FIR  LDS tile, 4 consecutive outputs per thread, pair-add first,
+//                            optional fused gain (fm.hs:40)
+//   + seam fix-up kernels (Cross outputs, sequential order) for real FIR and resampler
+//
+// Arithmetic contract as in kernels_generic.hip (-ffp-contract=off, lane orders of the
+// AVX variants: resampleAVXRR resample.c:70-87, filterAVXSymmetricRR filter.c:60-68).
+#include "kernels.hpp"
+
+namespace sdrhip {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// K3  fmDemod, Demod.hs:21-46 (+ GHC base atan2, glibc/fdlibm atanf).  Same
+// operations in the same order as device_atanf/ghc_atan2 of kernels_generic.hip, but
+// every data-dependent branch is a select: on noise-like IQ all of fdlibm's five
+// argument ranges occur in every wave, so branches would serialise all of them.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float atanf_sel(float x)
+{
+    const uint32_t hx = __float_as_uint(x);
+    const uint32_t ix = hx & 0x7fffffffu;
+    const bool neg = (hx >> 31) != 0;
+    const float ax = __uint_as_float(ix);
+    const bool tiny_range = ix < 0x3ee00000u;                 // |x| < 0.4375: no reduction, keeps sign
+    const bool r0 = !tiny_range && ix < 0x3f300000u;
+    const bool r1 = !tiny_range && !r0 && ix < 0x3f980000u;
+    const bool r2 = !tiny_range && !r0 && !r1 && ix < 0x401c0000u;
+    // numerator / denominator of the reduction; x/1 is exact so the unreduced range shares the divide
+    const float num = tiny_range ? x : r0 ? (2.0f * ax - 1.0f) : r1 ? (ax - 1.0f) : r2 ? (ax - 1.5f) : -1.0f;
+    const float den = tiny_range ? 1.0f : r0 ? (2.0f + ax) : r1 ? (ax + 1.0f) : r2 ? (1.0f + 1.5f * ax) : ax;
+    const float xr = num / den;
+    const float hv = r0 ? 4.6364760399e-01f : r1 ? 7.8539812565e-01f : r2 ? 9.8279368877e-01f : 1.5707962513e+00f;
+    const float lv = r0 ? 5.0121582440e-09f : r1 ? 3.7748947079e-08f : r2 ? 3.4473217170e-08f : 7.5497894159e-08f;
+    const float z = xr * xr;
+    const float w = z * z;
+    const float s1 = z * (3.3333334327e-01f + w * (1.4285714924e-01f + w * (9.0908870101e-02f + w * (6.6610731184e-02f + w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
+    const float s2 = w * (-2.0000000298e-01f + w * (-1.1111110449e-01f + w * (-7.6918758452e-02f + w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
+    const float small = xr - xr * (s1 + s2);
+    const float zz = hv - ((xr * (s1 + s2) - lv) - xr);
+    float res = tiny_range ? small : (neg ? -zz : zz);
+    if (ix < 0x31000000u) res = x;                             // |x| < 2^-29
+    if (ix >= 0x4c000000u) {                                   // |x| >= 2^25, inf, nan
+        const float big = 1.5707962513e+00f + 7.5497894159e-08f;
+        res = ix > 0x7f800000u ? x + x : (neg ? -big : big);
+    }
+    return res;
+}
+
+__device__ __forceinline__ bool negzero(float v) { return __float_as_uint(v) == 0x80000000u; }
+
+// GHC RealFloat default atan2, evaluated once on (|case|-folded) operands
+__device__ __forceinline__ float ghc_atan2_sel(float y, float x)
+{
+    const float pi = 3.14159274101257324f;
+    // clause 4 (negate (atan2 (negate y) x)) folds the lower half-plane onto the upper one
+    const bool fold = (x <= 0.0f && y < 0.0f) || (x < 0.0f && negzero(y)) || (negzero(x) && negzero(y));
+    const bool c1 = x > 0.0f;
+    const float yy = (!c1 && fold) ? -y : y;
+    const float a = atanf_sel(yy / x);
+    float r;
+    if (c1) r = a;                                            // clause 1 (never folded: x > 0)
+    else if (x == 0.0f && yy > 0.0f) r = pi / 2.0f;
+    else if (x < 0.0f && yy > 0.0f) r = pi + a;
+    else if (yy == 0.0f && (x < 0.0f || negzero(x))) r = pi;
+    else if (x == 0.0f && yy == 0.0f) r = yy;
+    else r = x + yy;
+    return (!c1 && fold) ? -r : r;
+}
+
+__device__ __forceinline__ float fm_phase_sel(float2 cur, float2 prev)
+{
+    const float nd = -prev.y;
+    const float re = cur.x * prev.x - cur.y * nd;
+    const float im = cur.x * nd + cur.y * prev.x;
+    const float p = ghc_atan2_sel(im, re);
+    return (re == 0.0f && im == 0.0f) ? 0.0f : p;
+}
+
+__global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__ in, float* __restrict__ out, int64_t count,
+                                                        int has_prev, float last_re, float last_im, int out_vec)
+{
+    // 4 samples per thread: five 8-byte loads (the IQ stream is only 8-byte aligned in
+    // general: it usually starts one sample into a buffer), one 16-byte store
+    const float2* in2 = reinterpret_cast<const float2*>(in);
+    const int64_t nquad = count >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += stride) {
+        const float2 s0 = in2[4 * q], s1 = in2[4 * q + 1], s2 = in2[4 * q + 2], s3 = in2[4 * q + 3];
+        float2 prev;
+        if (q > 0 || has_prev) prev = in2[4 * q - 1];
+        else prev = make_float2(last_re, last_im);
+        float4 r;
+        r.x = fm_phase_sel(s0, prev);
+        r.y = fm_phase_sel(s1, s0);
+        r.z = fm_phase_sel(s2, s1);
+        r.w = fm_phase_sel(s3, s2);
+        if (out_vec) {
+            reinterpret_cast<float4*>(out)[q] = r;
+        } else {
+            out[4 * q] = r.x; out[4 * q + 1] = r.y; out[4 * q + 2] = r.z; out[4 * q + 3] = r.w;
+        }
+    }
+    // tail (< 4 samples)
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+        const int64_t i = (nquad << 2) + threadIdx.x;
+        const float2 cur = in2[i];
+        float2 prev;
+        if (i > 0 || has_prev) prev = in2[i - 1];
+        else prev = make_float2(last_re, last_im);
+        out[i] = fm_phase_sel(cur, prev);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K5  symmetric real FIR, 8 lanes (filterAVXSymmetricRR, filter.c:60-68 ->
+// avx_sym_dotprod_R common.h:181-201):  out[o] = tree8( a_l ),
+//   a_l = sum_{k = l, l+8, ..} c[k] * (x[o+k] + x[o+2n-1-k])     (pair-add FIRST).
+// One workgroup = NT*R consecutive outputs staged in LDS; one thread = R consecutive
+// outputs; its window (R + 2n - 1 floats) is read with 16-byte LDS loads.
+// ---------------------------------------------------------------------------
+template <int NH, int R, int NT>
+__global__ void __launch_bounds__(NT) k_fir_sym8_fast(const float* __restrict__ in, int64_t x0, int count,
+                                                       const float* __restrict__ taps, float* __restrict__ out,
+                                                       float gain, int apply_gain, int aligned)
+{
+    constexpr int OUTS = NT * R;
+    constexpr int SPAN = OUTS + 2 * NH - 1;
+    constexpr int SPAN4 = (SPAN + 3) / 4;
+    constexpr int WIN = R + 2 * NH - 1;
+    constexpr int WIN4 = (WIN + 3) / 4;
+    static_assert(R % 4 == 0, "thread windows must start on 16-byte boundaries");
+    __shared__ __attribute__((aligned(16))) float lds[SPAN4 * 4 + 4];
+
+    const int out0 = blockIdx.x * OUTS;
+    const int64_t total_avail = (int64_t)count + 2 * NH - 1;
+    const int64_t av64 = total_avail - out0;
+    const int avail = av64 > SPAN ? SPAN : (int)av64;
+    const float* src = in + x0 + out0;
+    for (int v = threadIdx.x; v < SPAN4; v += NT) {
+        const int s = 4 * v;
+        float4 val;
+        if (aligned && s + 3 < avail) {
+            val = *reinterpret_cast<const float4*>(src + s);
+        } else {
+            val.x = s + 0 < avail ? src[s + 0] : 0.0f;
+            val.y = s + 1 < avail ? src[s + 1] : 0.0f;
+            val.z = s + 2 < avail ? src[s + 2] : 0.0f;
+            val.w = s + 3 < avail ? src[s + 3] : 0.0f;
+        }
+        *reinterpret_cast<float4*>(&lds[s]) = val;
+    }
+    __syncthreads();
+
+    float w[WIN4 * 4];
+    const float* win = lds + threadIdx.x * R;
+#pragma unroll
+    for (int i = 0; i < WIN4; i++) {
+        const float4 q = *reinterpret_cast<const float4*>(win + 4 * i);
+        w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+    }
+    float acc[R][8];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int l = 0; l < 8; l++) acc[r][l] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NH; k++) {
+        const float c = taps[k];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r][k & 7] = acc[r][k & 7] + c * (w[r + k] + w[r + 2 * NH - 1 - k]);
+    }
+    const int o = out0 + threadIdx.x * R;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        float res = ((acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3])) + ((acc[r][4] + acc[r][5]) + (acc[r][6] + acc[r][7]));
+        if (apply_gain) res = res * gain;
+        if (o + r < count) out[o + r] = res;
+    }
+}
+
+// Cross outputs of a real FIR / decimator: sequential over the Lp plain taps
+// (filterCrossHighLevel / decimateCrossHighLevel, FilterInternal.hs:397-408).
+__global__ void __launch_bounds__(256) k_fir_real_crossfix(Geom g, const float* __restrict__ xtaps,
+                                                            const float* __restrict__ in, float* __restrict__ out,
+                                                            int64_t first_seam, int nseams, int per_seam, float gain,
+                                                            int apply_gain)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseams * per_seam) return;
+    const int si = t / per_seam, ci = t - si * per_seam;
+    const int64_t edge = (first_seam + si) * g.seamBI;
+    const int64_t m = (edge + g.D - 1) / g.D - 1 - ci;
+    if (m < g.k_begin || m >= g.k_begin + g.count) return;
+    const int64_t v = m * g.D;
+    if (!(v < edge && v + g.Lp > edge)) return;
+    const float* x = in + (v - g.in_base);
+    float r = 0.0f;
+    for (int j = 0; j < g.Lp; j++) r = r + x[j] * xtaps[j];
+    if (apply_gain) r = r * gain;
+    out[m - g.k_begin] = r;
+}
+
+// ---------------------------------------------------------------------------
+// K4  polyphase resampler, 8 lanes (resampleAVXRR, resample.c:70-87), specialised
+// for NG polyphase groups of NLOOP (padded) taps.  The launch starts at an output
+// whose group is 0, so thread t owns outputs 3t..3t+NG-1 = groups 0..NG-1 and every
+// tap is wave-uniform.  inc[] (the per-group input increments) are compile-time.
+// ---------------------------------------------------------------------------
+template <int NG, int NLOOP, int INC0, int INC1, int INC2, int NT>
+__global__ void __launch_bounds__(NT) k_resample3_fast(const float* __restrict__ in, int64_t pos0, int ncycles,
+                                                        int64_t avail_total, const float* __restrict__ groups,
+                                                        int row_stride, float* __restrict__ out)
+{
+    static_assert(NG == 3, "specialised for three polyphase groups");
+    constexpr int PERIOD = INC0 + INC1 + INC2;
+    constexpr int PRE[3] = {0, INC0, INC0 + INC1};
+    constexpr int WIN = PRE[2] + NLOOP;                 // floats one thread reads
+    constexpr int SPAN = (NT - 1) * PERIOD + WIN;       // floats one workgroup reads
+    constexpr int SPAN4 = (SPAN + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float lds[SPAN4 * 4 + 4];
+
+    const int cyc0 = blockIdx.x * NT;
+    const int64_t base = pos0 + (int64_t)cyc0 * PERIOD;  // first input of this workgroup, relative to `in`
+    const int64_t av64 = avail_total - (int64_t)cyc0 * PERIOD;
+    const int avail = av64 > SPAN ? SPAN : (int)av64;
+    const float* src = in + base;
+    const bool al = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    for (int v = threadIdx.x; v < SPAN4; v += NT) {
+        const int s = 4 * v;
+        float4 val;
+        if (al && s + 3 < avail) {
+            val = *reinterpret_cast<const float4*>(src + s);
+        } else {
+            val.x = s + 0 < avail ? src[s + 0] : 0.0f;
+            val.y = s + 1 < avail ? src[s + 1] : 0.0f;
+            val.z = s + 2 < avail ? src[s + 2] : 0.0f;
+            val.w = s + 3 < avail ? src[s + 3] : 0.0f;
+        }
+        *reinterpret_cast<float4*>(&lds[s]) = val;
+    }
+    __syncthreads();
+
+    const int cyc = cyc0 + threadIdx.x;
+    if (cyc >= ncycles) return;
+    float w[WIN];
+    const float* win = lds + threadIdx.x * PERIOD;
+#pragma unroll
+    for (int i = 0; i < WIN; i++) w[i] = win[i];
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        const float* c = groups + g * row_stride;
+        float acc[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) acc[l] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NLOOP; j++) acc[j & 7] = acc[j & 7] + c[j] * w[PRE[g] + j];
+        out[(int64_t)cyc * 3 + g] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
+}
+
+// Cross outputs of the real resampler (resampleCrossHighLevel, FilterInternal.hs:410-423)
+__global__ void __launch_bounds__(256) k_resample_real_crossfix(Geom g, const float* __restrict__ plain, int ntaps,
+                                                                 const float* __restrict__ in, float* __restrict__ out,
+                                                                 int64_t first_seam, int nseams, int per_seam)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseams * per_seam) return;
+    const int si = t / per_seam, ci = t - si * per_seam;
+    const int64_t edge = (first_seam + si) * g.seamBI;          // in upsampled units
+    const int64_t m = (edge + g.D - 1) / g.D - 1 - ci;
+    if (m < g.k_begin || m >= g.k_begin + g.count) return;
+    const int64_t v = m * g.D;
+    if (!(v < edge && v + g.Lp > edge)) return;
+    const int64_t pos = (v + g.I - 1) / g.I;                     // inOff(m)
+    const int fo = (int)(pos * g.I - v);
+    const float* x = in + (pos - g.in_base);
+    float r = 0.0f;
+    for (int l = 0, j = fo; j < ntaps; l++, j += g.I) r = r + x[l] * plain[j];
+    out[m - g.k_begin] = r;
+}
+
+inline void seam_range(const Geom& g, int64_t& first, int64_t& last)
+{
+    const int64_t v_lo = g.k_begin * g.D, v_hi = (g.k_begin + g.count - 1) * g.D + g.Lp;
+    first = v_lo / g.seamBI + 1;
+    last = (v_hi - 1) / g.seamBI;
+}
+
+}  // namespace
+
+void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int64_t count, bool has_prev, float last_re,
+                          float last_im)
+{
+    if (count <= 0) return;
+    const int out_vec = ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0) ? 1 : 0;
+    int64_t blocks = ((count >> 2) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_fm_demod_fast, dim3((int)blocks), dim3(256), 0, s, d_in_iq, d_out, count, has_prev ? 1 : 0, last_re,
+                       last_im, out_vec);
+}
+
+bool launch_fir_sym8_fast(hipStream_t s, const Geom& g, const float* d_half_taps, int nhalf, const float* d_cross_taps,
+                          const float* d_in, float* d_out, float gain, bool apply_gain)
+{
+    if (g.I != 1 || g.D != 1 || nhalf != 64 || g.count <= 0 || g.seamBI < 0) return false;
+    if (g.seamBI != 0 && d_cross_taps == nullptr) return false;
+    constexpr int NH = 64, R = 4, NT = 256;
+    const int64_t x0 = g.k_begin - g.in_base;
+    const int aligned = ((reinterpret_cast<uintptr_t>(d_in + x0) & 15) == 0) ? 1 : 0;
+    const int tiles = (g.count + NT * R - 1) / (NT * R);
+    hipLaunchKernelGGL((k_fir_sym8_fast<NH, R, NT>), dim3(tiles), dim3(NT), 0, s, d_in, x0, g.count, d_half_taps, d_out, gain,
+                       apply_gain ? 1 : 0, aligned);
+    if (g.seamBI != 0) {
+        int64_t first, last;
+        seam_range(g, first, last);
+        if (last >= first) {
+            const int nseams = (int)(last - first + 1);
+            const int per = (g.Lp + g.D - 2) / g.D;
+            const int total = nseams * per;
+            hipLaunchKernelGGL(k_fir_real_crossfix, dim3((total + 255) / 256), dim3(256), 0, s, g, d_cross_taps, d_in, d_out,
+                               first, nseams, per, gain, apply_gain ? 1 : 0);
+        }
+    }
+    return true;
+}
+
+bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& t, const int* increments,
+                               const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out)
+{
+    // specialised for the FM chain's resampler: 3 groups, increments {4,3,3}, 64-float rows, AVX order
+    if (t.ngroups != 3 || t.nloop != 64 || g.seamBI < 0 || t.force_seq) return false;
+    if (!(increments[0] == 4 && increments[1] == 3 && increments[2] == 3)) return false;
+    if (g.seamBI != 0 && d_plain_taps == nullptr) return false;
+    if (g.count <= 0) return false;
+    constexpr int NT = 256;
+    // outputs before the first group-0 output and after the last whole cycle go to the generic kernel
+    int lead = (3 - t.group0) % 3;
+    if (lead > g.count) lead = g.count;
+    const int ncycles = (g.count - lead) / 3;
+    const int tail = g.count - lead - 3 * ncycles;
+    Geom gs = g;
+    gs.seamBI = 0;  // every output as One first; seams are fixed up below
+    if (lead > 0) {
+        Geom gl = gs;
+        gl.count = lead;
+        launch_resample_real(s, gl, 8, t, d_groups, d_plain_taps, d_in, d_out);
+    }
+    if (ncycles > 0) {
+        // position of the first group-0 output relative to d_in
+        int64_t pos = t.pos0 + (lead > 0 ? t.pre[lead - 1] + increments[(t.group0 + lead - 1) % 3] : 0);
+        const int64_t avail_total = (int64_t)(ncycles - 1) * 10 + 7 + 64;
+        const int blocks = (ncycles + NT - 1) / NT;
+        hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
+                           d_groups, t.row_stride, d_out + lead);
+    }
+    if (tail > 0) {
+        const int done = lead + 3 * ncycles;
+        Geom gt = gs;
+        gt.k_begin = g.k_begin + done;
+        gt.count = tail;
+        ResampTable tt = t;
+        tt.group0 = 0;
+        tt.pos0 = t.pos0 + (lead > 0 ? t.pre[lead - 1] + increments[(t.group0 + lead - 1) % 3] : 0) + (int64_t)ncycles * 10;
+        tt.pre[0] = 0; tt.pre[1] = 4; tt.pre[2] = 7;
+        launch_resample_real(s, gt, 8, tt, d_groups, d_plain_taps, d_in, d_out + done);
+    }
+    if (g.seamBI != 0) {
+        int64_t first, last;
+        seam_range(g, first, last);
+        if (last >= first) {
+            const int nseams = (int)(last - first + 1);
+            const int per = (g.Lp + g.D - 2) / g.D;
+            const int total = nseams * per;
+            hipLaunchKernelGGL(k_resample_real_crossfix, dim3((total + 255) / 256), dim3(256), 0, s, g, d_plain_taps,
+                               t.ntaps_plain, d_in, d_out, first, nseams, per);
+        }
+    }
+    return true;
+}
+
+}  // namespace sdrhip

@@ -207,7 +207,7 @@ int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
         SDRHIP_CHECK_HIP(hipMemcpyAsync(d.p, sl.hin.p, (size_t)n * ein, hipMemcpyHostToDevice, p->up));
         SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, p->up));
         SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->stream, sl.ev_up, 0));
-        launch_fm_demod(p->stream, (const float*)d.p, (float*)sl.dout.p, n, false, p->last_re, p->last_im);
+        launch_fm_demod_fast(p->stream, (const float*)d.p, (float*)sl.dout.p, n, false, p->last_re, p->last_im);
         SDRHIP_CHECK_HIP(hipGetLastError());
         SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, p->stream));
         SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->down, sl.ev_k, 0));

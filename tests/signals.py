@@ -43,8 +43,9 @@ def iq_u8(n_samples, seed=SEED_IQ):
     return np.random.default_rng(seed).integers(0, 256, 2 * n_samples, dtype=np.uint8)
 
 
-def iq_u8_fm(n_samples, fs=1.28e6, f_mod=1e3, dev=75e3, seed=SEED_IQ):
-    """u8-quantised unit-amplitude FM signal (1 kHz tone, 75 kHz deviation) + a little noise."""
+def iq_u8_fm(n_samples, fs=1.28e6, f_mod=1e3, dev=25e3, seed=SEED_IQ):
+    """u8-quantised FM signal (1 kHz tone, 25 kHz deviation: inside the +-40 kHz passband of
+    the 1/16-cutoff decimation filter) + a little noise."""
     t = np.arange(n_samples) / fs
     phase = 2 * np.pi * dev / (2 * np.pi * f_mod) * np.sin(2 * np.pi * f_mod * t)
     rng = np.random.default_rng(seed)

@@ -1,0 +1,131 @@
+"""The C-ABI boundary without a GPU: libsdr_hip.so loads, exports every symbol that
+include/sdr_hip.h declares (and every one of the reference's native symbols the hot
+path's FFI binds), descriptors and planning work on the host, and anything that
+needs the device fails LOUDLY instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import signals as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sdr_hip.h")
+
+# the reference's exported native surface (cpuid.c excluded: x86 only)
+REFERENCE_SYMBOLS = """filterRR filterSSERR filterAVXRR filterSSESymmetricRR filterAVXSymmetricRR filterRC filterSSERC
+filterSSERC2 filterAVXRC filterAVXRC2 filterSSESymmetricRC filterAVXSymmetricRC dcBlocker decimateRR decimateSSERR
+decimateAVXRR decimateSSESymmetricRR decimateAVXSymmetricRR decimateRC decimateSSERC decimateSSERC2 decimateAVXRC
+decimateAVXRC2 decimateSSESymmetricRC decimateAVXSymmetricRC resampleRR resample2RR resampleSSERR resampleAVXRR
+resample2RC resampleSSERC resampleAVXRC convertC convertCSSE convertCAVX convertCBladeRF convertCSSEBladeRF
+convertCAVXBladeRF convertBladeRFTransmit scale scaleSSE scaleAVX""".split()
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)
+    skip = {"defined", "sizeof"}
+    return sorted({n for n in names if n not in skip and not n.isupper()})
+
+
+@pytest.fixture(scope="module")
+def L():
+    import sdr_amd.lib as L
+    return L
+
+
+def test_library_exports_every_declared_symbol(L):
+    names = declared_functions()
+    assert len(names) > 80
+    missing = [n for n in names if not hasattr(L.lib, n)]
+    assert not missing, f"declared in sdr_hip.h but not exported: {missing}"
+
+
+def test_library_exports_the_reference_native_surface(L):
+    missing = [n for n in REFERENCE_SYMBOLS if not hasattr(L.lib, n)]
+    assert not missing
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libsdr_ref.so")):
+        import subprocess
+        out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "oracle", "_ref", "libsdr_ref.so")],
+                             capture_output=True, text=True).stdout
+        ref_syms = {l.split()[-1] for l in out.splitlines() if " T " in l}
+        assert not [s for s in ref_syms if s not in ("cpuid", "cpuid_extended") and not hasattr(L.lib, s)]
+
+
+def test_no_cpu_fallback_in_the_product():
+    """The product never imports / links the oracle."""
+    import subprocess
+    so = os.path.join(ROOT, "sdr_amd", "lib", "libsdr_hip.so")
+    out = subprocess.run(["nm", "-D", so], capture_output=True, text=True).stdout
+    assert "orc_" not in out
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sdr_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "libsdr_oracle" not in src, f
+
+
+def test_descriptors_and_padding_rules(L):
+    """numCoeffs as the reference's constructors compute them (Filter.hs:169,244,284,324,422)."""
+    t = S.taps_decim127()
+    assert L.Decimator(8, t, L.ORDER_AVX, complex_=True).num_coeffs == 128
+    assert L.Decimator(8, t, L.ORDER_SSE, complex_=True).num_coeffs == 128
+    assert L.Decimator(8, t, L.ORDER_SCALAR, complex_=True).num_coeffs == 127
+    assert L.Decimator(8, t, L.ORDER_AVX).num_coeffs == 128
+    assert L.Filter(t[:51], L.ORDER_AVX).num_coeffs == 56
+    assert L.Filter(t[:51], L.ORDER_SSE).num_coeffs == 52
+    assert L.Filter(S.taps_audio_half64(), L.ORDER_AVX, sym=True).num_coeffs == 128
+    r = L.Resampler(3, 10, S.taps_resamp191(), L.ORDER_AVX)
+    assert r.num_coeffs == 192 and r.num_groups == 3
+    assert L.Resampler(3, 10, S.taps_resamp191(), L.ORDER_SSE).num_coeffs == 192
+    assert L.Resampler(3, 10, S.taps_resamp191(), L.ORDER_SCALAR).num_coeffs == 192   # roundUp 191 (3*1)
+    assert [r.in_offset(m) for m in range(7)] == [0, 4, 7, 10, 14, 17, 20]
+    assert [r.filter_offset(m) for m in range(6)] == [0, 2, 1, 0, 2, 1]
+    assert [r.group(m) for m in range(6)] == [0, 1, 2, 0, 1, 2]
+    r2 = L.Resampler(2, 4, S.gauss_taps(40, 1), L.ORDER_AVX)     # gcd != 1: a single group
+    assert r2.num_groups == 1 and r2.in_offset(5) == 10
+    with pytest.raises(L.SdrHipError):
+        L.Filter(t[:30], L.ORDER_AVX, sym=True)
+    with pytest.raises(L.SdrHipError):
+        L.Filter(t[:32], L.ORDER_SCALAR, sym=True)           # "At least SSE4.2 required" (Filter.hs:261)
+    with pytest.raises(L.SdrHipError):
+        L.Resampler(10, 3, t)
+
+
+def test_chain_planning_on_the_host(L):
+    chain = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, 8192)
+    total = 100 * 8192
+    Q0, Q1, halo = chain.plan(0, total, total)
+    assert Q0 == 0 and halo == 0
+    K = (total - 128) // 8 + 1
+    M = (K * 3 - 192) // 10 + 1
+    assert Q1 == M - 127
+    # shards partition the outputs; each needs only a right halo bounded by max_halo
+    mh = chain.max_halo()
+    assert 3000 < mh < 5000
+    for n in (2, 3, 8):
+        Slen = total // n // 8 * 8
+        prev = 0
+        for r in range(n):
+            s0, s1 = r * Slen, (total if r == n - 1 else (r + 1) * Slen)
+            q0, q1, h = chain.plan(s0, s1, total)
+            assert q0 == prev and q1 >= q0 and 0 <= h <= mh
+            prev = q1
+        assert prev == Q1
+    with pytest.raises(L.SdrHipError):
+        L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, 100)  # block < filter
+
+
+def test_device_calls_fail_loudly_without_a_gpu(L):
+    if L.device_count() > 0:
+        pytest.skip("a GPU is present")
+    dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
+    buf = np.zeros(4096, np.float32)
+    with pytest.raises(L.SdrHipError):
+        dec.run(buf.ctypes.data, 0, buf.ctypes.data, 0, 4, 0)
+    p = C.c_void_p()
+    assert L.lib.sdrhip_malloc(C.byref(p), 1024) < 0
+    assert b"hipMalloc" in L.lib.sdrhip_last_error()
