@@ -6,7 +6,7 @@ examples/fm/fm.hs:34-41 -- u8 IQ -> cfloat (fused) -> 127(->128)-tap complex FIR
 decimate-by-8 -> fmDemod -> polyphase resample 3/10 (191 taps) -> 128-tap (64
 half-tap) symmetric FIR -> *0.2 -- with the reference Pipes' 8192-sample block
 seams reproduced bit-exactly.  One "step" = one pass of that chain over one batch
-of `--blocks` 8192-sample blocks per GPU (default 8192 blocks = 2^26 samples),
+of `--blocks` 8192-sample blocks per GPU (default 65536 blocks = 2^29 samples = 1 GiB of u8 IQ),
 inputs already resident in HBM.
 
 N > 1: one process per GPU (torch.distributed, backend "nccl" = RCCL).  The sample
@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=8192, help="8192-sample blocks per GPU per step")
+    ap.add_argument("--blocks", type=int, default=65536, help="8192-sample blocks per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -66,26 +66,42 @@ __device__ __forceinline__ tap8 load_tap_chunk(const float* taps, int c)
 template <int D, int P, int R, class T>
 __device__ __forceinline__ void mac_window(const float2* __restrict__ win, const float* __restrict__ taps, float2 (&acc)[R][4])
 {
-    constexpr int TC = 8;
-    static_assert(P % TC == 0, "taps are fetched in chunks of 8");
+    constexpr int TC = 8;                       // taps per scalar load == samples per block
+    static_assert(P % TC == 0 && T::WIN % TC == 0, "window and taps are walked in blocks of 8");
     constexpr int NCH = P / TC;
+    constexpr int NB = T::WIN / TC;             // sample blocks per thread
     tap8 tc[NCH];
+    float4 buf[2][TC / 2];                      // LDS reads are double-buffered one block ahead
     tc[0] = load_tap_chunk(taps, 0);
 #pragma unroll
-    for (int s = 0; s < T::WIN; s += 2) {
-        if (s % TC == 0 && s / TC + 1 < NCH) tc[s / TC + 1] = load_tap_chunk(taps, s / TC + 1);
-        const float4 v2 = *reinterpret_cast<const float4*>(&win[s + 2 * (s / T::CHUNK)]);
-        const float2 v[2] = {make_float2(v2.x, v2.y), make_float2(v2.z, v2.w)};
+    for (int i = 0; i < TC / 2; i++) buf[0][i] = *reinterpret_cast<const float4*>(&win[2 * i + 2 * ((2 * i) / T::CHUNK)]);
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const int ss = s + e;
+    for (int b = 0; b < NB; b++) {
+        // the fence inside load_tap_chunk keeps these reads (block b+1) here, ahead of block b's MACs
+        if (b + 1 < NCH) tc[b + 1] = load_tap_chunk(taps, b + 1);
+        else asm volatile("" ::: "memory");
+        if (b + 1 < NB) {
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int j = ss - r * D;
-                if (j >= 0 && j < P) {
-                    const float h = tc[j / TC][j % TC];
-                    acc[r][j & 3].x = acc[r][j & 3].x + h * v[e].x;
-                    acc[r][j & 3].y = acc[r][j & 3].y + h * v[e].y;
+            for (int i = 0; i < TC / 2; i++) {
+                const int s = TC * (b + 1) + 2 * i;
+                buf[(b + 1) & 1][i] = *reinterpret_cast<const float4*>(&win[s + 2 * (s / T::CHUNK)]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TC / 2; i++) {
+            const float4 v2 = buf[b & 1][i];
+            const float2 v[2] = {make_float2(v2.x, v2.y), make_float2(v2.z, v2.w)};
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int ss = TC * b + 2 * i + e;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int j = ss - r * D;
+                    if (j >= 0 && j < P) {
+                        const float h = tc[j / TC][j % TC];
+                        acc[r][j & 3].x = acc[r][j & 3].x + h * v[e].x;
+                        acc[r][j & 3].y = acc[r][j & 3].y + h * v[e].y;
+                    }
                 }
             }
         }
@@ -200,10 +216,12 @@ struct Stage {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         float4 f;
-                        f.x = ((float)(w[k] & 0xff) - 128.0f) * (1.0f / 128.0f);
-                        f.y = ((float)((w[k] >> 8) & 0xff) - 128.0f) * (1.0f / 128.0f);
-                        f.z = ((float)((w[k] >> 16) & 0xff) - 128.0f) * (1.0f / 128.0f);
-                        f.w = ((float)(w[k] >> 24) - 128.0f) * (1.0f / 128.0f);
+                        // (u - 128) * (1/128) == fma(u, 1/128, -1) exactly: every result is
+                        // representable, so the single rounding of the fma returns the same bits
+                        f.x = __builtin_fmaf((float)(w[k] & 0xff), 1.0f / 128.0f, -1.0f);
+                        f.y = __builtin_fmaf((float)((w[k] >> 8) & 0xff), 1.0f / 128.0f, -1.0f);
+                        f.z = __builtin_fmaf((float)((w[k] >> 16) & 0xff), 1.0f / 128.0f, -1.0f);
+                        f.w = __builtin_fmaf((float)(w[k] >> 24), 1.0f / 128.0f, -1.0f);
                         const int ss = s + 2 * k;
                         if (ss < T::SPAN + 1) *reinterpret_cast<float4*>(&lds[T::lds_idx(ss)]) = f;
                     }
@@ -352,19 +370,35 @@ __global__ void __launch_bounds__(256) k_decimate_c_crossfix(Geom g, const float
     if (!(v < edge && v + g.Lp > edge)) return;
     int64_t x = v - g.in_base;
     float re = 0.0f, im = 0.0f;
-    for (int j = 0; j < g.Lp; j++) {
-        float a, b;
-        if constexpr (U8) {
-            const uint8_t* p = reinterpret_cast<const uint8_t*>(in) + 2 * (x + j);
-            a = ((float)p[0] - 128.0f) * (1.0f / 128.0f);
-            b = ((float)p[1] - 128.0f) * (1.0f / 128.0f);
-        } else {
-            const float* p = reinterpret_cast<const float*>(in) + 2 * (x + j);
-            a = p[0];
-            b = p[1];
+    // 16-byte vector loads (the caller guarantees 16-byte aligned windows and Lp % 8 == 0)
+    if constexpr (U8) {
+        const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(in) + 2 * x);
+        for (int c = 0; c < g.Lp / 8; c++) {
+            const uint4 q = p[c];
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float a0 = ((float)(w[k] & 0xff) - 128.0f) * (1.0f / 128.0f);
+                const float b0 = ((float)((w[k] >> 8) & 0xff) - 128.0f) * (1.0f / 128.0f);
+                const float a1 = ((float)((w[k] >> 16) & 0xff) - 128.0f) * (1.0f / 128.0f);
+                const float b1 = ((float)(w[k] >> 24) - 128.0f) * (1.0f / 128.0f);
+                const float h0 = xtaps[8 * c + 2 * k], h1 = xtaps[8 * c + 2 * k + 1];
+                re = re + a0 * h0;
+                im = im + b0 * h0;
+                re = re + a1 * h1;
+                im = im + b1 * h1;
+            }
         }
-        re = re + a * xtaps[j];
-        im = im + b * xtaps[j];
+    } else {
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(in) + 2 * x);
+        for (int c = 0; c < g.Lp / 2; c++) {
+            const float4 q = p[c];
+            const float h0 = xtaps[2 * c], h1 = xtaps[2 * c + 1];
+            re = re + q.x * h0;
+            im = im + q.y * h0;
+            re = re + q.z * h1;
+            im = im + q.w * h1;
+        }
     }
     *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
 }
@@ -422,7 +456,7 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
                              const void* d_in, bool in_is_u8, float* d_out)
 {
     if (g.I != 1 || g.count <= 0 || g.seamBI < 0) return false;
-    if (!(g.D == 8 && P == 128)) return false;
+    if (!(g.D == 8 && P == 128 && g.Lp == 128)) return false;
     if (g.seamBI != 0 && d_cross_taps == nullptr) return false;
     int64_t x0 = g.k_begin * g.D - g.in_base;
     // vector loads need 16-byte aligned tile starts (tiles begin at multiples of 8 samples from x0)
