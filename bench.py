@@ -153,11 +153,18 @@ def main():
     import signals as S
     from sdr_amd import sharding
 
-    torch.cuda.set_device(local_rank)
-    L.check(L.lib.sdrhip_set_device(local_rank), "sdrhip_set_device")
+    # BENCH_BACKEND=gloo is a plumbing check only (several ranks may then share one GPU and the
+    # halo travels through host memory); the measured configuration is "nccl" = RCCL over xGMI.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev)
+    L.check(L.lib.sdrhip_set_device(dev), "sdrhip_set_device")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     chain = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), gain=0.2, block=BLOCK)
     S_len = args.blocks * BLOCK
@@ -172,7 +179,7 @@ def main():
 
     def step():
         if world > 1:
-            sharding.halo_exchange(buf, plan, dist)               # RCCL send/recv of the ntaps-1 overlap
+            sharding.halo_exchange(buf, plan, dist, via_host=(backend != "nccl"))   # RCCL send/recv of the ntaps-1 overlap
         chain.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q1, ws.data_ptr(), ws_bytes,
                   stream=sptr)
 
@@ -195,7 +202,7 @@ def main():
     chain.enable_timing(False)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -231,7 +238,7 @@ def main():
                 "workload": "full FM chain (u8 IQ -> decim8 127 taps -> fmDemod -> resamp 3/10 191 taps -> 128-tap sym filter -> *0.2), 8192-sample block seams",
                 "blocks_per_gpu_per_step": args.blocks,
                 "samples_per_gpu_per_step": S_len,
-                "sharding": "none" if world == 1 else f"contiguous shards x{world}, RCCL halo exchange of {plan.halo} samples/step",
+                "sharding": "none" if world == 1 else f"contiguous shards x{world}, {backend} halo exchange of {plan.halo_cap} samples/step",
                 "order": "AVX (bit-exact vs reference AVX path)",
             },
             "roofline": {

@@ -23,6 +23,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
+# Per-file extras.  kernels_chain.hip: the SLP vectoriser packs unrelated scalar f32 ops into
+# v_pk_* (no faster than scalar on gfx950: 4 cycles vs 2) and pays for it in v_mov shuffles.
+FILE_FLAGS = {"kernels_chain.hip": ["-fno-slp-vectorize"]}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
@@ -41,7 +46,7 @@ def _stale(out, deps):
 
 
 def _compile(src, obj, extra):
-    cmd = [HIPCC] + FLAGS + extra + ["-x", "hip", "-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + extra + ["-x", "hip", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
@@ -58,7 +63,7 @@ def build(force=False, save_temps=False, verbose=False):
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src) + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
+        if force or _stale(obj, [src, os.path.abspath(__file__)] + hdrs):
             jobs.append((src, obj))
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:

@@ -46,11 +46,10 @@ __device__ __forceinline__ float atanf_sel(float x)
     const float small = xr - xr * (s1 + s2);
     const float zz = hv - ((xr * (s1 + s2) - lv) - xr);
     float res = tiny_range ? small : (neg ? -zz : zz);
-    if (ix < 0x31000000u) res = x;                             // |x| < 2^-29
-    if (ix >= 0x4c000000u) {                                   // |x| >= 2^25, inf, nan
-        const float big = 1.5707962513e+00f + 7.5497894159e-08f;
-        res = ix > 0x7f800000u ? x + x : (neg ? -big : big);
-    }
+    res = ix < 0x31000000u ? x : res;                          // |x| < 2^-29
+    const float big = 1.5707962513e+00f + 7.5497894159e-08f;
+    const float huge_res = ix > 0x7f800000u ? x + x : (neg ? -big : big);
+    res = ix >= 0x4c000000u ? huge_res : res;                  // |x| >= 2^25, inf, nan
     return res;
 }
 
@@ -65,13 +64,13 @@ __device__ __forceinline__ float ghc_atan2_sel(float y, float x)
     const bool c1 = x > 0.0f;
     const float yy = (!c1 && fold) ? -y : y;
     const float a = atanf_sel(yy / x);
-    float r;
-    if (c1) r = a;                                            // clause 1 (never folded: x > 0)
-    else if (x == 0.0f && yy > 0.0f) r = pi / 2.0f;
-    else if (x < 0.0f && yy > 0.0f) r = pi + a;
-    else if (yy == 0.0f && (x < 0.0f || negzero(x))) r = pi;
-    else if (x == 0.0f && yy == 0.0f) r = yy;
-    else r = x + yy;
+    const bool xz = x == 0.0f, xn = x < 0.0f, yp = yy > 0.0f, yz = yy == 0.0f;
+    const float r = c1 ? a                                    // clause 1 (never folded: x > 0)
+                  : (xz && yp) ? pi / 2.0f
+                  : (xn && yp) ? pi + a
+                  : (yz && (xn || negzero(x))) ? pi
+                  : (xz && yz) ? yy
+                  : x + yy;
     return (!c1 && fold) ? -r : r;
 }
 
@@ -135,7 +134,6 @@ __global__ void __launch_bounds__(NT) k_fir_sym8_fast(const float* __restrict__ 
     constexpr int SPAN = OUTS + 2 * NH - 1;
     constexpr int SPAN4 = (SPAN + 3) / 4;
     constexpr int WIN = R + 2 * NH - 1;
-    constexpr int WIN4 = (WIN + 3) / 4;
     static_assert(R % 4 == 0, "thread windows must start on 16-byte boundaries");
     __shared__ __attribute__((aligned(16))) float lds[SPAN4 * 4 + 4];
 
@@ -159,23 +157,39 @@ __global__ void __launch_bounds__(NT) k_fir_sym8_fast(const float* __restrict__ 
     }
     __syncthreads();
 
-    float w[WIN4 * 4];
+    // Walk the half-taps eight at a time in a ROLLED loop (unrolling it lets the scheduler hoist
+    // all LDS reads to the top: 130+ VGPRs, spills, half the occupancy).  Iteration j
+    // (k = 8j..8j+7) needs the front samples w[8j .. 8j+R+6] and the back samples
+    // w[2NH-8-8j .. 2NH-1-8j+R-1]: three 16-byte LDS reads each.  With ~60 VGPRs eight waves
+    // per SIMD hide the LDS latency.
+    static_assert(R == 4 && NH % 8 == 0, "windows assume 4 outputs per thread, 8 half-taps per step");
+    typedef float f8v __attribute__((ext_vector_type(8)));
     const float* win = lds + threadIdx.x * R;
-#pragma unroll
-    for (int i = 0; i < WIN4; i++) {
-        const float4 q = *reinterpret_cast<const float4*>(win + 4 * i);
-        w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
-    }
     float acc[R][8];
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
         for (int l = 0; l < 8; l++) acc[r][l] = 0.0f;
+#pragma unroll 1
+    for (int j = 0; j < NH / 8; j++) {
+        const f8v c8 = *reinterpret_cast<const f8v*>(taps + 8 * j);      // wave-uniform: s_load_dwordx8
+        const float* fp = win + 8 * j;
+        const float* bp = win + 2 * NH - 8 - 8 * j;
+        float fw[12], bw[12];
 #pragma unroll
-    for (int k = 0; k < NH; k++) {
-        const float c = taps[k];
+        for (int q = 0; q < 3; q++) {
+            const float4 a = *reinterpret_cast<const float4*>(fp + 4 * q);
+            const float4 b = *reinterpret_cast<const float4*>(bp + 4 * q);
+            fw[4 * q] = a.x; fw[4 * q + 1] = a.y; fw[4 * q + 2] = a.z; fw[4 * q + 3] = a.w;
+            bw[4 * q] = b.x; bw[4 * q + 1] = b.y; bw[4 * q + 2] = b.z; bw[4 * q + 3] = b.w;
+        }
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r][k & 7] = acc[r][k & 7] + c * (w[r + k] + w[r + 2 * NH - 1 - k]);
+        for (int kk = 0; kk < 8; kk++) {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                // k = 8j+kk: front w[r+k] = fw[r+kk]; back w[r+2NH-1-k] = bw[r + 7 - kk]; lane k&7 = kk
+                acc[r][kk] = acc[r][kk] + c8[kk] * (fw[r + kk] + bw[r + 7 - kk]);
+        }
     }
     const int o = out0 + threadIdx.x * R;
 #pragma unroll
@@ -215,7 +229,7 @@ __global__ void __launch_bounds__(256) k_fir_real_crossfix(Geom g, const float* 
 // tap is wave-uniform.  inc[] (the per-group input increments) are compile-time.
 // ---------------------------------------------------------------------------
 template <int NG, int NLOOP, int INC0, int INC1, int INC2, int NT>
-__global__ void __launch_bounds__(NT) k_resample3_fast(const float* __restrict__ in, int64_t pos0, int ncycles,
+__global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restrict__ in, int64_t pos0, int ncycles,
                                                         int64_t avail_total, const float* __restrict__ groups,
                                                         int row_stride, float* __restrict__ out)
 {
@@ -250,10 +264,18 @@ __global__ void __launch_bounds__(NT) k_resample3_fast(const float* __restrict__
 
     const int cyc = cyc0 + threadIdx.x;
     if (cyc >= ncycles) return;
-    float w[WIN];
+    // window start = 10*t floats: 8-byte aligned, and a 10-dword lane stride is conflict-free
+    // for ds_read_b64 (distinct even banks within each 32-lane group)
+    static_assert(PERIOD % 2 == 0, "8-byte aligned thread windows");
+    float w[WIN + 1];
     const float* win = lds + threadIdx.x * PERIOD;
 #pragma unroll
-    for (int i = 0; i < WIN; i++) w[i] = win[i];
+    for (int i = 0; i < (WIN + 1) / 2; i++) {
+        const float2 q = *reinterpret_cast<const float2*>(win + 2 * i);
+        w[2 * i] = q.x;
+        w[2 * i + 1] = q.y;
+    }
+    float res[3];
 #pragma unroll
     for (int g = 0; g < 3; g++) {
         const float* c = groups + g * row_stride;
@@ -262,8 +284,12 @@ __global__ void __launch_bounds__(NT) k_resample3_fast(const float* __restrict__
         for (int l = 0; l < 8; l++) acc[l] = 0.0f;
 #pragma unroll
         for (int j = 0; j < NLOOP; j++) acc[j & 7] = acc[j & 7] + c[j] * w[PRE[g] + j];
-        out[(int64_t)cyc * 3 + g] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        res[g] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
+    // one 12-byte store per thread: the wave writes 768 contiguous bytes
+    struct __attribute__((packed, aligned(4))) f3 { float a, b, c; };
+    f3 v = {res[0], res[1], res[2]};
+    *reinterpret_cast<f3*>(out + (int64_t)cyc * 3) = v;
 }
 
 // Cross outputs of the real resampler (resampleCrossHighLevel, FilterInternal.hs:410-423)

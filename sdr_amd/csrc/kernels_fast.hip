@@ -175,30 +175,38 @@ struct Stage {
     __device__ __forceinline__ void load(const void* __restrict__ src_v, int64_t sample0, int avail)
     {
         const char* src = reinterpret_cast<const char*>(src_v) + (U8 ? 2 : 8) * sample0;
+        if (avail >= T::SPAN) {
+            // every tile but the last: unconditional 16-byte loads, all in flight together
 #pragma unroll
+            for (int i = 0; i < PER; i++) {
+                const int v = threadIdx.x + i * NT;
+                if (i + 1 < PER || v < NV) r[i] = *reinterpret_cast<const uint4*>(src + 16 * (int64_t)v);
+            }
+            return;
+        }
+        // ragged end of the stream (one workgroup per launch): element-wise, zero-filled (u8 128 == 0.0f)
+#pragma unroll 1
         for (int i = 0; i < PER; i++) {
             const int v = threadIdx.x + i * NT;
             const int s = v * SPV;
-            if (v < NV) {
-                if (s + SPV <= avail) {
-                    r[i] = *reinterpret_cast<const uint4*>(src + 16 * (int64_t)v);
-                } else {
-                    // ragged end of the stream: element-wise, zero-filled (u8 128 == 0.0f)
-                    uint32_t w[4];
+            uint32_t w[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) w[k] = U8 ? 0x80808080u : 0u;
-                    if constexpr (U8) {
-                        const uint8_t* b = reinterpret_cast<const uint8_t*>(src) + 16 * (int64_t)v;
-                        for (int e = 0; e < 16; e++)
-                            if (s + e / 2 < avail) w[e >> 2] = (w[e >> 2] & ~(0xffu << (8 * (e & 3)))) | ((uint32_t)b[e] << (8 * (e & 3)));
-                    } else {
-                        const uint32_t* f = reinterpret_cast<const uint32_t*>(src) + 4 * (int64_t)v;
-                        for (int e = 0; e < 4; e++)
-                            if (s + e / 2 < avail) w[e] = f[e];
-                    }
-                    r[i] = make_uint4(w[0], w[1], w[2], w[3]);
+            for (int k = 0; k < 4; k++) w[k] = U8 ? 0x80808080u : 0u;
+            if (v < NV) {
+                if constexpr (U8) {
+                    const uint8_t* b = reinterpret_cast<const uint8_t*>(src) + 16 * (int64_t)v;
+                    for (int e = 0; e < 16; e++)
+                        if (s + e / 2 < avail) w[e >> 2] = (w[e >> 2] & ~(0xffu << (8 * (e & 3)))) | ((uint32_t)b[e] << (8 * (e & 3)));
+                } else {
+                    const uint32_t* f = reinterpret_cast<const uint32_t*>(src) + 4 * (int64_t)v;
+                    for (int e = 0; e < 4; e++)
+                        if (s + e / 2 < avail) w[e] = f[e];
                 }
             }
+            // PER is small and compile-time: a select chain keeps r[] in registers
+#pragma unroll
+            for (int q = 0; q < PER; q++)
+                if (q == i) r[q] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
 

@@ -37,7 +37,7 @@ class ShardPlan:
         self.right = (rank + 1) % world
 
 
-def halo_exchange(buf_u8, plan, dist):
+def halo_exchange(buf_u8, plan, dist, via_host=False):
     """buf_u8: 1-D uint8 tensor of 2*(shard_len + halo_cap) bytes (interleaved IQ).
     Sends this rank's first halo_cap samples to the LEFT neighbour and receives the
     RIGHT neighbour's head into the halo region.  (For the last rank the right
@@ -46,6 +46,15 @@ def halo_exchange(buf_u8, plan, dist):
     head = buf_u8[:nb]
     tail = buf_u8[2 * plan.shard_len: 2 * plan.shard_len + nb]
     if plan.world == 1:
+        return
+    if via_host:
+        # plumbing check for backends without device-memory P2P (gloo + GPU buffers)
+        h_head = head.cpu()
+        h_tail = h_head.new_empty(h_head.shape)
+        ops = [dist.P2POp(dist.isend, h_head, plan.left), dist.P2POp(dist.irecv, h_tail, plan.right)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        tail.copy_(h_tail)
         return
     ops = [dist.P2POp(dist.isend, head, plan.left), dist.P2POp(dist.irecv, tail, plan.right)]
     for req in dist.batch_isend_irecv(ops):
