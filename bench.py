@@ -201,6 +201,32 @@ def main():
     stage_ms, runs = chain.read_timing()
     chain.enable_timing(False)
 
+    # BASELINE configs[1] (the north_star's roofline kernel): the same decimate-by-8 kernel fed
+    # cfloat IQ (8 B read + 1 B written per input sample), device-resident, 8192-sample seams.
+    cfg1 = None
+    if rank == 0 and world == 1:
+        n1 = 1 << 27
+        k1 = (n1 - 128) // 8 + 1
+        dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
+        x1 = torch.rand(2 * n1, device="cuda") * 2 - 1
+        o1 = torch.empty(2 * k1, device="cuda")
+        for _ in range(3):
+            dec.run(x1.data_ptr(), 0, o1.data_ptr(), 0, k1, BLOCK, stream=sptr)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record(stream)
+        for _ in range(reps):
+            dec.run(x1.data_ptr(), 0, o1.data_ptr(), 0, k1, BLOCK, stream=sptr)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        t1 = e0.elapsed_time(e1) * 1e-3 / reps
+        cfg1 = {"kernel": "k_decimate_c4 (cfloat in) + seam fix-up", "samples_per_launch": n1,
+                "avg_launch_ms": round(t1 * 1e3, 5), "Msamples_per_s": round(n1 / t1 / 1e6, 1),
+                "bound": "hbm", "achieved": round(9.0 * n1 / t1 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(9.0 * n1 / t1 / 1e9 / HBM_PEAK_GBS, 4),
+                "read_only_frac": round(8.0 * n1 / t1 / 1e9 / HBM_PEAK_GBS, 4)}
+        del x1, o1
+
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -256,6 +282,7 @@ def main():
                          "unit": "TFLOP/s (unfused f32 mul+add)",
                          "frac": round(k2_flops / k2_s / 1e12 / VALU_PEAK_TFLOPS, 4) if k2_s > 0 else 0.0},
             },
+            "roofline_config1_cfloat_decimate": cfg1,
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
             "cpu_baseline": cpu,
         }

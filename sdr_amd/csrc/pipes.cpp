@@ -61,7 +61,10 @@ struct sdrhip_pipe {
     } slot[2];
     int64_t pushes = 0;
 
-    std::deque<float> fifo;            // produced output floats not yet popped
+    // produced output floats not yet popped: contiguous storage + read cursor (memcpy in/out)
+    std::vector<float> fifo;
+    size_t fifo_head = 0;
+    size_t fifo_size() const { return fifo.size() - fifo_head; }
     std::deque<int> demod_blocks;      // fmDemod: output block lengths (one per input block)
 
     int esz_in() const { return cplx_in ? 2 : 1; }
@@ -107,7 +110,16 @@ static int harvest(sdrhip_pipe* p, int si)
     if (!s.busy) return SDRHIP_OK;
     SDRHIP_CHECK_HIP(hipEventSynchronize(s.ev));
     const float* h = (const float*)s.hout.p;
-    p->fifo.insert(p->fifo.end(), h, h + s.n_out);
+    if (p->fifo_head > 0 && p->fifo_head == p->fifo.size()) {
+        p->fifo.clear();
+        p->fifo_head = 0;
+    } else if (p->fifo_head > (1u << 20) && p->fifo_head * 2 > p->fifo.size()) {
+        p->fifo.erase(p->fifo.begin(), p->fifo.begin() + p->fifo_head);   // compact occasionally
+        p->fifo_head = 0;
+    }
+    const size_t old = p->fifo.size();
+    p->fifo.resize(old + (size_t)s.n_out);
+    memcpy(p->fifo.data() + old, h, (size_t)s.n_out * sizeof(float));
     s.busy = false;
     return SDRHIP_OK;
 }
@@ -116,7 +128,7 @@ static int ready_blocks(const sdrhip_pipe* p)
 {
     if (p->kind == PK_DEMOD) {
         // complete blocks = those whose floats have all been harvested
-        size_t have = p->fifo.size(), n = 0;
+        size_t have = p->fifo_size(), n = 0;
         for (int len : p->demod_blocks) {
             if (have < (size_t)len) break;
             have -= len;
@@ -124,7 +136,7 @@ static int ready_blocks(const sdrhip_pipe* p)
         }
         return (int)n;
     }
-    return (int)(p->fifo.size() / ((size_t)p->block_out * p->esz_out()));
+    return (int)(p->fifo_size() / ((size_t)p->block_out * p->esz_out()));
 }
 
 extern "C" {
@@ -309,8 +321,8 @@ int sdrhip_pipe_pop(sdrhip_pipe* p, float* out, int capacity)
     int len = p->kind == PK_DEMOD ? p->demod_blocks.front() : p->block_out;
     SDRHIP_REQUIRE(capacity >= len, "sdrhip_pipe_pop: capacity smaller than the block");
     size_t nf = (size_t)len * p->esz_out();
-    for (size_t i = 0; i < nf; i++) out[i] = p->fifo[i];
-    p->fifo.erase(p->fifo.begin(), p->fifo.begin() + nf);
+    memcpy(out, p->fifo.data() + p->fifo_head, nf * sizeof(float));
+    p->fifo_head += nf;
     if (p->kind == PK_DEMOD) p->demod_blocks.pop_front();
     return len;
 }

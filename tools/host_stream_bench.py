@@ -1,0 +1,75 @@
+"""PCIe-inclusive rates (never bench.py's `value`): (a) the whole FM chain with pinned, double-buffered
+H2D/D2H around the device-resident chain, (b) the Pipe operators on 8192-sample host blocks."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import sdr_amd.lib as L
+import signals as S
+
+B = 8192
+
+
+def chain_streamed(blocks_per_batch=8192, batches=12):
+    chain = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, B)
+    n = blocks_per_batch * B
+    halo = (chain.max_halo() + 7) // 8 * 8
+    q0, q1, _ = chain.plan(0, n, -1)
+    host_in = [torch.randint(0, 256, (2 * (n + halo),), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    host_out = [torch.empty(q1 - q0, dtype=torch.float32).pin_memory() for _ in range(2)]
+    dev_in = [torch.empty(2 * (n + halo), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    dev_out = [torch.empty(q1 - q0, dtype=torch.float32, device="cuda") for _ in range(2)]
+    wsb = chain.workspace_bytes(n + halo)
+    ws = [torch.empty(wsb, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+
+    def submit(i):
+        s = streams[i & 1]
+        with torch.cuda.stream(s):
+            dev_in[i & 1].copy_(host_in[i & 1], non_blocking=True)
+            chain.run(dev_in[i & 1].data_ptr(), 0, n + halo, dev_out[i & 1].data_ptr(), q0, q1, ws[i & 1].data_ptr(), wsb,
+                      stream=s.cuda_stream)
+            host_out[i & 1].copy_(dev_out[i & 1], non_blocking=True)
+
+    for i in range(2):
+        submit(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(batches):
+        streams[i & 1].synchronize()
+        submit(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"chain host-streamed (pinned, 2 streams, {n} samples/batch): {batches * n / dt / 1e6:10.1f} Msamples/s "
+          f"({batches * 2 * n / dt / 1e9:.1f} GB/s H2D)")
+
+
+def pipe_blocks(nblocks=512):
+    dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
+    pipe = L.firDecimator(dec, B)
+    x = np.random.default_rng(0).uniform(-1, 1, 2 * B).astype(np.float32)
+    for _ in range(8):
+        pipe.push(x)
+    t0 = time.perf_counter()
+    for _ in range(nblocks):
+        pipe.push(x)
+    pipe.flush()
+    dt = time.perf_counter() - t0
+    print(f"firDecimator Pipe on 8192-sample host blocks: {nblocks * B / dt / 1e6:10.1f} Msamples/s ({dt / nblocks * 1e6:.1f} us/block)")
+    big = np.random.default_rng(0).uniform(-1, 1, 2 * B * 1024).astype(np.float32)
+    pipe2 = L.firDecimator(dec, B)
+    for _ in range(2):
+        pipe2.push(big)
+    t0 = time.perf_counter()
+    for _ in range(8):
+        pipe2.push(big)
+    pipe2.flush()
+    dt = time.perf_counter() - t0
+    print(f"firDecimator Pipe on 8Mi-sample host blocks:  {8 * B * 1024 / dt / 1e6:10.1f} Msamples/s")
+
+
+if __name__ == "__main__":
+    print(L.device_name())
+    chain_streamed()
+    pipe_blocks()
