@@ -133,7 +133,6 @@ __global__ void __launch_bounds__(NT) k_fir_sym8_fast(const float* __restrict__ 
     constexpr int OUTS = NT * R;
     constexpr int SPAN = OUTS + 2 * NH - 1;
     constexpr int SPAN4 = (SPAN + 3) / 4;
-    constexpr int WIN = R + 2 * NH - 1;
     static_assert(R % 4 == 0, "thread windows must start on 16-byte boundaries");
     __shared__ __attribute__((aligned(16))) float lds[SPAN4 * 4 + 4];
 
@@ -222,6 +221,33 @@ __global__ void __launch_bounds__(256) k_fir_real_crossfix(Geom g, const float* 
     out[m - g.k_begin] = r;
 }
 
+// The filter case (D == 1, LP taps): the LP-1 straddlers of a seam have windows one sample apart;
+// one workgroup stages their union (2*LP - 2 floats, coalesced) in LDS and thread c walks window c.
+template <int LP>
+__global__ void __launch_bounds__(LP) k_filter_real_crossfix_lds(Geom g, const float* __restrict__ xtaps,
+                                                                  const float* __restrict__ in, float* __restrict__ out,
+                                                                  int64_t first_seam, float gain, int apply_gain)
+{
+    constexpr int UNI = 2 * LP - 2;
+    __shared__ float lds[2 * LP];
+    const int tid = threadIdx.x;
+    const int64_t edge = (first_seam + blockIdx.x) * g.seamBI;
+    const int64_t v0 = edge - (LP - 1);                               // first straddler starts here
+    const int64_t lo = g.k_begin - g.in_base, hi = g.k_begin + g.count - 1 + LP - g.in_base;
+    for (int e = tid; e < UNI; e += LP) {
+        const int64_t idx = v0 + e - g.in_base;
+        lds[e] = (idx >= lo && idx < hi) ? in[idx] : 0.0f;
+    }
+    __syncthreads();
+    const int64_t m = v0 + tid;                                        // candidates v0 .. v0 + LP - 2
+    if (tid >= LP - 1 || m < g.k_begin || m >= g.k_begin + g.count) return;
+    float r = 0.0f;
+#pragma unroll 16
+    for (int j = 0; j < LP; j++) r = r + lds[tid + j] * xtaps[j];
+    if (apply_gain) r = r * gain;
+    out[m - g.k_begin] = r;
+}
+
 // ---------------------------------------------------------------------------
 // K4  polyphase resampler, 8 lanes (resampleAVXRR, resample.c:70-87), specialised
 // for NG polyphase groups of NLOOP (padded) taps.  The launch starts at an output
@@ -292,22 +318,41 @@ __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restric
     *reinterpret_cast<f3*>(out + (int64_t)cyc * 3) = v;
 }
 
-// Cross outputs of the real resampler (resampleCrossHighLevel, FilterInternal.hs:410-423)
+// Cross outputs of the real resampler (resampleCrossHighLevel, FilterInternal.hs:410-423):
+// taps = stride I (drop filterOffset coeffs) over the UNPADDED taps, sequential.  A group of 32
+// lanes serves one seam: its <= PER straddlers read a union of <= UNI consecutive inputs, staged in LDS.
+template <int PER, int UNI>
 __global__ void __launch_bounds__(256) k_resample_real_crossfix(Geom g, const float* __restrict__ plain, int ntaps,
                                                                  const float* __restrict__ in, float* __restrict__ out,
-                                                                 int64_t first_seam, int nseams, int per_seam)
+                                                                 int64_t first_seam, int nseams, int64_t in_avail)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nseams * per_seam) return;
-    const int si = t / per_seam, ci = t - si * per_seam;
-    const int64_t edge = (first_seam + si) * g.seamBI;          // in upsampled units
-    const int64_t m = (edge + g.D - 1) / g.D - 1 - ci;
+    static_assert(PER <= 32, "one 32-lane group per seam");
+    constexpr int SPW = 8;                                        // seams per workgroup
+    __shared__ float lds[SPW][UNI];
+    const int tid = threadIdx.x, sl = tid >> 5, ci = tid & 31;
+    const int si = blockIdx.x * SPW + sl;
+    const bool live = si < nseams;
+    int64_t edge = 0, m_lo = 0, p_lo = 0;
+    if (live) {
+        edge = (first_seam + si) * g.seamBI;                     // in upsampled units
+        const int64_t m_hi = (edge + g.D - 1) / g.D - 1;         // last output starting before the edge
+        m_lo = m_hi - (PER - 1);
+        if (m_lo < 0) m_lo = 0;
+        p_lo = (m_lo * g.D + g.I - 1) / g.I;                     // inOff(m_lo): first input of the union
+        for (int e = ci; e < UNI; e += 32) {
+            const int64_t idx = p_lo + e - g.in_base;
+            lds[sl][e] = (idx >= 0 && idx < in_avail) ? in[idx] : 0.0f;
+        }
+    }
+    __syncthreads();
+    if (!live || ci >= PER) return;
+    const int64_t m = m_lo + ci;
     if (m < g.k_begin || m >= g.k_begin + g.count) return;
     const int64_t v = m * g.D;
     if (!(v < edge && v + g.Lp > edge)) return;
     const int64_t pos = (v + g.I - 1) / g.I;                     // inOff(m)
     const int fo = (int)(pos * g.I - v);
-    const float* x = in + (pos - g.in_base);
+    const float* x = lds[sl] + (pos - p_lo);
     float r = 0.0f;
     for (int l = 0, j = fo; j < ntaps; l++, j += g.I) r = r + x[l] * plain[j];
     out[m - g.k_begin] = r;
@@ -350,10 +395,9 @@ bool launch_fir_sym8_fast(hipStream_t s, const Geom& g, const float* d_half_taps
         seam_range(g, first, last);
         if (last >= first) {
             const int nseams = (int)(last - first + 1);
-            const int per = (g.Lp + g.D - 2) / g.D;
-            const int total = nseams * per;
-            hipLaunchKernelGGL(k_fir_real_crossfix, dim3((total + 255) / 256), dim3(256), 0, s, g, d_cross_taps, d_in, d_out,
-                               first, nseams, per, gain, apply_gain ? 1 : 0);
+            // D == 1, Lp == 128 here: one 128-thread workgroup per seam
+            hipLaunchKernelGGL((k_filter_real_crossfix_lds<128>), dim3(nseams), dim3(128), 0, s, g, d_cross_taps, d_in, d_out, first,
+                               gain, apply_gain ? 1 : 0);
         }
     }
     return true;
@@ -404,10 +448,12 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
         seam_range(g, first, last);
         if (last >= first) {
             const int nseams = (int)(last - first + 1);
-            const int per = (g.Lp + g.D - 2) / g.D;
-            const int total = nseams * per;
-            hipLaunchKernelGGL(k_resample_real_crossfix, dim3((total + 255) / 256), dim3(256), 0, s, g, d_plain_taps,
-                               t.ntaps_plain, d_in, d_out, first, nseams, per);
+            // Lp = 192, D = 10: <= 20 straddlers per seam, 3.33 inputs apart, each reading <= 64 inputs
+            constexpr int PER = 20, UNI = 64 + (PER * 10 + 2) / 3 + 4;
+            const int64_t last_m = g.k_begin + g.count - 1;
+            const int64_t in_avail = (last_m * g.D + g.I - 1) / g.I - g.in_base + t.nloop;          // inputs the caller guarantees
+            hipLaunchKernelGGL((k_resample_real_crossfix<PER, UNI>), dim3((nseams + 7) / 8), dim3(256), 0, s, g, d_plain_taps,
+                               t.ntaps_plain, d_in, d_out, first, nseams, in_avail);
         }
     }
     return true;

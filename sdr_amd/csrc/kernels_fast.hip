@@ -360,53 +360,65 @@ __global__ void __launch_bounds__(NT, WPS) k_decimate_c4_pipe(const void* __rest
 }
 
 // Cross outputs: sequential order over the Lp plain taps (decimateCrossHighLevel,
-// FilterInternal.hs:397-402).  One thread per (seam, candidate).
-template <bool U8>
-__global__ void __launch_bounds__(256) k_decimate_c_crossfix(Geom g, const float* __restrict__ xtaps,
-                                                             const void* __restrict__ in, float* __restrict__ out,
-                                                             int64_t first_seam, int nseams, int per_seam)
+// FilterInternal.hs:397-402).  The <= ceil((Lp-1)/D) straddlers of one seam have
+// windows that overlap almost entirely, so a group of PER threads stages their union
+// (Lp + (PER-1)*D samples, converted once) in LDS with coalesced loads and each
+// thread then walks its own window.  SPW seams per workgroup.
+template <bool U8, int D, int LP, int PER, int SPW>
+__global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const float* __restrict__ xtaps,
+                                                                   const void* __restrict__ in, float* __restrict__ out,
+                                                                   int64_t first_seam, int nseams)
 {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nseams * per_seam) return;
-    int si = t / per_seam, ci = t - si * per_seam;
-    int64_t edge = (first_seam + si) * g.seamBI;      // input index of the block boundary
-    // outputs with m*D < edge < m*D + Lp  <=>  m in (ceil((edge-Lp+1)/D) .. ceil(edge/D)-1]
-    int64_t m_hi = (edge + g.D - 1) / g.D - 1;
-    int64_t m = m_hi - ci;
-    if (m < g.k_begin || m >= g.k_begin + g.count) return;
-    int64_t v = m * g.D;
-    if (!(v < edge && v + g.Lp > edge)) return;
-    int64_t x = v - g.in_base;
-    float re = 0.0f, im = 0.0f;
-    // 16-byte vector loads (the caller guarantees 16-byte aligned windows and Lp % 8 == 0)
-    if constexpr (U8) {
-        const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(in) + 2 * x);
-        for (int c = 0; c < g.Lp / 8; c++) {
-            const uint4 q = p[c];
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float a0 = ((float)(w[k] & 0xff) - 128.0f) * (1.0f / 128.0f);
-                const float b0 = ((float)((w[k] >> 8) & 0xff) - 128.0f) * (1.0f / 128.0f);
-                const float a1 = ((float)((w[k] >> 16) & 0xff) - 128.0f) * (1.0f / 128.0f);
-                const float b1 = ((float)(w[k] >> 24) - 128.0f) * (1.0f / 128.0f);
-                const float h0 = xtaps[8 * c + 2 * k], h1 = xtaps[8 * c + 2 * k + 1];
-                re = re + a0 * h0;
-                im = im + b0 * h0;
-                re = re + a1 * h1;
-                im = im + b1 * h1;
+    static_assert(D == 8 && PER == 16, "LDS layout below is worked out for 16 candidates 8 samples apart");
+    constexpr int UNI = LP + (PER - 1) * D;          // samples in the union of one seam's windows
+    // layout: one float2 of padding after every 8 samples (candidate c then starts at 9c float2 = 18c
+    // dwords: 16 distinct bank pairs), rows 16 (mod 32) float2 apart (the two seams of a 32-lane group
+    // land on complementary banks): ds_read_b64 conflict-free.
+    constexpr int ROW = ((UNI + UNI / 8 + 31) / 32) * 32 + 16;
+    static_assert(UNI <= PER * SPW, "one staging pass per seam");
+    __shared__ float2 lds[SPW * ROW];
+    const int tid = threadIdx.x;
+    const int seam0 = blockIdx.x * SPW;
+    const int64_t lo = g.k_begin * D - g.in_base, hi = (g.k_begin + g.count - 1) * (int64_t)D + LP - g.in_base;
+    for (int sl = 0; sl < SPW; sl++) {
+        const int si = seam0 + sl;                                   // wave-uniform
+        if (si >= nseams) break;
+        const int64_t edge = (first_seam + si) * g.seamBI;
+        const int64_t m_hi = (edge + D - 1) / D - 1;                 // last output starting before the edge
+        const int64_t idx = (m_hi - (PER - 1)) * D + tid - g.in_base;
+        if (tid < UNI) {
+            float2 v = make_float2(0.0f, 0.0f);
+            // the union may reach before the launch's first window / past its last one: those samples
+            // only feed candidates that are discarded below
+            if (idx >= lo && idx < hi) {
+                if constexpr (U8) {
+                    const uchar2 u = *reinterpret_cast<const uchar2*>(reinterpret_cast<const uint8_t*>(in) + 2 * idx);
+                    v = make_float2(((float)u.x - 128.0f) * (1.0f / 128.0f), ((float)u.y - 128.0f) * (1.0f / 128.0f));
+                } else {
+                    v = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(in) + 2 * idx);
+                }
             }
+            lds[sl * ROW + tid + tid / 8] = v;
         }
-    } else {
-        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(in) + 2 * x);
-        for (int c = 0; c < g.Lp / 2; c++) {
-            const float4 q = p[c];
-            const float h0 = xtaps[2 * c], h1 = xtaps[2 * c + 1];
-            re = re + q.x * h0;
-            im = im + q.y * h0;
-            re = re + q.z * h1;
-            im = im + q.w * h1;
-        }
+    }
+    __syncthreads();
+    const int sl = tid / PER, ci = tid - sl * PER;
+    const int si = seam0 + sl;
+    if (si >= nseams) return;
+    const int64_t edge = (first_seam + si) * g.seamBI;
+    const int64_t m_hi = (edge + D - 1) / D - 1;
+    const int64_t m = m_hi - (PER - 1) + ci;
+    if (m < g.k_begin || m >= g.k_begin + g.count) return;
+    const int64_t vm = m * D;
+    if (!(vm < edge && vm + LP > edge)) return;
+    const float2* w = lds + sl * ROW + ci * (D + 1);
+    float re = 0.0f, im = 0.0f;
+#pragma unroll
+    for (int j = 0; j < LP; j++) {
+        const float2 x = w[j + j / 8];
+        const float h = xtaps[j];
+        re = re + x.x * h;
+        im = im + x.y * h;
     }
     *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
 }
@@ -509,13 +521,12 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
         int64_t last = (v_hi - 1) / g.seamBI;         // last boundary strictly below v_hi
         if (last >= first) {
             int nseams = (int)(last - first + 1);
-            int per = (g.Lp + g.D - 2) / g.D;          // ceil((Lp-1)/D) candidates per seam
-            int total = nseams * per;
-            dim3 grid((total + 255) / 256), block(256);
+            constexpr int PER = 16, SPW = 16;          // ceil((128-1)/8) = 16 candidates per seam
+            dim3 grid((nseams + SPW - 1) / SPW), block(PER * SPW);
             if (in_is_u8)
-                hipLaunchKernelGGL(k_decimate_c_crossfix<true>, grid, block, 0, s, g, d_cross_taps, d_in, d_out, first, nseams, per);
+                hipLaunchKernelGGL((k_decimate_c_crossfix<true, 8, 128, PER, SPW>), grid, block, 0, s, g, d_cross_taps, d_in, d_out, first, nseams);
             else
-                hipLaunchKernelGGL(k_decimate_c_crossfix<false>, grid, block, 0, s, g, d_cross_taps, d_in, d_out, first, nseams, per);
+                hipLaunchKernelGGL((k_decimate_c_crossfix<false, 8, 128, PER, SPW>), grid, block, 0, s, g, d_cross_taps, d_in, d_out, first, nseams);
         }
     }
     return true;
