@@ -382,22 +382,30 @@ void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int
 bool launch_fir_sym8_fast(hipStream_t s, const Geom& g, const float* d_half_taps, int nhalf, const float* d_cross_taps,
                           const float* d_in, float* d_out, float gain, bool apply_gain)
 {
-    if (g.I != 1 || g.D != 1 || nhalf != 64 || g.count <= 0 || g.seamBI < 0) return false;
+    if (g.I != 1 || g.D != 1 || !(nhalf == 64 || nhalf == 32) || g.count <= 0 || g.seamBI < 0) return false;
     if (g.seamBI != 0 && d_cross_taps == nullptr) return false;
-    constexpr int NH = 64, R = 4, NT = 256;
+    constexpr int R = 4, NT = 256;
     const int64_t x0 = g.k_begin - g.in_base;
     const int aligned = ((reinterpret_cast<uintptr_t>(d_in + x0) & 15) == 0) ? 1 : 0;
     const int tiles = (g.count + NT * R - 1) / (NT * R);
-    hipLaunchKernelGGL((k_fir_sym8_fast<NH, R, NT>), dim3(tiles), dim3(NT), 0, s, d_in, x0, g.count, d_half_taps, d_out, gain,
-                       apply_gain ? 1 : 0, aligned);
+    if (nhalf == 64)
+        hipLaunchKernelGGL((k_fir_sym8_fast<64, R, NT>), dim3(tiles), dim3(NT), 0, s, d_in, x0, g.count, d_half_taps, d_out, gain,
+                           apply_gain ? 1 : 0, aligned);
+    else
+        hipLaunchKernelGGL((k_fir_sym8_fast<32, R, NT>), dim3(tiles), dim3(NT), 0, s, d_in, x0, g.count, d_half_taps, d_out, gain,
+                           apply_gain ? 1 : 0, aligned);
     if (g.seamBI != 0) {
         int64_t first, last;
         seam_range(g, first, last);
         if (last >= first) {
             const int nseams = (int)(last - first + 1);
-            // D == 1, Lp == 128 here: one 128-thread workgroup per seam
-            hipLaunchKernelGGL((k_filter_real_crossfix_lds<128>), dim3(nseams), dim3(128), 0, s, g, d_cross_taps, d_in, d_out, first,
-                               gain, apply_gain ? 1 : 0);
+            // D == 1: one Lp-thread workgroup per seam
+            if (nhalf == 64)
+                hipLaunchKernelGGL((k_filter_real_crossfix_lds<128>), dim3(nseams), dim3(128), 0, s, g, d_cross_taps, d_in, d_out,
+                                   first, gain, apply_gain ? 1 : 0);
+            else
+                hipLaunchKernelGGL((k_filter_real_crossfix_lds<64>), dim3(nseams), dim3(64), 0, s, g, d_cross_taps, d_in, d_out,
+                                   first, gain, apply_gain ? 1 : 0);
         }
     }
     return true;
@@ -407,7 +415,7 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
                                const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out)
 {
     // specialised for the FM chain's resampler: 3 groups, increments {4,3,3}, 64-float rows, AVX order
-    if (t.ngroups != 3 || t.nloop != 64 || g.seamBI < 0 || t.force_seq) return false;
+    if (t.ngroups != 3 || !(t.nloop == 64 || t.nloop == 16) || g.seamBI < 0 || t.force_seq) return false;
     if (!(increments[0] == 4 && increments[1] == 3 && increments[2] == 3)) return false;
     if (g.seamBI != 0 && d_plain_taps == nullptr) return false;
     if (g.count <= 0) return false;
@@ -427,10 +435,14 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
     if (ncycles > 0) {
         // position of the first group-0 output relative to d_in
         int64_t pos = t.pos0 + (lead > 0 ? t.pre[lead - 1] + increments[(t.group0 + lead - 1) % 3] : 0);
-        const int64_t avail_total = (int64_t)(ncycles - 1) * 10 + 7 + 64;
+        const int64_t avail_total = (int64_t)(ncycles - 1) * 10 + 7 + t.nloop;
         const int blocks = (ncycles + NT - 1) / NT;
-        hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
-                           d_groups, t.row_stride, d_out + lead);
+        if (t.nloop == 64)
+            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
+                               d_groups, t.row_stride, d_out + lead);
+        else
+            hipLaunchKernelGGL((k_resample3_fast<3, 16, 4, 3, 3, NT>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
+                               d_groups, t.row_stride, d_out + lead);
     }
     if (tail > 0) {
         const int done = lead + 3 * ncycles;
@@ -448,7 +460,7 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
         seam_range(g, first, last);
         if (last >= first) {
             const int nseams = (int)(last - first + 1);
-            // Lp = 192, D = 10: <= 20 straddlers per seam, 3.33 inputs apart, each reading <= 64 inputs
+            // Lp <= 192, D = 10: <= 20 straddlers per seam, 3.33 inputs apart, each reading <= 64 inputs
             constexpr int PER = 20, UNI = 64 + (PER * 10 + 2) / 3 + 4;
             const int64_t last_m = g.k_begin + g.count - 1;
             const int64_t in_avail = (last_m * g.D + g.I - 1) / g.I - g.in_base + t.nloop;          // inputs the caller guarantees

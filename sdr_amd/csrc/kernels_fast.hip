@@ -49,11 +49,14 @@ struct Tile {
 // fences memory operations, so neither the tap loads nor the LDS reads of later
 // sample blocks can pile up at the top of the unrolled code.  Constant address
 // space + an SGPR-resident address => s_load_dwordx8.
-typedef float tap8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ tap8 load_tap_chunk(const float* taps, int c)
+template <int TC> struct TapVec;
+template <> struct TapVec<8> { typedef float type __attribute__((ext_vector_type(8))); };
+template <> struct TapVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <int TC>
+__device__ __forceinline__ typename TapVec<TC>::type load_tap_chunk(const float* taps, int c)
 {
-    typedef const __attribute__((address_space(4))) tap8* ctapp;
-    uint64_t a = reinterpret_cast<uint64_t>(taps) + 32u * (uint32_t)c;
+    typedef const __attribute__((address_space(4))) typename TapVec<TC>::type* ctapp;
+    uint64_t a = reinterpret_cast<uint64_t>(taps) + (4u * TC) * (uint32_t)c;
     asm volatile("" : "+s"(a));
     return *reinterpret_cast<ctapp>(a);
 }
@@ -66,19 +69,19 @@ __device__ __forceinline__ tap8 load_tap_chunk(const float* taps, int c)
 template <int D, int P, int R, class T>
 __device__ __forceinline__ void mac_window(const float2* __restrict__ win, const float* __restrict__ taps, float2 (&acc)[R][4])
 {
-    constexpr int TC = 8;                       // taps per scalar load == samples per block
-    static_assert(P % TC == 0 && T::WIN % TC == 0, "window and taps are walked in blocks of 8");
+    constexpr int TC = (P % 8 == 0) ? 8 : 4;    // taps per scalar load == samples per block
+    static_assert(P % TC == 0 && T::WIN % TC == 0, "window and taps are walked in blocks of TC");
     constexpr int NCH = P / TC;
     constexpr int NB = T::WIN / TC;             // sample blocks per thread
-    tap8 tc[NCH];
+    typename TapVec<TC>::type tc[NCH];
     float4 buf[2][TC / 2];                      // LDS reads are double-buffered one block ahead
-    tc[0] = load_tap_chunk(taps, 0);
+    tc[0] = load_tap_chunk<TC>(taps, 0);
 #pragma unroll
     for (int i = 0; i < TC / 2; i++) buf[0][i] = *reinterpret_cast<const float4*>(&win[2 * i + 2 * ((2 * i) / T::CHUNK)]);
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         // the fence inside load_tap_chunk keeps these reads (block b+1) here, ahead of block b's MACs
-        if (b + 1 < NCH) tc[b + 1] = load_tap_chunk(taps, b + 1);
+        if (b + 1 < NCH) tc[b + 1] = load_tap_chunk<TC>(taps, b + 1);
         else asm volatile("" ::: "memory");
         if (b + 1 < NB) {
 #pragma unroll
@@ -369,7 +372,7 @@ __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const
                                                                    const void* __restrict__ in, float* __restrict__ out,
                                                                    int64_t first_seam, int nseams)
 {
-    static_assert(D == 8 && PER == 16, "LDS layout below is worked out for 16 candidates 8 samples apart");
+    static_assert(D == 8 && PER == 16 && LP <= 128, "LDS layout below is worked out for 16 candidate slots 8 samples apart");
     constexpr int UNI = LP + (PER - 1) * D;          // samples in the union of one seam's windows
     // layout: one float2 of padding after every 8 samples (candidate c then starts at 9c float2 = 18c
     // dwords: 16 distinct bank pairs), rows 16 (mod 32) float2 apart (the two seams of a 32-lane group
@@ -476,7 +479,7 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
                              const void* d_in, bool in_is_u8, float* d_out)
 {
     if (g.I != 1 || g.count <= 0 || g.seamBI < 0) return false;
-    if (!(g.D == 8 && P == 128 && g.Lp == 128)) return false;
+    if (!(g.D == 8 && (P == 128 || P == 52) && g.Lp == P)) return false;
     if (g.seamBI != 0 && d_cross_taps == nullptr) return false;
     int64_t x0 = g.k_begin * g.D - g.in_base;
     // vector loads need 16-byte aligned tile starts (tiles begin at multiples of 8 samples from x0)
@@ -488,30 +491,20 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
     }
     if ((reinterpret_cast<uintptr_t>(d_out) & 15) != 0) return false;
     static const int variant = getenv("SDRHIP_K2_VARIANT") ? atoi(getenv("SDRHIP_K2_VARIANT")) : 3;
-    if (variant == 0) {
-        if (in_is_u8) launch_c4<8, 128, 4, 256, true>(s, g, d_plain_taps, d_in, d_out);
-        else launch_c4<8, 128, 4, 256, false>(s, g, d_plain_taps, d_in, d_out);
-    } else if (variant == 1) {
-        if (in_is_u8) launch_c4_pipe<8, 128, 4, 256, true, 2>(s, g, d_plain_taps, d_in, d_out);
-        else launch_c4_pipe<8, 128, 4, 256, false, 2>(s, g, d_plain_taps, d_in, d_out);
+    if (P == 52) {
+        // the tap count of the reference FM example's RF decimation filter (51 -> 52)
+        if (in_is_u8) launch_c4<8, 52, 2, 256, true>(s, g, d_plain_taps, d_in, d_out);
+        else launch_c4<8, 52, 2, 256, false>(s, g, d_plain_taps, d_in, d_out);
     } else if (variant == 2) {
         if (in_is_u8) launch_c4_pipe<8, 128, 2, 256, true, 4>(s, g, d_plain_taps, d_in, d_out);
         else launch_c4_pipe<8, 128, 2, 256, false, 4>(s, g, d_plain_taps, d_in, d_out);
-    } else if (variant == 7) {
-        if (in_is_u8) launch_c4_pipe<8, 128, 2, 512, true, 2>(s, g, d_plain_taps, d_in, d_out);
-        else launch_c4_pipe<8, 128, 2, 512, false, 2>(s, g, d_plain_taps, d_in, d_out);
-    } else if (variant == 3) {
-        if (in_is_u8) launch_c4<8, 128, 2, 256, true>(s, g, d_plain_taps, d_in, d_out);
-        else launch_c4<8, 128, 2, 256, false>(s, g, d_plain_taps, d_in, d_out);
-    } else if (variant == 4) {
-        if (in_is_u8) launch_c4<8, 128, 3, 256, true>(s, g, d_plain_taps, d_in, d_out);
-        else launch_c4<8, 128, 3, 256, false>(s, g, d_plain_taps, d_in, d_out);
     } else if (variant == 5) {
         if (in_is_u8) launch_c4<8, 128, 2, 512, true>(s, g, d_plain_taps, d_in, d_out);
         else launch_c4<8, 128, 2, 512, false>(s, g, d_plain_taps, d_in, d_out);
     } else {
-        if (in_is_u8) launch_c4<8, 128, 2, 128, true>(s, g, d_plain_taps, d_in, d_out);
-        else launch_c4<8, 128, 2, 128, false>(s, g, d_plain_taps, d_in, d_out);
+        // default: R = 2 outputs per thread, 256 threads, 4 workgroups per CU
+        if (in_is_u8) launch_c4<8, 128, 2, 256, true>(s, g, d_plain_taps, d_in, d_out);
+        else launch_c4<8, 128, 2, 256, false>(s, g, d_plain_taps, d_in, d_out);
     }
 
     if (g.seamBI != 0) {
@@ -521,12 +514,12 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
         int64_t last = (v_hi - 1) / g.seamBI;         // last boundary strictly below v_hi
         if (last >= first) {
             int nseams = (int)(last - first + 1);
-            constexpr int PER = 16, SPW = 16;          // ceil((128-1)/8) = 16 candidates per seam
+            constexpr int PER = 16, SPW = 16;          // 16 candidate slots per seam (ceil((128-1)/8))
             dim3 grid((nseams + SPW - 1) / SPW), block(PER * SPW);
-            if (in_is_u8)
-                hipLaunchKernelGGL((k_decimate_c_crossfix<true, 8, 128, PER, SPW>), grid, block, 0, s, g, d_cross_taps, d_in, d_out, first, nseams);
-            else
-                hipLaunchKernelGGL((k_decimate_c_crossfix<false, 8, 128, PER, SPW>), grid, block, 0, s, g, d_cross_taps, d_in, d_out, first, nseams);
+#define FIX(U, LPV) hipLaunchKernelGGL((k_decimate_c_crossfix<U, 8, LPV, PER, SPW>), grid, block, 0, s, g, d_cross_taps, d_in, d_out, first, nseams)
+            if (P == 52) { if (in_is_u8) FIX(true, 52); else FIX(false, 52); }
+            else { if (in_is_u8) FIX(true, 128); else FIX(false, 128); }
+#undef FIX
         }
     }
     return true;

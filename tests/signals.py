@@ -66,3 +66,21 @@ def real_block(n, seed=SEED_RF, lo=-1.0, hi=1.0):
 
 def gauss_taps(n, seed, sigma=0.05):
     return np.random.default_rng(seed).normal(0, sigma, n).astype(np.float32)
+
+
+# "Example-shaped" tap sets: the lengths of the reference FM example's real filters
+# (examples/fm/Coeffs.hs: 51-tap RF decimation filter, 31-tap audio resampler filter, 32 half-taps of
+# a 64-tap symmetric audio filter) with our own windowed-sinc values.
+def taps_decim51():
+    return windowed_sinc(51, 1.0 / 16, "blackman")
+
+
+def taps_resamp31():
+    return (3.0 * windowed_sinc(31, 1.0 / 10)).astype(np.float32)
+
+
+def taps_audio_half32():
+    n = np.arange(64) - 31.5
+    s = np.sin(np.pi * 0.3 * n) / (n * np.pi)
+    w = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(64) / 63)
+    return (s * w).astype(np.float32)[:32]
