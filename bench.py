@@ -149,7 +149,14 @@ def main():
 
     import torch
     import torch.distributed as dist
-    import sdr_amd.lib as L          # raises if libsdr_hip.so is missing: no fallback
+    from sdr_amd import build as _build
+    if not os.path.exists(_build.LIB) and local_rank == 0:
+        _build.build()               # a fresh checkout: compile the HIP library (hipcc is in the image)
+    for _ in range(600):
+        if os.path.exists(_build.LIB):
+            break
+        time.sleep(0.5)
+    import sdr_amd.lib as L          # raises if libsdr_hip.so is missing: there is no CPU fallback
     import signals as S
     from sdr_amd import sharding
 

@@ -36,6 +36,9 @@ def ref():
 @pytest.fixture(scope="session")
 def hip():
     """The product library through its ctypes binding; requires a GPU."""
+    from sdr_amd import build as B
+    if not os.path.exists(B.LIB):
+        B.build()
     import sdr_amd.lib as L
     if L.device_count() < 1:
         pytest.skip("no HIP device")

@@ -33,6 +33,9 @@ def declared_functions():
 
 @pytest.fixture(scope="module")
 def L():
+    from sdr_amd import build as B
+    if not os.path.exists(B.LIB):
+        B.build()
     import sdr_amd.lib as L
     return L
 
