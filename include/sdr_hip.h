@@ -247,10 +247,18 @@ size_t sdrhip_fm_chain_workspace_bytes(const sdrhip_fm_chain *c, int64_t n_in);
 int sdrhip_fm_chain_run(sdrhip_fm_chain *c, void *stream, const uint8_t *d_in_iq, int64_t s0, int64_t n_in,
                         float *d_audio, int64_t q0, int64_t q1, void *d_workspace, size_t workspace_bytes);
 
-/* Per-stage timing with HIP events recorded on the run's own stream between the
- * stages {decimate(+seam fix-up), fmDemod, resample, filter, gain}.  read_timing waits
- * for the recorded runs, returns the SUM of elapsed ms per stage over `*runs` runs
- * and resets the recorder. */
+/* One run can be software-pipelined over `nsub` sub-batches of the output range (default 1 = off;
+ * measured slower than off on MI355X, see chain.cpp):
+ * the decimate kernel of sub-batch i+1 runs on the caller's stream while fmDemod / resample /
+ * filter of sub-batch i run on an internal second HIP stream; the caller's stream is made to
+ * wait for the internal one before the call returns control of the stream.  Results do not
+ * depend on nsub (every kernel works in global stream indices). */
+int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain *c, int nsub);
+/* Per-stage timing with HIP events recorded around each stage's kernels on the stream they are
+ * launched on; stages {decimate(+seam fix-up), fmDemod, resample, filter(+gain), unused}.
+ * read_timing waits for the recorded runs, returns the SUM of elapsed ms per stage over
+ * `*runs` runs and resets the recorder.  With pipelining on, stages of neighbouring sub-batches
+ * overlap in time, so the per-stage sums add up to more than the run's wall time. */
 int sdrhip_fm_chain_enable_timing(sdrhip_fm_chain *c, int enable);
 int sdrhip_fm_chain_read_timing(sdrhip_fm_chain *c, double ms_sum[5], int *runs);
 

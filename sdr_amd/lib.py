@@ -93,6 +93,7 @@ lib.sdrhip_fm_chain_workspace_bytes.argtypes = [_vp, _i64]
 lib.sdrhip_fm_chain_workspace_bytes.restype = C.c_size_t
 lib.sdrhip_fm_chain_run.argtypes = [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, C.c_size_t]
 
+lib.sdrhip_fm_chain_set_pipelining.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_enable_timing.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_read_timing.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
@@ -335,6 +336,9 @@ class FmChain(_Handle):
         return lib.sdrhip_fm_chain_workspace_bytes(self.h, n_in)
 
     STAGES = ("decimate", "fm_demod", "resample", "filter", "gain")
+
+    def set_pipelining(self, nsub):
+        check(lib.sdrhip_fm_chain_set_pipelining(self.h, nsub), "sdrhip_fm_chain_set_pipelining")
 
     def enable_timing(self, on=True):
         check(lib.sdrhip_fm_chain_enable_timing(self.h, int(on)), "sdrhip_fm_chain_enable_timing")

@@ -160,3 +160,26 @@ def test_example_shaped_taps_chain(hip, oracle):
     chain.run(ptr(to_dev(u8)), 0, total, ptr(out), 0, q1, ptr(ws), ws.numel())
     assert exp.size >= 2 * B
     assert_bit_equal(to_host(out)[: exp.size], exp, "example-shaped chain")
+
+
+def test_chain_pipelining_is_invisible(hip):
+    """The internal two-stream software pipelining (nsub sub-batches) must not change a bit, and the
+    caller's stream must see the finished result without any extra synchronisation."""
+    n = 1 << 25
+    u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda")
+    chain = hip.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, B)
+    ws = torch.empty(chain.workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    q0, q1, _ = chain.plan(0, n, n)
+    outs = []
+    st = torch.cuda.Stream()
+    for nsub in (1, 8, 3, 16):
+        chain.set_pipelining(nsub)
+        out = torch.zeros(q1, dtype=torch.float32, device="cuda")
+        with torch.cuda.stream(st):
+            for _ in range(3):     # back-to-back runs reuse the workspace: exercises the cross-run ordering
+                chain.run(ptr(u8), 0, n, ptr(out), 0, q1, ptr(ws), ws.numel(), stream=st.cuda_stream)
+            res = out.clone()      # ordinary stream-ordered consumer, no explicit sync with the internal stream
+        st.synchronize()
+        outs.append(res)
+    for o in outs[1:]:
+        assert torch.equal(outs[0].view(torch.int32), o.view(torch.int32))
