@@ -383,25 +383,61 @@ __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const
     const int tid = threadIdx.x;
     const int seam0 = blockIdx.x * SPW;
     const int64_t lo = g.k_begin * D - g.in_base, hi = (g.k_begin + g.count - 1) * (int64_t)D + LP - g.in_base;
-    for (int sl = 0; sl < SPW; sl++) {
-        const int si = seam0 + sl;                                   // wave-uniform
-        if (si >= nseams) break;
-        const int64_t edge = (first_seam + si) * g.seamBI;
-        const int64_t m_hi = (edge + D - 1) / D - 1;                 // last output starting before the edge
-        const int64_t idx = (m_hi - (PER - 1)) * D + tid - g.in_base;
-        if (tid < UNI) {
-            float2 v = make_float2(0.0f, 0.0f);
-            // the union may reach before the launch's first window / past its last one: those samples
-            // only feed candidates that are discarded below
-            if (idx >= lo && idx < hi) {
-                if constexpr (U8) {
-                    const uchar2 u = *reinterpret_cast<const uchar2*>(reinterpret_cast<const uint8_t*>(in) + 2 * idx);
-                    v = make_float2(((float)u.x - 128.0f) * (1.0f / 128.0f), ((float)u.y - 128.0f) * (1.0f / 128.0f));
+    {
+        // staging: the PER lanes of a seam load its union with 16-byte vectors, all seams of the
+        // workgroup at once (one HBM round trip).  The union starts at a multiple of 8 samples, i.e.
+        // 16-byte aligned like the tiles of the main kernel.
+        const int sl = tid / PER, lane = tid - sl * PER;
+        const int si = seam0 + sl;
+        if (si < nseams) {
+            const int64_t edge = (first_seam + si) * g.seamBI;
+            const int64_t m_hi = (edge + D - 1) / D - 1;                 // last output starting before the edge
+            const int64_t u0 = (m_hi - (PER - 1)) * D - g.in_base;       // first sample of the union, relative to `in`
+            constexpr int SPV = U8 ? 8 : 2;                              // samples per 16-byte vector
+            constexpr int NV = (UNI + SPV - 1) / SPV;
+            float2* row = lds + sl * ROW;
+            for (int v = lane; v < NV; v += PER) {
+                const int64_t idx = u0 + (int64_t)v * SPV;
+                float2 smp[SPV];
+                // vectors that poke outside the launch's own windows only feed discarded candidates
+                if (idx >= lo && idx + SPV <= hi) {
+                    if constexpr (U8) {
+                        const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(in) + 2 * idx);
+                        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            smp[2 * k] = make_float2(((float)(w[k] & 0xff) - 128.0f) * (1.0f / 128.0f),
+                                                     ((float)((w[k] >> 8) & 0xff) - 128.0f) * (1.0f / 128.0f));
+                            smp[2 * k + 1] = make_float2(((float)((w[k] >> 16) & 0xff) - 128.0f) * (1.0f / 128.0f),
+                                                         ((float)(w[k] >> 24) - 128.0f) * (1.0f / 128.0f));
+                        }
+                    } else {
+                        const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(in) + 2 * idx);
+                        smp[0] = make_float2(q.x, q.y);
+                        smp[1] = make_float2(q.z, q.w);
+                    }
                 } else {
-                    v = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(in) + 2 * idx);
+#pragma unroll
+                    for (int k = 0; k < SPV; k++) {
+                        const int64_t ik = idx + k;
+                        float2 t = make_float2(0.0f, 0.0f);
+                        if (ik >= lo && ik < hi) {
+                            if constexpr (U8) {
+                                const uchar2 u = *reinterpret_cast<const uchar2*>(reinterpret_cast<const uint8_t*>(in) + 2 * ik);
+                                t = make_float2(((float)u.x - 128.0f) * (1.0f / 128.0f), ((float)u.y - 128.0f) * (1.0f / 128.0f));
+                            } else {
+                                t = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(in) + 2 * ik);
+                            }
+                        }
+                        smp[k] = t;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < SPV; k++) {
+                    const int so = v * SPV + k;
+                    if (so < UNI) row[so + so / 8] = smp[k];
                 }
             }
-            lds[sl * ROW + tid + tid / 8] = v;
         }
     }
     __syncthreads();
