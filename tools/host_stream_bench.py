@@ -69,7 +69,23 @@ def pipe_blocks(nblocks=512):
     print(f"firDecimator Pipe on 8Mi-sample host blocks:  {8 * B * 1024 / dt / 1e6:10.1f} Msamples/s")
 
 
+def resampler_pipe_cfg4(nblocks=256):
+    """BASELINE configs[3]: fastResamplerR 3/10, 191 taps, 65536-sample blocks streamed (async double-buffered)."""
+    r = L.Resampler(3, 10, S.taps_resamp191(), L.ORDER_AVX)
+    pipe = L.firResampler(r, 8192)
+    x = np.random.default_rng(1).uniform(-1, 1, 65536).astype(np.float32)
+    for _ in range(8):
+        pipe.push(x)
+    t0 = time.perf_counter()
+    for _ in range(nblocks):
+        pipe.push(x)
+    pipe.flush()
+    dt = time.perf_counter() - t0
+    print(f"firResampler Pipe 3/10 on 65536-sample host blocks: {nblocks * 65536 / dt / 1e6:10.1f} Msamples/s ({dt / nblocks * 1e6:.1f} us/block)")
+
+
 if __name__ == "__main__":
     print(L.device_name())
     chain_streamed()
     pipe_blocks()
+    resampler_pipe_cfg4()
