@@ -251,7 +251,15 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
 
-    const int tile = blockIdx.x;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (each XCD has its own L2).  Within every group
+    // of 64 consecutive tiles XCD x takes the 8 consecutive tiles [8x, 8x+8), so 7 of 8 tile-to-tile
+    // overlaps (120 samples each) hit in the SAME L2, while all XCDs still stream through the same
+    // ~2 MB neighbourhood of HBM (giving every XCD its own far-apart eighth of the buffer measured
+    // 20 % slower: DRAM locality matters more than the 3 % of re-reads).
+    const int ntiles = (count + T::OUTS - 1) / T::OUTS;
+    const int b = blockIdx.x;
+    const int tile = (b & ~63) + ((b & 7) << 3) + ((b >> 3) & 7);
+    if (tile >= ntiles) return;
     const int out0 = tile * T::OUTS;
     const int64_t s0 = (int64_t)out0 * D;                     // first sample of the tile, relative to x0
     const int64_t total_avail = (int64_t)(count - 1) * D + P; // samples that exist from x0 on
@@ -505,8 +513,9 @@ void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, 
         attr_set = true;
     }
     int tiles = (g.count + T::OUTS - 1) / T::OUTS;
+    int grid = ((tiles + 63) / 64) * 64;       // whole groups of 64: the kernel permutes blockIdx -> tile within a group
     int64_t x0 = g.k_begin * D - g.in_base;
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, taps, out);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, taps, out);
 }
 
 }  // namespace
