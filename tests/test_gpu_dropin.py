@@ -188,3 +188,34 @@ def test_dc_blocker(hip, ref):
                       exp.ctypes.data_as(C.POINTER(C.c_float)))
     assert_bit_equal(out, exp, "dcBlocker")
     assert fs == efs.value and fo == efo.value
+
+
+def test_empty_and_tiny_calls(hip, oracle):
+    """num = 0 is a no-op for every family (the reference's loops simply do not execute); the smallest
+    non-empty calls work."""
+    x = S.real_block(256)
+    h = S.gauss_taps(128, 4)
+    assert hip.DropIn.filt("filterAVXRR", 0, h, x).size == 0
+    assert hip.DropIn.decim("decimateAVXRC", 0, 8, duplicate(h), S.cfloat_block(256), True).size == 0
+    assert hip.DropIn.convert("convertCAVX", np.zeros(0, np.uint8)).size == 0
+    assert hip.DropIn.fm_demod(np.zeros(0, np.float32)).size == 0
+    prep = oracle.prepare_coeffs(8, 3, 10, S.taps_resamp191())
+    out, g = hip.DropIn.resample("resampleAVXRR", 0, prep["num_coeffs"], 2, prep["increments"], prep["groups"], x)
+    assert out.size == 0 and g == 2
+    assert_bit_equal(hip.DropIn.filt("filterAVXRR", 1, h, x[:128]), oracle.filter_rr(8, 1, h, x[:128]), "one output")
+    xc = S.cfloat_block(128)
+    assert_bit_equal(hip.DropIn.decim("decimateAVXRC", 1, 8, duplicate(h), xc, True), oracle.decimate_rc(4, 1, 8, duplicate(h), xc), "one output")
+
+
+def test_reference_test_suite_maximum_size(hip, oracle):
+    """The largest size of the reference's generators (65536, TestSuite.hs:55) with its largest taps (1024)."""
+    n, ntaps = 65536, 1024
+    rng = np.random.default_rng(99)
+    x = rng.uniform(-10, 10, n).astype(np.float32)
+    xc = rng.uniform(-10, 10, 2 * n).astype(np.float32)
+    h = rng.uniform(-10, 10, ntaps).astype(np.float32)
+    num = n - ntaps + 1
+    assert_bit_equal(hip.DropIn.filt("filterAVXRR", num, h, x), oracle.filter_rr(8, num, h, x), "filterAVXRR 65536/1024")
+    assert_bit_equal(hip.DropIn.filt("filterAVXSymmetricRR", num, h[:512], x), oracle.filter_sym_rr(8, num, h[:512], x), "sym")
+    nd = (n - ntaps) // 23 + 1
+    assert_bit_equal(hip.DropIn.decim("decimateAVXRC", nd, 23, duplicate(h), xc, True), oracle.decimate_rc(4, nd, 23, duplicate(h), xc), "decimateAVXRC /23")
