@@ -142,6 +142,9 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
         if (d->corder == CO_L4 &&
             launch_decimate_c4_fast(s, g, d->d_plain, d->Lp, d->d_cross, d_in, in_u8, d_out)) {
             // specialised kernel took it
+        } else if (d->corder == CO_L4 && !in_u8 &&
+                   launch_filter_cplx4_fast(s, g, d->d_taps, d->Lp, d->d_cross, (const float*)d_in, d_out)) {
+            // LDS-tiled complex filter took it
         } else if (in_u8) {
             launch_fir_cplx_u8(s, g, d->corder, d->d_taps, d->ntaps_kernel, d->d_cross, (const uint8_t*)d_in, d_out);
         } else {
@@ -150,8 +153,8 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
         if (gain != 1.0f) launch_scale(s, gain, d_out, d_out, 2 * (int64_t)g.count);
     } else {
         SDRHIP_REQUIRE(!in_u8, "fir_run: u8 input is IQ data, complex stages only");
-        if (d->sym && d->lanes == 8 &&
-            launch_fir_sym8_fast(s, g, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out, gain, gain != 1.0f)) {
+        if (d->lanes == 8 &&
+            launch_fir_real8_fast(s, g, d->sym, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out, gain, gain != 1.0f)) {
             // LDS-tiled kernel took it (gain fused)
         } else {
             launch_fir_real(s, g, d->lanes, d->sym, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out);

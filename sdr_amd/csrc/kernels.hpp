@@ -83,8 +83,12 @@ void launch_dc_blocker(hipStream_t s, int64_t num, float last_sample, float last
 // kernels_chain.hip: fast paths of the low-rate stages
 void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int64_t count, bool has_prev,
                           float last_re, float last_im);
-bool launch_fir_sym8_fast(hipStream_t s, const Geom& g, const float* d_half_taps, int nhalf, const float* d_cross_taps,
+// real filters (D == 1), AVX order, nk taps walked (half-taps when sym), nk % 8 == 0
+bool launch_fir_real8_fast(hipStream_t s, const Geom& g, bool sym, const float* d_taps, int nk, const float* d_cross_taps,
                           const float* d_in, float* d_out, float gain, bool apply_gain);
+// complex filter (D == 1), AVX "RC" order, duplicated taps (2P floats), P % 4 == 0
+bool launch_filter_cplx4_fast(hipStream_t s, const Geom& g, const float* d_dup_taps, int P, const float* d_cross_taps,
+                              const float* d_in, float* d_out);
 bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& t, const int* increments,
                                const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out);
 bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps,

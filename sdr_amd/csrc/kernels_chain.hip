@@ -119,29 +119,37 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------
-// K5  symmetric real FIR, 8 lanes (filterAVXSymmetricRR, filter.c:60-68 ->
-// avx_sym_dotprod_R common.h:181-201):  out[o] = tree8( a_l ),
-//   a_l = sum_{k = l, l+8, ..} c[k] * (x[o+k] + x[o+2n-1-k])     (pair-add FIRST).
-// One workgroup = NT*R consecutive outputs staged in LDS; one thread = R consecutive
-// outputs; its window (R + 2n - 1 floats) is read with 16-byte LDS loads.
+// K5  real FIR filters (D = 1), 8 lanes:
+//   SYM  (filterAVXSymmetricRR, filter.c:60-68 -> avx_sym_dotprod_R common.h:181-201):
+//        out[o] = tree8(a_l),  a_l = sum_{k = l, l+8, ..} c[k] * (x[o+k] + x[o+2n-1-k])   (pair-add FIRST)
+//   !SYM (filterAVXRR, filter.c:36-46 -> avx_dotprod_R common.h:58-72):
+//        a_l = sum_{k = l, l+8, ..} c[k] * x[o+k]
+// nk = number of taps the kernel walks (n half-taps / all taps), a multiple of 8, run-time.
+// One workgroup = NT*R consecutive outputs staged in (dynamic) LDS; one thread = R = 4
+// consecutive outputs.  The taps are walked eight at a time in a ROLLED loop (unrolling it lets
+// the scheduler hoist all LDS reads to the top: 130+ VGPRs, spills, half the occupancy);
+// iteration j (k = 8j..8j+7) needs the front samples w[8j .. 8j+R+6] and, for SYM, the back
+// samples w[2n-8-8j .. 2n-1-8j+R-1]: three 16-byte LDS reads each.
 // ---------------------------------------------------------------------------
-template <int NH, int R, int NT>
-__global__ void __launch_bounds__(NT) k_fir_sym8_fast(const float* __restrict__ in, int64_t x0, int count,
-                                                       const float* __restrict__ taps, float* __restrict__ out,
-                                                       float gain, int apply_gain, int aligned)
+template <bool SYM, int R, int NT>
+__global__ void __launch_bounds__(NT) k_fir_real8_fast(const float* __restrict__ in, int64_t x0, int count,
+                                                        const float* __restrict__ taps, int nk, float* __restrict__ out,
+                                                        float gain, int apply_gain, int aligned)
 {
+    static_assert(R == 4, "windows assume 4 outputs per thread (16-byte aligned thread windows)");
     constexpr int OUTS = NT * R;
-    constexpr int SPAN = OUTS + 2 * NH - 1;
-    constexpr int SPAN4 = (SPAN + 3) / 4;
-    static_assert(R % 4 == 0, "thread windows must start on 16-byte boundaries");
-    __shared__ __attribute__((aligned(16))) float lds[SPAN4 * 4 + 4];
+    const int full = SYM ? 2 * nk : nk;                 // filter length
+    const int span = OUTS + full - 1;
+    const int span4 = (span + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    float* lds = lds_dyn;
 
     const int out0 = blockIdx.x * OUTS;
-    const int64_t total_avail = (int64_t)count + 2 * NH - 1;
+    const int64_t total_avail = (int64_t)count + full - 1;
     const int64_t av64 = total_avail - out0;
-    const int avail = av64 > SPAN ? SPAN : (int)av64;
+    const int avail = av64 > span ? span : (int)av64;
     const float* src = in + x0 + out0;
-    for (int v = threadIdx.x; v < SPAN4; v += NT) {
+    for (int v = threadIdx.x; v < span4 + 3; v += NT) {       // + 3: the last window's reads run 12 floats past it
         const int s = 4 * v;
         float4 val;
         if (aligned && s + 3 < avail) {
@@ -156,12 +164,6 @@ __global__ void __launch_bounds__(NT) k_fir_sym8_fast(const float* __restrict__ 
     }
     __syncthreads();
 
-    // Walk the half-taps eight at a time in a ROLLED loop (unrolling it lets the scheduler hoist
-    // all LDS reads to the top: 130+ VGPRs, spills, half the occupancy).  Iteration j
-    // (k = 8j..8j+7) needs the front samples w[8j .. 8j+R+6] and the back samples
-    // w[2NH-8-8j .. 2NH-1-8j+R-1]: three 16-byte LDS reads each.  With ~60 VGPRs eight waves
-    // per SIMD hide the LDS latency.
-    static_assert(R == 4 && NH % 8 == 0, "windows assume 4 outputs per thread, 8 half-taps per step");
     typedef float f8v __attribute__((ext_vector_type(8)));
     const float* win = lds + threadIdx.x * R;
     float acc[R][8];
@@ -170,24 +172,31 @@ __global__ void __launch_bounds__(NT) k_fir_sym8_fast(const float* __restrict__ 
 #pragma unroll
         for (int l = 0; l < 8; l++) acc[r][l] = 0.0f;
 #pragma unroll 1
-    for (int j = 0; j < NH / 8; j++) {
+    for (int j = 0; j < nk / 8; j++) {
         const f8v c8 = *reinterpret_cast<const f8v*>(taps + 8 * j);      // wave-uniform: s_load_dwordx8
         const float* fp = win + 8 * j;
-        const float* bp = win + 2 * NH - 8 - 8 * j;
         float fw[12], bw[12];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             const float4 a = *reinterpret_cast<const float4*>(fp + 4 * q);
-            const float4 b = *reinterpret_cast<const float4*>(bp + 4 * q);
             fw[4 * q] = a.x; fw[4 * q + 1] = a.y; fw[4 * q + 2] = a.z; fw[4 * q + 3] = a.w;
-            bw[4 * q] = b.x; bw[4 * q + 1] = b.y; bw[4 * q + 2] = b.z; bw[4 * q + 3] = b.w;
+        }
+        if constexpr (SYM) {
+            const float* bp = win + 2 * nk - 8 - 8 * j;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const float4 b = *reinterpret_cast<const float4*>(bp + 4 * q);
+                bw[4 * q] = b.x; bw[4 * q + 1] = b.y; bw[4 * q + 2] = b.z; bw[4 * q + 3] = b.w;
+            }
         }
 #pragma unroll
         for (int kk = 0; kk < 8; kk++) {
 #pragma unroll
-            for (int r = 0; r < R; r++)
-                // k = 8j+kk: front w[r+k] = fw[r+kk]; back w[r+2NH-1-k] = bw[r + 7 - kk]; lane k&7 = kk
-                acc[r][kk] = acc[r][kk] + c8[kk] * (fw[r + kk] + bw[r + 7 - kk]);
+            for (int r = 0; r < R; r++) {
+                // k = 8j+kk: front w[r+k] = fw[r+kk]; back w[r+2n-1-k] = bw[r + 7 - kk]; lane k&7 = kk
+                if constexpr (SYM) acc[r][kk] = acc[r][kk] + c8[kk] * (fw[r + kk] + bw[r + 7 - kk]);
+                else acc[r][kk] = acc[r][kk] + c8[kk] * fw[r + kk];
+            }
         }
     }
     const int o = out0 + threadIdx.x * R;
@@ -197,6 +206,110 @@ __global__ void __launch_bounds__(NT) k_fir_sym8_fast(const float* __restrict__ 
         if (apply_gain) res = res * gain;
         if (o + r < count) out[o + r] = res;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Complex FIR filter (D = 1), real taps, AVX "RC" order (filterAVXRC, filter.c:106-114): 4 complex
+// lanes over DUPLICATED taps (re uses taps[2k], im uses taps[2k+1], honoured as passed),
+// out = (L0+L1)+(L2+L3).  Same tiling as above with float2 elements: R = 4 outputs per thread,
+// 4 taps per rolled step (w[4j .. 4j+6]: four 16-byte LDS reads, one s_load_dwordx8 of taps).
+// ---------------------------------------------------------------------------
+template <int R, int NT>
+__global__ void __launch_bounds__(NT) k_filter_cplx4_fast(const float* __restrict__ in, int64_t x0, int count,
+                                                           const float* __restrict__ taps2, int P, float* __restrict__ out)
+{
+    static_assert(R == 4, "4 outputs per thread");
+    constexpr int OUTS = NT * R;
+    const int span = OUTS + P - 1;                        // complex samples
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    float2* lds = reinterpret_cast<float2*>(lds_dyn);
+
+    const int out0 = blockIdx.x * OUTS;
+    const int64_t total_avail = (int64_t)count + P - 1;
+    const int64_t av64 = total_avail - out0;
+    const int avail = av64 > span ? span : (int)av64;
+    const float2* src = reinterpret_cast<const float2*>(in) + x0 + out0;
+    const bool al = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    for (int v = threadIdx.x; v < (span + 1) / 2 + 4; v += NT) {   // + 4: the last window's reads run 8 samples past it
+        const int s = 2 * v;
+        float4 val;
+        if (al && s + 1 < avail) {
+            val = *reinterpret_cast<const float4*>(src + s);
+        } else {
+            const float2 a = s < avail ? src[s] : make_float2(0.0f, 0.0f);
+            const float2 b = s + 1 < avail ? src[s + 1] : make_float2(0.0f, 0.0f);
+            val = make_float4(a.x, a.y, b.x, b.y);
+        }
+        *reinterpret_cast<float4*>(&lds[s]) = val;
+    }
+    __syncthreads();
+
+    typedef float f8v __attribute__((ext_vector_type(8)));
+    const float2* win = lds + threadIdx.x * R;
+    float2 acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int l = 0; l < 4; l++) acc[r][l] = make_float2(0.0f, 0.0f);
+    // sliding 8-sample window: w[0..3] carried from the previous step, w[4..7] read fresh (two 16-byte reads)
+    float2 w[8];
+    {
+        const float4 a = *reinterpret_cast<const float4*>(win);
+        const float4 b = *reinterpret_cast<const float4*>(win + 2);
+        w[4] = make_float2(a.x, a.y); w[5] = make_float2(a.z, a.w);
+        w[6] = make_float2(b.x, b.y); w[7] = make_float2(b.z, b.w);
+    }
+#pragma unroll 1
+    for (int j = 0; j < P / 4; j++) {
+        const f8v c8 = *reinterpret_cast<const f8v*>(taps2 + 8 * j);     // (re,im) tap pairs of taps 4j..4j+3
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = w[q + 4];
+        {
+            const float4 a = *reinterpret_cast<const float4*>(win + 4 * j + 4);
+            const float4 b = *reinterpret_cast<const float4*>(win + 4 * j + 6);
+            w[4] = make_float2(a.x, a.y); w[5] = make_float2(a.z, a.w);
+            w[6] = make_float2(b.x, b.y); w[7] = make_float2(b.z, b.w);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                acc[r][kk].x = acc[r][kk].x + c8[2 * kk] * w[r + kk].x;
+                acc[r][kk].y = acc[r][kk].y + c8[2 * kk + 1] * w[r + kk].y;
+            }
+        }
+    }
+    const int o = out0 + threadIdx.x * R;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const float2 res = make_float2((acc[r][0].x + acc[r][1].x) + (acc[r][2].x + acc[r][3].x),
+                                       (acc[r][0].y + acc[r][1].y) + (acc[r][2].y + acc[r][3].y));
+        if (o + r < count) *reinterpret_cast<float2*>(out + 2 * (int64_t)(o + r)) = res;
+    }
+}
+
+// Cross outputs of a complex filter / decimator: sequential over the Lp plain taps
+// (filterCrossHighLevel with Mult (Complex a) a, FilterInternal.hs:397-408, Util.hs:87-88).
+__global__ void __launch_bounds__(256) k_fir_cplx_crossfix(Geom g, const float* __restrict__ xtaps,
+                                                            const float* __restrict__ in, float* __restrict__ out,
+                                                            int64_t first_seam, int nseams, int per_seam)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseams * per_seam) return;
+    const int si = t / per_seam, ci = t - si * per_seam;
+    const int64_t edge = (first_seam + si) * g.seamBI;
+    const int64_t m = (edge + g.D - 1) / g.D - 1 - ci;
+    if (m < g.k_begin || m >= g.k_begin + g.count) return;
+    const int64_t v = m * g.D;
+    if (!(v < edge && v + g.Lp > edge)) return;
+    const float2* x = reinterpret_cast<const float2*>(in) + (v - g.in_base);
+    float re = 0.0f, im = 0.0f;
+    for (int j = 0; j < g.Lp; j++) {
+        const float2 s = x[j];
+        re = re + s.x * xtaps[j];
+        im = im + s.y * xtaps[j];
+    }
+    *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
 }
 
 // Cross outputs of a real FIR / decimator: sequential over the Lp plain taps
@@ -379,33 +492,65 @@ void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int
                        last_im, out_vec);
 }
 
-bool launch_fir_sym8_fast(hipStream_t s, const Geom& g, const float* d_half_taps, int nhalf, const float* d_cross_taps,
+bool launch_fir_real8_fast(hipStream_t s, const Geom& g, bool sym, const float* d_taps, int nk, const float* d_cross_taps,
                           const float* d_in, float* d_out, float gain, bool apply_gain)
 {
-    if (g.I != 1 || g.D != 1 || !(nhalf == 64 || nhalf == 32) || g.count <= 0 || g.seamBI < 0) return false;
+    // filters only (D == 1), 8 lanes, tap count a multiple of 8 (the AVX constructors guarantee it)
+    if (g.I != 1 || g.D != 1 || nk < 8 || nk % 8 != 0 || nk > 4096 || g.count <= 0 || g.seamBI < 0) return false;
     if (g.seamBI != 0 && d_cross_taps == nullptr) return false;
     constexpr int R = 4, NT = 256;
+    const int full = sym ? 2 * nk : nk;
     const int64_t x0 = g.k_begin - g.in_base;
     const int aligned = ((reinterpret_cast<uintptr_t>(d_in + x0) & 15) == 0) ? 1 : 0;
     const int tiles = (g.count + NT * R - 1) / (NT * R);
-    if (nhalf == 64)
-        hipLaunchKernelGGL((k_fir_sym8_fast<64, R, NT>), dim3(tiles), dim3(NT), 0, s, d_in, x0, g.count, d_half_taps, d_out, gain,
-                           apply_gain ? 1 : 0, aligned);
+    const size_t lds_bytes = ((size_t)(NT * R + full - 1 + 3) / 4 * 4 + 16) * sizeof(float);
+    if (sym)
+        hipLaunchKernelGGL((k_fir_real8_fast<true, R, NT>), dim3(tiles), dim3(NT), lds_bytes, s, d_in, x0, g.count, d_taps, nk, d_out,
+                           gain, apply_gain ? 1 : 0, aligned);
     else
-        hipLaunchKernelGGL((k_fir_sym8_fast<32, R, NT>), dim3(tiles), dim3(NT), 0, s, d_in, x0, g.count, d_half_taps, d_out, gain,
-                           apply_gain ? 1 : 0, aligned);
+        hipLaunchKernelGGL((k_fir_real8_fast<false, R, NT>), dim3(tiles), dim3(NT), lds_bytes, s, d_in, x0, g.count, d_taps, nk, d_out,
+                           gain, apply_gain ? 1 : 0, aligned);
     if (g.seamBI != 0) {
         int64_t first, last;
         seam_range(g, first, last);
         if (last >= first) {
             const int nseams = (int)(last - first + 1);
-            // D == 1: one Lp-thread workgroup per seam
-            if (nhalf == 64)
+            if (full == 128)
                 hipLaunchKernelGGL((k_filter_real_crossfix_lds<128>), dim3(nseams), dim3(128), 0, s, g, d_cross_taps, d_in, d_out,
                                    first, gain, apply_gain ? 1 : 0);
-            else
+            else if (full == 64)
                 hipLaunchKernelGGL((k_filter_real_crossfix_lds<64>), dim3(nseams), dim3(64), 0, s, g, d_cross_taps, d_in, d_out,
                                    first, gain, apply_gain ? 1 : 0);
+            else {
+                const int per = full - 1;
+                const int64_t total = (int64_t)nseams * per;
+                hipLaunchKernelGGL(k_fir_real_crossfix, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, d_cross_taps, d_in,
+                                   d_out, first, nseams, per, gain, apply_gain ? 1 : 0);
+            }
+        }
+    }
+    return true;
+}
+
+bool launch_filter_cplx4_fast(hipStream_t s, const Geom& g, const float* d_dup_taps, int P, const float* d_cross_taps,
+                              const float* d_in, float* d_out)
+{
+    if (g.I != 1 || g.D != 1 || P < 4 || P % 4 != 0 || P > 2048 || g.count <= 0 || g.seamBI < 0) return false;
+    if (g.seamBI != 0 && d_cross_taps == nullptr) return false;
+    constexpr int R = 4, NT = 256;
+    const int64_t x0 = g.k_begin - g.in_base;
+    const int tiles = (g.count + NT * R - 1) / (NT * R);
+    const size_t lds_bytes = ((size_t)(NT * R + P - 1) + 16) * sizeof(float2);
+    hipLaunchKernelGGL((k_filter_cplx4_fast<R, NT>), dim3(tiles), dim3(NT), lds_bytes, s, d_in, x0, g.count, d_dup_taps, P, d_out);
+    if (g.seamBI != 0) {
+        int64_t first, last;
+        seam_range(g, first, last);
+        if (last >= first) {
+            const int nseams = (int)(last - first + 1);
+            const int per = P - 1;
+            const int64_t total = (int64_t)nseams * per;
+            hipLaunchKernelGGL(k_fir_cplx_crossfix, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, d_cross_taps, d_in, d_out,
+                               first, nseams, per);
         }
     }
     return true;

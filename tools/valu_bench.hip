@@ -14,7 +14,7 @@ __global__ void __launch_bounds__(256) k(float* out, const float* taps, int iter
     f2 acc[16], t[16], x[4];
     for (int i = 0; i < 16; i++) acc[i] = f2{(float)threadIdx.x * 1e-3f + i, 1.0f - i * 1e-2f};
     for (int i = 0; i < 4; i++) x[i] = f2{(float)threadIdx.x * 1e-3f + i, (float)threadIdx.x * 2e-3f + i};
-    for (int it = 0; it < iters; it++) {
+    for (int it = 0; it < (MODE == 6 ? 0 : iters); it++) {
 #pragma unroll
         for (int rep = 0; rep < 4; rep++) {
 #pragma unroll
@@ -36,6 +36,18 @@ __global__ void __launch_bounds__(256) k(float* out, const float* taps, int iter
                     asm volatile("v_mul_f32 %0, %4, %6\n\tv_mul_f32 %1, %5, %7\n\tv_add_f32 %2, %2, %0\n\tv_add_f32 %3, %3, %1"
                                  : "=&v"(t[i].x), "=&v"(t[i].y), "+v"(acc[i].x), "+v"(acc[i].y)
                                  : "v"(hv.x), "v"(hv.y), "v"(x[i & 3].x), "v"(x[i & 3].y));
+            }
+        }
+    }
+    if constexpr (MODE == 6) {
+        // software-pipelined: 16 independent multiplies, then the 16 adds that consume them
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int rep = 0; rep < 4; rep++) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t[i]) : "s"(hs), "v"(x[i & 3]));
+#pragma unroll
+                for (int i = 0; i < 16; i++) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc[i]) : "v"(t[i]));
             }
         }
     }
@@ -77,7 +89,8 @@ void run(const char* name, int blocks, int inst_per_cmac)
 
 int main()
 {
-    for (int blocks : {256, 1024, 2048, 8192}) {
+    for (int blocks : {256, 512, 1024, 2048, 8192}) {
+        run<6>("pk_mul x16 then pk_add x16 (SGPR)", blocks, 2);
         run<0>("pk_mul+pk_add (VGPR tap)", blocks, 2);
         run<1>("pk_mul+pk_add (SGPR tap, op_sel)", blocks, 2);
         run<2>("v_mul+v_add x2 (SGPR tap)", blocks, 4);
