@@ -314,28 +314,43 @@ void launch_resample_cplx(hipStream_t s, const Geom& g, ComplexOrder order, cons
 // ---------------------------------------------------------------------------
 // element-wise
 // ---------------------------------------------------------------------------
-// convert.c:15-50.  16 bytes per thread in, 4 x float4 out (coalesced 1 KiB stores per wave).
+// convert.c:15-50.  The kernel is write-dominated (2 B in, 8 B out per sample), so the STORES are
+// what must coalesce: each lane converts one dword (4 bytes) into one float4, so a wave's store
+// instruction writes 1 KiB of consecutive floats; four such dword/float4 pairs per thread per trip,
+// a whole workgroup-stride apart, keep enough loads in flight.
 __global__ void __launch_bounds__(256) k_convert_u8(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t n)
 {
-    int64_t nvec = n >> 4;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
-        uint4 w = reinterpret_cast<const uint4*>(in)[v];
-        uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-        float4* o = reinterpret_cast<float4*>(out) + v * 4;
+    const int64_t nvec = n >> 2;                                    // dwords in / float4s out
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint32_t* in4 = reinterpret_cast<const uint32_t*>(in);
+    float4* out4 = reinterpret_cast<float4*>(out);
+    int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; v + 3 * stride < nvec; v += 4 * stride) {
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = in4[v + k * stride];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             float4 f;
-            f.x = ((float)(ws[k] & 0xff) - 128.0f) * (1.0f / 128.0f);
-            f.y = ((float)((ws[k] >> 8) & 0xff) - 128.0f) * (1.0f / 128.0f);
-            f.z = ((float)((ws[k] >> 16) & 0xff) - 128.0f) * (1.0f / 128.0f);
-            f.w = ((float)(ws[k] >> 24) - 128.0f) * (1.0f / 128.0f);
-            o[k] = f;
+            f.x = ((float)(w[k] & 0xff) - 128.0f) * (1.0f / 128.0f);
+            f.y = ((float)((w[k] >> 8) & 0xff) - 128.0f) * (1.0f / 128.0f);
+            f.z = ((float)((w[k] >> 16) & 0xff) - 128.0f) * (1.0f / 128.0f);
+            f.w = ((float)(w[k] >> 24) - 128.0f) * (1.0f / 128.0f);
+            out4[v + k * stride] = f;
         }
     }
-    // tail (< 16 bytes)
+    for (; v < nvec; v += stride) {
+        const uint32_t w = in4[v];
+        float4 f;
+        f.x = ((float)(w & 0xff) - 128.0f) * (1.0f / 128.0f);
+        f.y = ((float)((w >> 8) & 0xff) - 128.0f) * (1.0f / 128.0f);
+        f.z = ((float)((w >> 16) & 0xff) - 128.0f) * (1.0f / 128.0f);
+        f.w = ((float)(w >> 24) - 128.0f) * (1.0f / 128.0f);
+        out4[v] = f;
+    }
+    // tail (< 4 bytes)
     if (blockIdx.x == 0) {
-        int64_t t = (nvec << 4) + threadIdx.x;
+        int64_t t = (nvec << 2) + threadIdx.x;
         if (t < n) out[t] = ((float)in[t] - 128.0f) * (1.0f / 128.0f);
     }
 }
@@ -359,7 +374,7 @@ void launch_convert_u8(hipStream_t s, const uint8_t* d_in, float* d_out, int64_t
 {
     if (n <= 0) return;
     bool aligned = ((reinterpret_cast<uintptr_t>(d_in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
-    if (aligned) hipLaunchKernelGGL(k_convert_u8, dim3(grid_for((n >> 4) + 1)), dim3(256), 0, s, d_in, d_out, n);
+    if (aligned) hipLaunchKernelGGL(k_convert_u8, dim3(grid_for((n >> 4) + 1, 256 * 16)), dim3(256), 0, s, d_in, d_out, n);
     else hipLaunchKernelGGL(k_convert_u8_unaligned, dim3(grid_for(n)), dim3(256), 0, s, d_in, d_out, n);
 }
 
