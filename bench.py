@@ -61,7 +61,7 @@ def cpu_chain_worker(seconds, nblk=64):
         dec_acc = []
         for b in blocks:
             if ref is not None:
-                x = ref.convert("convertCAVX", b, pad=0) if False else ref.convert("convertCAVX", b)
+                x = ref.convert("convertCAVX", b)
                 d = ref.decim("decimateAVXRC", n_dec, 8, taps_dd, x, True)
             else:
                 x = orc.convert_u8(b)
