@@ -73,7 +73,8 @@ def test_decimator_spot_checks_against_oracle_at_full_size(hip, oracle):
 def test_chain_shift_invariance_at_full_size(hip):
     """The seamed chain repeats itself under an input shift of 8192*80 samples (every stage's seam grid
     maps onto itself: 8192*80/8 = 10*8192 decimator outputs, *3/10 = 3*8192 audio samples).  Only the
-    outputs that see the very first demod sample (last = 0) differ."""
+    outputs that see the very first demod sample (last = 0) may differ (through a 1e-5 edge tap, so
+    often not even those): the first 256 are skipped."""
     n = 1 << 26
     shift, qshift = B * 80, 3 * B
     u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda")
@@ -90,7 +91,6 @@ def test_chain_shift_invariance_at_full_size(hip):
     b = run(u8[2 * shift:].contiguous(), n - shift)
     skip = 256
     assert torch.equal(a[qshift + skip: qshift + b.numel()].view(torch.int32), b[skip:].view(torch.int32))
-    assert not torch.equal(a[qshift: qshift + 8].view(torch.int32), b[:8].view(torch.int32))
 
 
 def test_chain_launch_cut_invariance_at_full_size(hip):
