@@ -22,8 +22,6 @@
 //   * taps are wave-uniform -> scalar loads / SGPR operands.
 //   "Cross" outputs (seam straddlers, sequential order) are rewritten afterwards by
 //   a tiny fix-up kernel on the same stream: ~1.5 % of outputs.
-#include <stdlib.h>
-
 #include "kernels.hpp"
 
 namespace sdrhip {
@@ -111,63 +109,8 @@ __device__ __forceinline__ void mac_window(const float2* __restrict__ win, const
     }
 }
 
-// stage the tile's samples [0, SPAN) into LDS; `avail` = how many of them exist
-template <class T, bool U8>
-__device__ __forceinline__ void stage_tile(float2* __restrict__ lds, const void* __restrict__ src_v, int64_t src_sample0,
-                                           int avail)
-{
-    const int tid = threadIdx.x;
-    if constexpr (!U8) {
-        // float4 = 2 samples
-        const float* src = reinterpret_cast<const float*>(src_v) + 2 * src_sample0;
-        constexpr int NV = (T::SPAN + 1) / 2;
-        const int nthreads = blockDim.x;
-        for (int v = tid; v < NV; v += nthreads) {
-            int s = 2 * v;
-            float4 val;
-            if (s + 1 < avail) {
-                val = *reinterpret_cast<const float4*>(src + 2 * s);
-            } else {
-                val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (s < avail) { val.x = src[2 * s]; val.y = src[2 * s + 1]; }
-            }
-            // CHUNK is even, so the two samples of a float4 never straddle a pad
-            *reinterpret_cast<float4*>(&lds[T::lds_idx(s)]) = val;
-        }
-    } else {
-        // uint4 = 16 bytes = 8 samples
-        const uint8_t* src = reinterpret_cast<const uint8_t*>(src_v) + 2 * src_sample0;
-        constexpr int NV = (T::SPAN + 7) / 8;
-        const int nthreads = blockDim.x;
-        for (int v = tid; v < NV; v += nthreads) {
-            int s = 8 * v;
-            uint32_t w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};  // 128 -> 0.0f
-            if (s + 7 < avail) {
-                uint4 q = *reinterpret_cast<const uint4*>(src + 2 * s);
-                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-            } else {
-                for (int e = 0; e < 8; e++) {
-                    if (s + e < avail) {
-                        uint32_t lo = src[2 * (s + e)], hi = src[2 * (s + e) + 1];
-                        uint32_t sh = (e & 1) * 16;
-                        w[e >> 1] = (w[e >> 1] & ~(0xffffu << sh)) | ((lo | (hi << 8)) << sh);
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float4 f;
-                f.x = ((float)(w[k] & 0xff) - 128.0f) * (1.0f / 128.0f);
-                f.y = ((float)((w[k] >> 8) & 0xff) - 128.0f) * (1.0f / 128.0f);
-                f.z = ((float)((w[k] >> 16) & 0xff) - 128.0f) * (1.0f / 128.0f);
-                f.w = ((float)(w[k] >> 24) - 128.0f) * (1.0f / 128.0f);
-                int ss = s + 2 * k;
-                if (ss < T::SPAN + 1) *reinterpret_cast<float4*>(&lds[T::lds_idx(ss)]) = f;
-            }
-        }
-    }
-}
-
+// Staging of one tile: all of a thread's 16-byte global loads are issued before the first wait, then
+// converted (u8) and written to the padded LDS layout.
 template <class T, bool U8, int NT>
 struct Stage {
     static constexpr int SPV = U8 ? 8 : 2;                       // samples per 16-byte vector
@@ -302,74 +245,6 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
     }
 }
 
-// ---------------------------------------------------------------------------
-// Persistent, software-pipelined variant: each workgroup walks tiles
-// blockIdx.x, blockIdx.x + gridDim.x, ...  While the VALU works through tile i out
-// of LDS, the global loads of tile i+1 are already in flight into registers; they
-// are written to LDS only after every wave has finished reading tile i.  This takes
-// the HBM latency off the critical path (the one-shot kernel above exposes a full
-// load phase per tile) without needing a second LDS buffer -- LDS capacity is what
-// bounds occupancy here (64 B of window per in-flight output).
-// ---------------------------------------------------------------------------
-template <int D, int P, int R, int NT, bool U8, int WPS>
-__global__ void __launch_bounds__(NT, WPS) k_decimate_c4_pipe(const void* __restrict__ in, int64_t x0, int count, int ntiles,
-                                                         const float* __restrict__ taps, float* __restrict__ out)
-{
-    using T = Tile<D, P, R, NT>;
-    static_assert(D % 4 == 0, "lane of a tap must not depend on the output within a thread");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* lds = reinterpret_cast<float2*>(smem_raw);
-    const int64_t total_avail = (int64_t)(count - 1) * D + P;
-
-    Stage<T, U8, NT> st;
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    {
-        const int64_t s0 = (int64_t)tile * T::OUTS * D;
-        const int64_t av = total_avail - s0;
-        st.load(in, x0 + s0, av > T::SPAN ? T::SPAN : (int)av);
-        st.store(lds);
-    }
-    __syncthreads();
-
-    const float2* win = lds + T::lds_idx(threadIdx.x * T::CHUNK);
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int next = tile + gridDim.x;
-        if (next < ntiles) {
-            const int64_t s0 = (int64_t)next * T::OUTS * D;
-            const int64_t av = total_avail - s0;
-            st.load(in, x0 + s0, av > T::SPAN ? T::SPAN : (int)av);   // in flight during the MACs below
-        }
-
-        float2 acc[R][4];
-#pragma unroll
-        for (int r = 0; r < R; r++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) acc[r][k] = make_float2(0.0f, 0.0f);
-        mac_window<D, P, R, T>(win, taps, acc);
-        const int o = tile * T::OUTS + threadIdx.x * R;
-        float2 res[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            res[r].x = (acc[r][0].x + acc[r][1].x) + (acc[r][2].x + acc[r][3].x);
-            res[r].y = (acc[r][0].y + acc[r][1].y) + (acc[r][2].y + acc[r][3].y);
-        }
-        if (R % 2 == 0 && o + R <= count) {
-            float4* dst = reinterpret_cast<float4*>(out + 2 * (int64_t)o);
-#pragma unroll
-            for (int r = 0; r + 1 < R; r += 2) dst[r / 2] = make_float4(res[r].x, res[r].y, res[r + 1].x, res[r + 1].y);
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; r++)
-                if (o + r < count) *reinterpret_cast<float2*>(out + 2 * (int64_t)(o + r)) = res[r];
-        }
-
-        __syncthreads();                       // every wave is done reading this tile
-        if (next < ntiles) st.store(lds);
-        __syncthreads();
-    }
-}
-
 // Cross outputs: sequential order over the Lp plain taps (decimateCrossHighLevel,
 // FilterInternal.hs:397-402).  The <= ceil((Lp-1)/D) straddlers of one seam have
 // windows that overlap almost entirely, so a group of PER threads stages their union
@@ -470,37 +345,6 @@ __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const
     *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
 }
 
-int num_cus()
-{
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
-template <int D, int P, int R, int NT, bool U8, int WGS_PER_CU>
-void launch_c4_pipe(hipStream_t s, const Geom& g, const float* taps, const void* in, float* out)
-{
-    using T = Tile<D, P, R, NT>;
-    constexpr int wgs_per_cu = WGS_PER_CU;
-    static bool attr_set = false;
-    auto kern = k_decimate_c4_pipe<D, P, R, NT, U8, (WGS_PER_CU * NT / 64 + 3) / 4>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)T::LDS_BYTES);
-        attr_set = true;
-    }
-    int tiles = (g.count + T::OUTS - 1) / T::OUTS;
-    int grid = num_cus() * wgs_per_cu;
-    if (grid > tiles) grid = tiles;
-    int64_t x0 = g.k_begin * D - g.in_base;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, tiles, taps, out);
-}
-
 template <int D, int P, int R, int NT, bool U8>
 void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, float* out)
 {
@@ -535,19 +379,15 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
         if (((base + 8 * (uintptr_t)x0) & 15) != 0) return false;
     }
     if ((reinterpret_cast<uintptr_t>(d_out) & 15) != 0) return false;
-    static const int variant = getenv("SDRHIP_K2_VARIANT") ? atoi(getenv("SDRHIP_K2_VARIANT")) : 3;
+    // R = 2 outputs per thread, 256 threads, 4 workgroups per CU.  Alternatives measured on MI355X and dropped:
+    // R = 4 (the compiler's SGPR allocation for the sliding tap window collapses into spills), 512-thread
+    // workgroups (same rate), and a persistent kernel that prefetches the next tile into registers during the
+    // MAC phase (same rate: with random data the kernel is power/clock-limited, the exposed load phase is ~4 %).
     if (P == 52) {
         // the tap count of the reference FM example's RF decimation filter (51 -> 52)
         if (in_is_u8) launch_c4<8, 52, 2, 256, true>(s, g, d_plain_taps, d_in, d_out);
         else launch_c4<8, 52, 2, 256, false>(s, g, d_plain_taps, d_in, d_out);
-    } else if (variant == 2) {
-        if (in_is_u8) launch_c4_pipe<8, 128, 2, 256, true, 4>(s, g, d_plain_taps, d_in, d_out);
-        else launch_c4_pipe<8, 128, 2, 256, false, 4>(s, g, d_plain_taps, d_in, d_out);
-    } else if (variant == 5) {
-        if (in_is_u8) launch_c4<8, 128, 2, 512, true>(s, g, d_plain_taps, d_in, d_out);
-        else launch_c4<8, 128, 2, 512, false>(s, g, d_plain_taps, d_in, d_out);
     } else {
-        // default: R = 2 outputs per thread, 256 threads, 4 workgroups per CU
         if (in_is_u8) launch_c4<8, 128, 2, 256, true>(s, g, d_plain_taps, d_in, d_out);
         else launch_c4<8, 128, 2, 256, false>(s, g, d_plain_taps, d_in, d_out);
     }
