@@ -262,6 +262,23 @@ int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain *c, int nsub);
 int sdrhip_fm_chain_enable_timing(sdrhip_fm_chain *c, int enable);
 int sdrhip_fm_chain_read_timing(sdrhip_fm_chain *c, double ms_sum[5], int *runs);
 
+/* Host-block streaming front end of the chain: u8 IQ source blocks in (host memory, `block` samples
+ * each or a whole multiple), audio blocks of exactly block_size_out floats out -- the five middle
+ * stages of examples/fm/fm.hs:34-41 as ONE operator with every intermediate resident in HBM.  Pinned
+ * staging, H2D / compute / D2H on three HIP streams, two slots: results lag one push (flush drains).
+ * The chain must outlive the stream and must not be run concurrently by another caller. */
+typedef struct sdrhip_fm_stream sdrhip_fm_stream;
+int sdrhip_fm_stream_create(sdrhip_fm_stream **st, sdrhip_fm_chain *chain, int max_block_samples, int block_size_out);
+void sdrhip_fm_stream_destroy(sdrhip_fm_stream *st);
+/* returns the number of complete audio blocks ready to pop (>= 0) or a negative error */
+int sdrhip_fm_stream_push(sdrhip_fm_stream *st, const uint8_t *iq, int n_samples);
+/* Zero-copy variant: the pinned staging buffer (2*max_block_samples bytes) the NEXT push will upload
+ * from.  Let the source (e.g. the RTL-SDR read of SDR/RTLSDRStream.hs) write into it, then push that
+ * same pointer: the host-side memcpy is skipped.  Valid until that push; NULL on error. */
+uint8_t *sdrhip_fm_stream_input_buffer(sdrhip_fm_stream *st);
+int sdrhip_fm_stream_flush(sdrhip_fm_stream *st);
+int sdrhip_fm_stream_pop(sdrhip_fm_stream *st, float *out, int capacity);
+
 /* ------------------------------------------------------------------------ */
 /* (3) Pipe operators on host blocks                                        */
 /* ------------------------------------------------------------------------ */

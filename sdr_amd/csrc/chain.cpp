@@ -9,6 +9,8 @@
 //   inOff(m) = ceil(m*D2/I2)) -> q audio outputs (window [q, q+L3)).
 // Seams: all four Pipes of fm.hs run with blockSizeOut = `block` and the source
 // delivers `block`-sample buffers, so each stage's input blocks are `block` long.
+#include <string.h>
+
 #include <vector>
 
 #include "descriptors.hpp"
@@ -337,6 +339,206 @@ int sdrhip_fm_chain_read_timing(sdrhip_fm_chain* c, double* ms_sum, int* runs)
     c->ev_used = 0;
     c->runs = 0;
     return SDRHIP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Host-block streaming front end of the chain: what a Haskell `Pipe (Vector CUChar) (Vector Float)`
+// replacing the five middle stages of examples/fm/fm.hs:34-41 binds to.  Source blocks (u8 IQ, host
+// memory, `block` samples each -- or a multiple) go in, audio blocks of exactly `block_size_out`
+// floats come out, bit-identical to what the reference's four Pipes + convert + gain yield.
+//
+// Per push: the block is copied into a pinned staging buffer, uploaded with hipMemcpyAsync on an
+// upload stream behind the carried tail (the samples earlier pushes received but later outputs still
+// need), the chain runs on the compute stream for every audio output whose receptive field is now
+// complete, and the result is downloaded on a third stream.  Two slots alternate, so the upload of
+// block i overlaps the compute of block i-1 and the download of block i-2; results lag one push
+// (sdrhip_fm_stream_flush drains).
+// ---------------------------------------------------------------------------
+struct sdrhip_fm_stream {
+    sdrhip_fm_chain* c = nullptr;
+    int max_block = 0;
+    int block_out = 0;
+    hipStream_t compute = nullptr, up = nullptr, down = nullptr;
+    hipEvent_t ev_tail = nullptr;
+    bool tail_pending = false;
+    DevBuf din[2];
+    DevBuf ws;
+    int cur = 0;
+    int64_t base = 0;      // global sample index of din[cur][0]
+    int64_t N = 0;         // samples received so far
+    int64_t q_done = 0;    // audio outputs computed so far
+    struct Slot {
+        PinBuf hin, hout;
+        DevBuf dout;
+        hipEvent_t ev = nullptr, ev_up = nullptr, ev_k = nullptr;
+        int64_t n_out = 0;
+        bool busy = false;
+    } slot[2];
+    int64_t pushes = 0;
+    std::vector<float> fifo;
+    size_t head = 0;
+
+    ~sdrhip_fm_stream()
+    {
+        for (hipStream_t st : {up, compute, down})
+            if (st) (void)hipStreamSynchronize(st);
+        for (auto& sl : slot)
+            for (hipEvent_t e : {sl.ev, sl.ev_up, sl.ev_k})
+                if (e) (void)hipEventDestroy(e);
+        if (ev_tail) (void)hipEventDestroy(ev_tail);
+        for (hipStream_t st : {up, compute, down})
+            if (st) (void)hipStreamDestroy(st);
+    }
+    int ready() const { return (int)((fifo.size() - head) / (size_t)block_out); }
+    int harvest(int si)
+    {
+        Slot& sl = slot[si];
+        if (!sl.busy) return SDRHIP_OK;
+        SDRHIP_CHECK_HIP(hipEventSynchronize(sl.ev));
+        if (head > 0 && head == fifo.size()) { fifo.clear(); head = 0; }
+        else if (head > (1u << 20) && head * 2 > fifo.size()) { fifo.erase(fifo.begin(), fifo.begin() + head); head = 0; }
+        const size_t old = fifo.size();
+        fifo.resize(old + (size_t)sl.n_out);
+        memcpy(fifo.data() + old, sl.hout.p, (size_t)sl.n_out * sizeof(float));
+        sl.busy = false;
+        return SDRHIP_OK;
+    }
+};
+
+extern "C" {
+
+int sdrhip_fm_stream_create(sdrhip_fm_stream** out, sdrhip_fm_chain* chain, int max_block_samples, int block_size_out)
+{
+    SDRHIP_REQUIRE(out != nullptr && chain != nullptr && max_block_samples > 0 && block_size_out > 0, "sdrhip_fm_stream_create");
+    SDRHIP_REQUIRE(chain->block == 0 || max_block_samples % chain->block == 0,
+                   "sdrhip_fm_stream_create: blocks must be whole multiples of the chain's seam block");
+    *out = nullptr;
+    sdrhip_fm_stream* st = new sdrhip_fm_stream();
+    st->c = chain;
+    st->max_block = max_block_samples;
+    st->block_out = block_size_out;
+    hipError_t e = hipStreamCreateWithFlags(&st->compute, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->up, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->down, hipStreamNonBlocking);
+    for (auto& sl : st->slot)
+        for (hipEvent_t* ev : {&sl.ev, &sl.ev_up, &sl.ev_k})
+            if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_tail, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        set_error("sdrhip_fm_stream_create: %s", hipGetErrorString(e));
+        delete st;
+        return SDRHIP_ERR_HIP;
+    }
+    *out = st;
+    return SDRHIP_OK;
+}
+
+void sdrhip_fm_stream_destroy(sdrhip_fm_stream* st) { delete st; }
+
+uint8_t* sdrhip_fm_stream_input_buffer(sdrhip_fm_stream* st)
+{
+    if (st == nullptr) { set_error("sdrhip_fm_stream_input_buffer: null stream"); return nullptr; }
+    sdrhip_fm_stream::Slot& sl = st->slot[st->pushes & 1];
+    if (hipEventSynchronize(sl.ev_up) != hipSuccess) { set_error("sdrhip_fm_stream_input_buffer: upload event"); return nullptr; }
+    if (sl.hin.ensure((size_t)st->max_block * 2) != SDRHIP_OK) return nullptr;
+    return (uint8_t*)sl.hin.p;
+}
+
+int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
+{
+    SDRHIP_REQUIRE(st != nullptr && iq != nullptr && n > 0 && n <= st->max_block, "sdrhip_fm_stream_push");
+    sdrhip_fm_chain* c = st->c;
+    SDRHIP_REQUIRE(c->block == 0 || n % c->block == 0,
+                   "sdrhip_fm_stream_push: the chain reproduces the seams of `block`-sample source buffers (fm.hs:17,24)");
+    const int si = (int)(st->pushes & 1);
+    sdrhip_fm_stream::Slot& sl = st->slot[si];
+    int rc;
+    if ((rc = st->harvest(si)) != SDRHIP_OK) return rc;
+    SDRHIP_CHECK_HIP(hipEventSynchronize(sl.ev_up));   // the slot's previous upload has left the staging buffer
+    if (iq != (const uint8_t*)sl.hin.p || sl.hin.p == nullptr) {   // else: the caller filled our staging buffer in place
+        if ((rc = sl.hin.ensure((size_t)st->max_block * 2)) != SDRHIP_OK) return rc;
+        memcpy(sl.hin.p, iq, (size_t)n * 2);
+    }
+
+    // outputs whose receptive field is complete once this block is in (end() is non-decreasing in q)
+    const int64_t N1 = st->N + n;
+    int64_t lo = st->q_done, hi = st->q_done;
+    if (c->end(lo) <= N1) {
+        hi = lo + 1;
+        while (c->end(hi) <= N1) hi = lo + 2 * (hi - lo);
+        while (lo + 1 < hi) {                      // invariant: end(lo) <= N1 < end(hi)
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (c->end(mid) <= N1) lo = mid; else hi = mid;
+        }
+        hi = lo + 1;                                // q_new (exclusive)
+    }
+    const int64_t q_new = hi;
+    // device input = [carried tail | new block]; the tail starts at the first sample the next pending output
+    // needs, rounded down to a multiple of 8 samples (16-byte aligned tiles for the LDS-tiled decimator)
+    int64_t keep_from = c->start(st->q_done) & ~(int64_t)7;
+    if (keep_from > st->N) keep_from = st->N & ~(int64_t)7;
+    const int64_t tail = st->N - keep_from;
+    DevBuf& prev = st->din[st->cur];
+    DevBuf& next = st->din[st->cur ^ 1];
+    if ((rc = next.ensure((size_t)(tail + n) * 2 + 64)) != SDRHIP_OK) return rc;
+    if (st->tail_pending) SDRHIP_CHECK_HIP(hipStreamWaitEvent(st->up, st->ev_tail, 0));
+    st->tail_pending = false;
+    if (tail > 0)
+        SDRHIP_CHECK_HIP(hipMemcpyAsync(next.p, (const char*)prev.p + (size_t)(keep_from - st->base) * 2, (size_t)tail * 2,
+                                        hipMemcpyDeviceToDevice, st->compute));
+    // everything queued so far that reads `prev` (earlier chain runs, this tail copy) precedes this event;
+    // the NEXT push uploads into `prev` and waits for it
+    SDRHIP_CHECK_HIP(hipEventRecord(st->ev_tail, st->compute));
+    st->tail_pending = true;
+    SDRHIP_CHECK_HIP(hipMemcpyAsync((char*)next.p + (size_t)tail * 2, sl.hin.p, (size_t)n * 2, hipMemcpyHostToDevice, st->up));
+    SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, st->up));
+    SDRHIP_CHECK_HIP(hipStreamWaitEvent(st->compute, sl.ev_up, 0));
+    st->cur ^= 1;
+    st->base = keep_from;
+
+    const int64_t n_out = q_new - st->q_done;
+    sl.n_out = 0;
+    if (n_out > 0) {
+        const size_t wsb = sdrhip_fm_chain_workspace_bytes(c, tail + n);
+        if ((rc = st->ws.ensure(wsb)) != SDRHIP_OK) return rc;
+        if ((rc = sl.dout.ensure((size_t)n_out * 4)) != SDRHIP_OK) return rc;
+        if ((rc = sl.hout.ensure((size_t)n_out * 4)) != SDRHIP_OK) return rc;
+        if ((rc = sdrhip_fm_chain_run(c, (void*)st->compute, (const uint8_t*)next.p, keep_from, tail + n, (float*)sl.dout.p,
+                                      st->q_done, q_new, st->ws.p, st->ws.cap)) != SDRHIP_OK) return rc;
+        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, st->compute));
+        SDRHIP_CHECK_HIP(hipStreamWaitEvent(st->down, sl.ev_k, 0));
+        SDRHIP_CHECK_HIP(hipMemcpyAsync(sl.hout.p, sl.dout.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st->down));
+        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, st->down));
+        sl.n_out = n_out;
+        sl.busy = true;
+    }
+    st->q_done = q_new;
+    st->N = N1;
+    st->pushes++;
+    if ((rc = st->harvest(si ^ 1)) != SDRHIP_OK) return rc;
+    return st->ready();
+}
+
+int sdrhip_fm_stream_flush(sdrhip_fm_stream* st)
+{
+    SDRHIP_REQUIRE(st != nullptr, "sdrhip_fm_stream_flush");
+    int rc;
+    const int first = (int)(st->pushes & 1);
+    if ((rc = st->harvest(first)) != SDRHIP_OK) return rc;
+    if ((rc = st->harvest(first ^ 1)) != SDRHIP_OK) return rc;
+    return st->ready();
+}
+
+int sdrhip_fm_stream_pop(sdrhip_fm_stream* st, float* out, int capacity)
+{
+    SDRHIP_REQUIRE(st != nullptr && out != nullptr, "sdrhip_fm_stream_pop");
+    if (st->ready() <= 0) return 0;
+    SDRHIP_REQUIRE(capacity >= st->block_out, "sdrhip_fm_stream_pop: capacity smaller than the block");
+    memcpy(out, st->fifo.data() + st->head, (size_t)st->block_out * sizeof(float));
+    st->head += (size_t)st->block_out;
+    return st->block_out;
 }
 
 }  // extern "C"

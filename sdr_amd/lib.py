@@ -97,6 +97,15 @@ lib.sdrhip_fm_chain_set_pipelining.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_enable_timing.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_read_timing.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
+lib.sdrhip_fm_stream_create.argtypes = [C.POINTER(_vp), _vp, C.c_int, C.c_int]
+lib.sdrhip_fm_stream_destroy.argtypes = [_vp]
+lib.sdrhip_fm_stream_destroy.restype = None
+lib.sdrhip_fm_stream_push.argtypes = [_vp, _u8p, C.c_int]
+lib.sdrhip_fm_stream_flush.argtypes = [_vp]
+lib.sdrhip_fm_stream_input_buffer.argtypes = [_vp]
+lib.sdrhip_fm_stream_input_buffer.restype = _vp
+lib.sdrhip_fm_stream_pop.argtypes = [_vp, _f32p, C.c_int]
+
 lib.sdrhip_pipe_fir_filter.argtypes = [C.POINTER(_vp), _vp, C.c_int]
 lib.sdrhip_pipe_fir_decimator.argtypes = [C.POINTER(_vp), _vp, C.c_int]
 lib.sdrhip_pipe_fir_resampler.argtypes = [C.POINTER(_vp), _vp, C.c_int]
@@ -353,6 +362,42 @@ class FmChain(_Handle):
 
     def run(self, d_in_u8, s0, n_in, d_audio, q0, q1, d_ws, ws_bytes, stream=None):
         check(lib.sdrhip_fm_chain_run(self.h, stream, d_in_u8, s0, n_in, d_audio, q0, q1, d_ws, ws_bytes), "sdrhip_fm_chain_run")
+
+
+class FmStream(_Handle):
+    """u8 IQ host blocks in, audio host blocks out: the FM receiver of fm.hs:34-41 as one operator."""
+    _destroy = lib.sdrhip_fm_stream_destroy
+
+    def __init__(self, chain, max_block_samples, block_size_out=8192):
+        super().__init__()
+        self.chain = chain  # keep alive
+        self.block_size_out = block_size_out
+        check(lib.sdrhip_fm_stream_create(C.byref(self.h), chain.h, max_block_samples, block_size_out), "sdrhip_fm_stream_create")
+
+    def _pop(self, ready):
+        outs = []
+        for _ in range(ready):
+            o = np.empty(self.block_size_out, np.float32)
+            check(lib.sdrhip_fm_stream_pop(self.h, _fp(o), self.block_size_out), "sdrhip_fm_stream_pop")
+            outs.append(o)
+        return outs
+
+    def push(self, u8_iq):
+        b = np.ascontiguousarray(u8_iq, dtype=np.uint8)
+        return self._pop(check(lib.sdrhip_fm_stream_push(self.h, b.ctypes.data_as(_u8p), b.size // 2), "sdrhip_fm_stream_push"))
+
+    def input_buffer(self, n_samples):
+        """numpy view of the pinned staging buffer of the next push (fill it, then push_inplace)."""
+        p = lib.sdrhip_fm_stream_input_buffer(self.h)
+        if not p:
+            raise SdrHipError(lib.sdrhip_last_error().decode())
+        return np.ctypeslib.as_array(C.cast(p, _u8p), shape=(2 * n_samples,))
+
+    def push_inplace(self, view):
+        return self._pop(check(lib.sdrhip_fm_stream_push(self.h, view.ctypes.data_as(_u8p), view.size // 2), "sdrhip_fm_stream_push"))
+
+    def flush(self):
+        return self._pop(check(lib.sdrhip_fm_stream_flush(self.h), "sdrhip_fm_stream_flush"))
 
 
 class Pipe(_Handle):

@@ -114,3 +114,48 @@ def test_chain_rejects_missing_halo(hip):
     out = dev_empty_f32(q1 - q0)
     with pytest.raises(hip.SdrHipError):
         chain.run(ptr(u8), 0, total // 2, ptr(out), q0, q1, ptr(ws), ws.numel())  # halo not provided
+
+
+@pytest.mark.parametrize("blocks_per_push", [1, 3, 16])
+def test_fm_stream_matches_pipes(hip, oracle, blocks_per_push):
+    """Host-block streaming front end (pinned, double-buffered, three streams): source blocks in, the
+    reference's audio blocks out, however many source blocks one push carries."""
+    nblk = 96
+    u8 = S.iq_u8_fm(nblk * B)
+    exp = _model(oracle, u8, nblk)
+    assert exp.size == 2 * B
+    chain = _chain(hip)
+    st = hip.FmStream(chain, blocks_per_push * B, B)
+    got = []
+    for i in range(0, nblk, blocks_per_push):
+        got += st.push(u8[2 * i * B: 2 * (i + blocks_per_push) * B])
+    got += st.flush()
+    # the stream yields an audio block as soon as its receptive field is complete, i.e. sometimes a push earlier than the
+    # four chained Pipes (each of which waits for a full 8192-block of ITS input); the sequence of blocks is the same
+    assert len(got) >= 2
+    assert_bit_equal(np.concatenate(got[:2]), exp, "fm stream vs pipes")
+    with pytest.raises(hip.SdrHipError):
+        st.push(u8[: 2 * (B - 8)])          # not a whole source block: the seams would be somewhere else
+
+
+def test_fm_stream_long_run_equals_chain(hip, oracle):
+    """Many pushes: the streamed audio equals one device-resident chain run over the same samples."""
+    nblk = 512
+    total = nblk * B
+    u8 = S.iq_u8(total)
+    chain = _chain(hip)
+    _, q1, _ = chain.plan(0, total, total)
+    full = _run(hip, chain, to_dev(u8), 0, total, 0, q1)
+    st = hip.FmStream(chain, 8 * B, B)
+    got = []
+    for i in range(0, nblk, 8):
+        if i % 16:
+            got += st.push(u8[2 * i * B: 2 * (i + 8) * B])
+        else:                                   # zero-copy: fill the pinned staging buffer in place
+            view = st.input_buffer(8 * B)
+            view[:] = u8[2 * i * B: 2 * (i + 8) * B]
+            got += st.push_inplace(view)
+    got += st.flush()
+    got = np.concatenate(got)
+    assert got.size == q1 // B * B
+    assert_bit_equal(got, full[: got.size], "streamed vs resident")

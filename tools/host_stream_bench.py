@@ -45,6 +45,28 @@ def chain_streamed(blocks_per_batch=8192, batches=12):
           f"({batches * 2 * n / dt / 1e9:.1f} GB/s H2D)")
 
 
+def fm_stream(blocks_per_push, pushes):
+    """The C-ABI streaming operator (sdrhip_fm_stream_*): pinned staging + 3 HIP streams inside the library."""
+    chain = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, B)
+    st = L.FmStream(chain, blocks_per_push * B, B)
+    x = np.random.default_rng(2).integers(0, 256, 2 * blocks_per_push * B, dtype=np.uint8)
+    for _ in range(4):
+        st.push(x)
+    t0 = time.perf_counter()
+    nout = 0
+    for _ in range(pushes):
+        nout += len(st.push(x))
+    nout += len(st.flush())
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(pushes):
+        nout += len(st.push_inplace(st.input_buffer(blocks_per_push * B)))   # source writes straight into pinned memory
+    nout += len(st.flush())
+    dz = time.perf_counter() - t0
+    print(f"sdrhip_fm_stream, {blocks_per_push:5d} source blocks/push: {pushes * blocks_per_push * B / dt / 1e6:10.1f} Msamples/s "
+          f"({dt / pushes * 1e6:.0f} us/push); zero-copy input {pushes * blocks_per_push * B / dz / 1e6:10.1f} Msamples/s")
+
+
 def pipe_blocks(nblocks=512):
     dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
     pipe = L.firDecimator(dec, B)
@@ -87,5 +109,7 @@ def resampler_pipe_cfg4(nblocks=256):
 if __name__ == "__main__":
     print(L.device_name())
     chain_streamed()
+    for bpp, pushes in ((1, 2000), (16, 1000), (256, 200), (4096, 24)):
+        fm_stream(bpp, pushes)
     pipe_blocks()
     resampler_pipe_cfg4()
