@@ -13,7 +13,9 @@
     > firResamplerGpu :: GpuResampler -> Int -> Pipe (Vector Float) (Vector Float) IO ()                       -- firResampler, Filter.hs:679
     > firFilterGpu    :: GpuFilter    -> Int -> Pipe (Vector Float) (Vector Float) IO ()                       -- firFilter,    Filter.hs:532
     > fmDemodGpu      :: Pipe (Vector (Complex Float)) (Vector Float) IO ()                                    -- fmDemod,      Demod.hs:40
+    > dcBlockingFilterGpu :: Pipe (Vector Float) (Vector Float) IO ()                                          -- dcBlockingFilter, Filter.hs:730
     > interleavedIQUnsignedByteToFloatGpu :: Vector CUChar -> Vector (Complex Float)                           -- Util.hs:137
+    > fmReceiverGpu   :: GpuFmChain -> Int -> Int -> Pipe (Vector CUChar) (Vector Float) IO ()                 -- fm.hs:34-41 as one operator
 
     and produce the same vectors, bit for bit, as the AVX variants the reference selects on any AVX
     host (the One/Cross split at buffer seams included).
@@ -21,8 +23,9 @@
 module SDR.GPU (
     GpuDecimator, GpuResampler, GpuFilter,
     gpuDecimatorC, gpuResamplerR, gpuFilterSymR, gpuFilterR,
-    firDecimatorGpu, firResamplerGpu, firFilterGpu, fmDemodGpu,
-    interleavedIQUnsignedByteToFloatGpu
+    firDecimatorGpu, firResamplerGpu, firFilterGpu, fmDemodGpu, dcBlockingFilterGpu,
+    interleavedIQUnsignedByteToFloatGpu,
+    GpuFmChain, gpuFmChain, fmReceiverGpu
     ) where
 
 import           Control.Monad
@@ -38,10 +41,13 @@ data SdrDecimator
 data SdrResampler
 data SdrFilter
 data SdrPipe
+data SdrChain
+data SdrStream
 
 newtype GpuDecimator = GpuDecimator (Ptr SdrDecimator)
 newtype GpuResampler = GpuResampler (Ptr SdrResampler)
 newtype GpuFilter    = GpuFilter    (Ptr SdrFilter)
+newtype GpuFmChain   = GpuFmChain   (Ptr SdrChain)
 
 -- The imports are `safe`: the calls block on the device and must not stall the RTS.
 foreign import ccall safe "sdrhip_last_error"          c_last_error        :: IO CString
@@ -55,6 +61,11 @@ foreign import ccall safe "sdrhip_pipe_fir_filter"     c_pipe_filter       :: Pt
 foreign import ccall safe "sdrhip_pipe_fm_demod"       c_pipe_demod        :: Ptr (Ptr SdrPipe) -> IO CInt
 foreign import ccall safe "sdrhip_pipe_push"           c_pipe_push         :: Ptr SdrPipe -> Ptr CFloat -> CInt -> IO CInt
 foreign import ccall safe "sdrhip_pipe_pop"            c_pipe_pop          :: Ptr SdrPipe -> Ptr CFloat -> CInt -> IO CInt
+foreign import ccall safe "sdrhip_pipe_dc_blocker"     c_pipe_dc_blocker   :: Ptr (Ptr SdrPipe) -> IO CInt
+foreign import ccall safe "sdrhip_fm_chain_create"     c_chain_create      :: Ptr (Ptr SdrChain) -> CInt -> CInt -> Ptr CFloat -> CInt -> CInt -> CInt -> Ptr CFloat -> CInt -> Ptr CFloat -> CInt -> CFloat -> Int64 -> IO CInt
+foreign import ccall safe "sdrhip_fm_stream_create"    c_stream_create     :: Ptr (Ptr SdrStream) -> Ptr SdrChain -> CInt -> CInt -> IO CInt
+foreign import ccall safe "sdrhip_fm_stream_push"      c_stream_push       :: Ptr SdrStream -> Ptr CUChar -> CInt -> IO CInt
+foreign import ccall safe "sdrhip_fm_stream_pop"       c_stream_pop        :: Ptr SdrStream -> Ptr CFloat -> CInt -> IO CInt
 foreign import ccall safe "convertCAVX"                c_convertCAVX       :: CInt -> Ptr CUChar -> Ptr CFloat -> IO ()
 
 -- | SDRHIP_ORDER_AVX: reproduce the variant 'SDR.CPUID.featureSelect' picks on any AVX host.
@@ -151,3 +162,52 @@ interleavedIQUnsignedByteToFloatGpu inBuf = unsafePerformIO $ do
     VS.unsafeWith inBuf $ \iPtr -> withForeignPtr fp $ \oPtr ->
         c_convertCAVX (fromIntegral $ VS.length inBuf) iPtr oPtr
     return $ VS.unsafeCast $ VS.unsafeFromForeignPtr0 fp (VS.length inBuf)
+
+-- | 'dcBlockingFilter' (Filter.hs:730-739): one output vector per input vector, the filter state
+--   carried on the device.  Worth it for long vectors only (a short block is one dependent chain).
+dcBlockingFilterGpu :: Pipe (VS.Vector Float) (VS.Vector Float) IO ()
+dcBlockingFilterGpu = do
+    pipe <- lift $ mkPipe c_pipe_dc_blocker
+    forever $ do
+        inp   <- await
+        ready <- lift $ VS.unsafeWith (VS.unsafeCast inp) $ \ptr ->
+                     c_pipe_push pipe ptr (fromIntegral (VS.length inp)) >>= check
+        replicateM_ (fromIntegral ready) $ do
+            out <- lift $ do
+                let cap = VS.length inp
+                fp  <- mallocForeignPtrArray cap :: IO (ForeignPtr CFloat)
+                n   <- withForeignPtr fp $ \o -> c_pipe_pop pipe o (fromIntegral cap) >>= check
+                return $ VS.unsafeCast $ VS.unsafeFromForeignPtr0 fp (fromIntegral n)
+            yield out
+
+-- | The whole receiver of examples/fm/fm.hs:34-41 -- convert, decimate, demodulate, resample, filter,
+--   gain -- with every intermediate resident in device memory.  Arguments as in fm.hs: decimation and
+--   its taps, interpolation / decimation and the resampler taps, the HALF taps of the symmetric audio
+--   filter, the gain ('P.map (VG.map (* 0.2))'), and the source block size ('samples'; the seams of the
+--   reference's Pipes fall at multiples of it).
+gpuFmChain :: Int -> [Float] -> Int -> Int -> [Float] -> [Float] -> Float -> Int -> IO GpuFmChain
+gpuFmChain decimation rfTaps interpolation decimation2 resampTaps audioHalf gain block =
+    withArrayLen (map realToFrac rfTaps) $ \n1 p1 ->
+    withArrayLen (map realToFrac resampTaps) $ \n2 p2 ->
+    withArrayLen (map realToFrac audioHalf) $ \n3 p3 ->
+    alloca $ \pp -> do
+        _ <- c_chain_create pp orderAVX (fromIntegral decimation) p1 (fromIntegral n1)
+                 (fromIntegral interpolation) (fromIntegral decimation2) p2 (fromIntegral n2)
+                 p3 (fromIntegral n3) (realToFrac gain) (fromIntegral block) >>= check
+        GpuFmChain <$> peek pp
+
+-- | u8 IQ blocks from 'sdrStream' in, audio blocks of exactly @blockSizeOut@ floats out: same blocks,
+--   bit for bit, as the five stages it replaces.  @maxBlock@ = the largest source block (a multiple of
+--   the chain's block size) that will be pushed.
+fmReceiverGpu :: GpuFmChain -> Int -> Int -> Pipe (VS.Vector CUChar) (VS.Vector Float) IO ()
+fmReceiverGpu (GpuFmChain c) maxBlock blockSizeOut = do
+    st <- lift $ alloca $ \pp -> c_stream_create pp c (fromIntegral maxBlock) (fromIntegral blockSizeOut) >>= check >> peek pp
+    forever $ do
+        inp   <- await
+        ready <- lift $ VS.unsafeWith inp $ \ptr -> c_stream_push st ptr (fromIntegral (VS.length inp `div` 2)) >>= check
+        replicateM_ (fromIntegral ready) $ do
+            out <- lift $ do
+                fp <- mallocForeignPtrArray blockSizeOut :: IO (ForeignPtr CFloat)
+                _  <- withForeignPtr fp $ \o -> c_stream_pop st o (fromIntegral blockSizeOut) >>= check
+                return $ VS.unsafeCast $ VS.unsafeFromForeignPtr0 fp blockSizeOut
+            yield out

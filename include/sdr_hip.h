@@ -220,6 +220,18 @@ int sdrhip_scale_run(void *stream, float factor, const float *d_in, float *d_out
  * (the Pipe's carried state; (0,0) at stream start, Demod.hs:41). */
 int sdrhip_fm_demod_run(void *stream, const float *d_in_iq, int64_t in_base, float *d_out,
                         int64_t k_begin, int64_t k_end, float last_re, float last_im);
+/* dcBlocker (c_sources/filter.c:152-161; Pipe dcBlockingFilter, Filter.hs:730-739) on device memory:
+ * y[i] = (float)((double)(x[i] - x[i-1]) + 0.997 * (double)y[i-1]), x[-1] = last_sample, y[-1] = last_output.
+ * Bit-identical to the sequential loop (speculative chunks, verified and settled on the device).
+ * d_final receives {finalSample, finalOutput}.  d_workspace may be NULL (sequential walk); when given
+ * it starts with three uint32 statistics {chunks left to the sequential settle pass, samples it rewrote,
+ * chunks recomputed by the parallel repair rounds} -- all zero when every speculation converged.  run_in =
+ * samples each chunk runs in before its first output (0 = default 12288; a shorter run-in does less
+ * redundant work but leaves more chunks to settle; the result never depends on it).  Not in-place. */
+size_t sdrhip_dc_blocker_workspace_bytes(int64_t n);
+int sdrhip_dc_blocker_run(void *stream, const float *d_in, float *d_out, int64_t n, float last_sample,
+                          float last_output, float *d_final, void *d_workspace, size_t workspace_bytes,
+                          int run_in);
 
 /* ---- the FM receiver chain (examples/fm/fm.hs:34-41) ----------------------- */
 /* u8 IQ -> [convert] -> decimator -> fmDemod -> resampler -> symmetric filter
@@ -288,6 +300,7 @@ int sdrhip_pipe_fir_filter(sdrhip_pipe **p, const sdrhip_filter *f, int block_si
 int sdrhip_pipe_fir_decimator(sdrhip_pipe **p, const sdrhip_decimator *d, int block_size_out);    /* firDecimator */
 int sdrhip_pipe_fir_resampler(sdrhip_pipe **p, const sdrhip_resampler *r, int block_size_out);    /* firResampler */
 int sdrhip_pipe_fm_demod(sdrhip_pipe **p);                                                         /* fmDemod      */
+int sdrhip_pipe_dc_blocker(sdrhip_pipe **p);                                     /* dcBlockingFilter, Filter.hs:730-739 */
 /* Feed one upstream block (n elements: floats, or complex pairs for complex
  * stages).  Returns the number of complete output blocks now ready (>= 0) or a
  * negative error.  A block shorter than numCoeffs is the reference's

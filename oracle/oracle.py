@@ -224,6 +224,15 @@ class Oracle:
         self.lib.orc_fm_demod(n, C.c_float(last[0]), C.c_float(last[1]), _fp(x), _fp(out))
         return out
 
+    # N2: dcBlocker, filter.c:152-161
+    def dc_blocker(self, x, last_sample=0.0, last_output=0.0):
+        x = _f32(x)
+        out = np.empty(x.size, np.float32)
+        fs, fo = C.c_float(), C.c_float()
+        self.lib.orc_dc_blocker.argtypes = [C.c_int64, C.c_float, C.c_float, _f32p, _f32p, _f32p, _f32p]
+        self.lib.orc_dc_blocker(x.size, last_sample, last_output, C.byref(fs), C.byref(fo), _fp(x), _fp(out))
+        return out, fs.value, fo.value
+
     def atanf_sweep(self, lo, hi, step=1):
         bad = C.c_uint32(0)
         n = self.lib.orc_atanf_sweep(lo, hi, step, C.byref(bad))
@@ -243,6 +252,14 @@ class Ref:
         self.lib.scale.argtypes = [C.c_int, C.c_float, _f32p, _f32p]
         self.lib.scaleSSE.argtypes = [C.c_int, C.c_float, _f32p, _f32p]
         self.lib.scaleAVX.argtypes = [C.c_int, C.c_float, _f32p, _f32p]
+
+    def dc_blocker(self, x, last_sample=0.0, last_output=0.0):
+        x = _f32(x)
+        out = np.empty(x.size, np.float32)
+        fs, fo = C.c_float(), C.c_float()
+        self.lib.dcBlocker.argtypes = [C.c_int, C.c_float, C.c_float, _f32p, _f32p, _f32p, _f32p]
+        self.lib.dcBlocker(x.size, last_sample, last_output, C.byref(fs), C.byref(fo), _fp(x), _fp(out))
+        return out, fs.value, fo.value
 
     def convert(self, sym, u8, pad=16):
         u8 = np.ascontiguousarray(u8, dtype=np.uint8)

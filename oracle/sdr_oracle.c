@@ -540,3 +540,18 @@ uint64_t orc_atanf_sweep(uint32_t lo, uint32_t hi, uint32_t step, uint32_t *firs
     }
     return bad;
 }
+
+/* dcBlocker, c_sources/filter.c:152-161.  `0.997` is a double constant: the f32 difference and the f32 state are
+ * promoted, multiplied/added in f64 and rounded back to f32 by the assignment (x86-64 SSE2, FLT_EVAL_METHOD 0). */
+void orc_dc_blocker(int64_t num, float last_sample, float last_output, float *final_sample, float *final_output,
+                    const float *in, float *out)
+{
+    for (int64_t i = 0; i < num; i++) {
+        const float d = in[i] - last_sample;
+        last_output = (float)((double)d + 0.997 * (double)last_output);
+        out[i] = last_output;
+        last_sample = in[i];
+    }
+    *final_sample = last_sample;
+    *final_output = last_output;
+}

@@ -477,4 +477,19 @@ int sdrhip_fm_demod_run(void* stream, const float* d_in_iq, int64_t in_base, flo
     return SDRHIP_OK;
 }
 
+size_t sdrhip_dc_blocker_workspace_bytes(int64_t n) { return dc_blocker_workspace_bytes(n); }
+
+int sdrhip_dc_blocker_run(void* stream, const float* d_in, float* d_out, int64_t n, float last_sample, float last_output,
+                          float* d_final, void* d_workspace, size_t workspace_bytes, int run_in)
+{
+    SDRHIP_REQUIRE(n >= 0 && d_final != nullptr && run_in >= 0, "sdrhip_dc_blocker_run");
+    if (n == 0) return SDRHIP_OK;
+    SDRHIP_REQUIRE(d_in != nullptr && d_out != nullptr && d_in != d_out, "sdrhip_dc_blocker_run: in-place is not supported");
+    SDRHIP_REQUIRE(d_workspace == nullptr || workspace_bytes >= dc_blocker_workspace_bytes(n),
+                   "sdrhip_dc_blocker_run: workspace smaller than sdrhip_dc_blocker_workspace_bytes(n)");
+    launch_dc_blocker((hipStream_t)stream, n, last_sample, last_output, d_in, d_out, d_final, d_workspace, run_in);
+    SDRHIP_CHECK_HIP(hipGetLastError());
+    return SDRHIP_OK;
+}
+
 }  // extern "C"

@@ -251,13 +251,14 @@ void dcBlocker(int num, float lastSample, float lastOutput, float* finalSample, 
     Scratch& sc = scratch();
     std::lock_guard<std::mutex> lk(sc.mu);
     up(sc, sc.in, inBuf, (size_t)num * 4);
-    die_if(sc.out.ensure((size_t)num * 4 + 8), "device buffer");
-    float* dout = (float*)sc.out.p;
-    launch_dc_blocker(sc.s(), num, lastSample, lastOutput, (const float*)sc.in.p, dout + 2, dout);
+    die_if(sc.out.ensure((size_t)num * 4 + 16), "device buffer");
+    die_if(sc.taps2.ensure(dc_blocker_workspace_bytes(num)), "device buffer");
+    float* dout = (float*)sc.out.p;   // {finalSample, finalOutput, -, -} then the block, 16-byte aligned
+    launch_dc_blocker(sc.s(), num, lastSample, lastOutput, (const float*)sc.in.p, dout + 4, dout, sc.taps2.p, 0);
     SDRHIP_DIE_HIP(hipGetLastError());
     float fin[2];
     SDRHIP_DIE_HIP(hipMemcpyAsync(fin, dout, 8, hipMemcpyDeviceToHost, sc.s()));
-    SDRHIP_DIE_HIP(hipMemcpyAsync(outBuf, dout + 2, (size_t)num * 4, hipMemcpyDeviceToHost, sc.s()));
+    SDRHIP_DIE_HIP(hipMemcpyAsync(outBuf, dout + 4, (size_t)num * 4, hipMemcpyDeviceToHost, sc.s()));
     SDRHIP_DIE_HIP(hipStreamSynchronize(sc.s()));
     *finalSample = fin[0];
     *finalOutput = fin[1];

@@ -74,9 +74,14 @@ void launch_scale(hipStream_t s, float factor, const float* d_in, float* d_out, 
 // y[i] = phase(x[i] * conj(x[i-1])), i < count; x[-1] = d_in[-1] if has_prev else (last_re,last_im)
 void launch_fm_demod(hipStream_t s, const float* d_in_iq, float* d_out, int64_t count, bool has_prev,
                      float last_re, float last_im);
-// filter.c:152-161 (sequential one-pole IIR; d_final receives {finalSample, finalOutput})
+// filter.c:152-161 (kernels_iir.hip: speculative chunks + verification, bit-exact with the sequential walk).
+// d_final receives {finalSample, finalOutput}; d_ws (dc_blocker_workspace_bytes, may be null = sequential walk)
+// starts with three u32 statistics {chunks left to the sequential settle, samples it rewrote, chunks recomputed in the
+// parallel repair rounds}; run_in <= 0 selects the default.  d_state, when given, holds {lastSample, lastOutput} on
+// the device and overrides the two scalars (it may alias d_final: a Pipe chains its blocks that way).
+size_t dc_blocker_workspace_bytes(int64_t num);
 void launch_dc_blocker(hipStream_t s, int64_t num, float last_sample, float last_output, const float* d_in,
-                       float* d_out, float* d_final);
+                       float* d_out, float* d_final, void* d_ws, int run_in, const float* d_state = nullptr);
 
 // Fast paths (kernels_fast.hip).  Return false when the configuration is not one
 // they are specialised for; the caller then uses the generic kernel.

@@ -534,29 +534,4 @@ void launch_fm_demod(hipStream_t s, const float* d_in_iq, float* d_out, int64_t 
                        last_re, last_im);
 }
 
-// ---------------------------------------------------------------------------
-// dcBlocker, filter.c:152-161: lastOutput = in[i] - lastSample + 0.997 * lastOutput
-// with the f32 subtract promoted to f64 by the double constant, rounded to f32 on
-// assignment.  Inherently sequential (one-pole IIR): one lane walks the block.
-// This is a "next" row, kept bit-exact, not yet parallelised.
-// ---------------------------------------------------------------------------
-__global__ void k_dc_blocker(int64_t num, float last_sample, float last_output, const float* __restrict__ in,
-                             float* __restrict__ out, float* __restrict__ fin)
-{
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    for (int64_t i = 0; i < num; i++) {
-        float d = in[i] - last_sample;
-        last_output = (float)((double)d + 0.997 * (double)last_output);
-        out[i] = last_output;
-        last_sample = in[i];
-    }
-    fin[0] = last_sample;
-    fin[1] = last_output;
-}
-void launch_dc_blocker(hipStream_t s, int64_t num, float last_sample, float last_output, const float* d_in,
-                       float* d_out, float* d_final)
-{
-    hipLaunchKernelGGL(k_dc_blocker, dim3(1), dim3(64), 0, s, num, last_sample, last_output, d_in, d_out, d_final);
-}
-
 }  // namespace sdrhip

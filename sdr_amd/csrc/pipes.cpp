@@ -26,7 +26,7 @@
 
 using namespace sdrhip;
 
-enum PipeKind { PK_FILTER, PK_DECIMATOR, PK_RESAMPLER, PK_DEMOD };
+enum PipeKind { PK_FILTER, PK_DECIMATOR, PK_RESAMPLER, PK_DEMOD, PK_DCBLOCK };
 
 struct sdrhip_pipe {
     PipeKind kind;
@@ -65,7 +65,9 @@ struct sdrhip_pipe {
     std::vector<float> fifo;
     size_t fifo_head = 0;
     size_t fifo_size() const { return fifo.size() - fifo_head; }
-    std::deque<int> demod_blocks;      // fmDemod: output block lengths (one per input block)
+    std::deque<int> demod_blocks;      // fmDemod / dcBlockingFilter: output block lengths (one per input block)
+    DevBuf dc_state, dc_ws;            // dcBlockingFilter: {lastSample, lastOutput} carried on the device
+    bool is_map() const { return kind == PK_DEMOD || kind == PK_DCBLOCK; }
 
     int esz_in() const { return cplx_in ? 2 : 1; }
     int esz_out() const { return cplx_out ? 2 : 1; }
@@ -126,7 +128,7 @@ static int harvest(sdrhip_pipe* p, int si)
 
 static int ready_blocks(const sdrhip_pipe* p)
 {
-    if (p->kind == PK_DEMOD) {
+    if (p->is_map()) {
         // complete blocks = those whose floats have all been harvested
         size_t have = p->fifo_size(), n = 0;
         for (int len : p->demod_blocks) {
@@ -197,6 +199,20 @@ int sdrhip_pipe_fm_demod(sdrhip_pipe** pp)
     return SDRHIP_OK;
 }
 
+int sdrhip_pipe_dc_blocker(sdrhip_pipe** pp)
+{
+    SDRHIP_REQUIRE(pp != nullptr, "sdrhip_pipe_dc_blocker");
+    int rc = pipe_new(pp, PK_DCBLOCK);
+    if (rc != SDRHIP_OK) return rc;
+    sdrhip_pipe* p = *pp;
+    p->cplx_in = false;
+    p->cplx_out = false;
+    if ((rc = p->dc_state.ensure(16)) != SDRHIP_OK) { delete p; *pp = nullptr; return rc; }
+    hipError_t e = hipMemsetAsync(p->dc_state.p, 0, 16, p->stream);   // func 0 0, Filter.hs:732
+    if (e != hipSuccess) { set_error("sdrhip_pipe_dc_blocker: %s", hipGetErrorString(e)); delete p; *pp = nullptr; return SDRHIP_ERR_HIP; }
+    return SDRHIP_OK;
+}
+
 int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
 {
     SDRHIP_REQUIRE(p != nullptr && block != nullptr && n > 0, "sdrhip_pipe_push");
@@ -210,8 +226,8 @@ int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
     if ((rc = sl.hin.ensure((size_t)n * ein)) != SDRHIP_OK) return rc;
     memcpy(sl.hin.p, block, (size_t)n * ein);
 
-    if (p->kind == PK_DEMOD) {
-        // fmDemodVec last dat (Demod.hs:32-36,43-46): one output vector per input vector
+    if (p->is_map()) {
+        // fmDemodVec last dat (Demod.hs:32-36,43-46) / dcBlockingFilter (Filter.hs:730-739): one output vector per input vector
         DevBuf& d = p->din[p->cur];
         if ((rc = d.ensure((size_t)n * ein)) != SDRHIP_OK) return rc;
         if ((rc = sl.dout.ensure((size_t)n * eout)) != SDRHIP_OK) return rc;
@@ -219,14 +235,20 @@ int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
         SDRHIP_CHECK_HIP(hipMemcpyAsync(d.p, sl.hin.p, (size_t)n * ein, hipMemcpyHostToDevice, p->up));
         SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, p->up));
         SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->stream, sl.ev_up, 0));
-        launch_fm_demod_fast(p->stream, (const float*)d.p, (float*)sl.dout.p, n, false, p->last_re, p->last_im);
+        if (p->kind == PK_DEMOD) {
+            launch_fm_demod_fast(p->stream, (const float*)d.p, (float*)sl.dout.p, n, false, p->last_re, p->last_im);
+            p->last_re = block[2 * (n - 1)];
+            p->last_im = block[2 * (n - 1) + 1];
+        } else {
+            if ((rc = p->dc_ws.ensure(dc_blocker_workspace_bytes(n))) != SDRHIP_OK) return rc;
+            launch_dc_blocker(p->stream, n, 0.0f, 0.0f, (const float*)d.p, (float*)sl.dout.p, (float*)p->dc_state.p, p->dc_ws.p, 0,
+                              (const float*)p->dc_state.p);
+        }
         SDRHIP_CHECK_HIP(hipGetLastError());
         SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, p->stream));
         SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->down, sl.ev_k, 0));
         SDRHIP_CHECK_HIP(hipMemcpyAsync(sl.hout.p, sl.dout.p, (size_t)n * eout, hipMemcpyDeviceToHost, p->down));
         SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, p->down));
-        p->last_re = block[2 * (n - 1)];
-        p->last_im = block[2 * (n - 1) + 1];
         sl.n_out = n;
         sl.busy = true;
         p->demod_blocks.push_back(n);
@@ -318,12 +340,12 @@ int sdrhip_pipe_pop(sdrhip_pipe* p, float* out, int capacity)
 {
     SDRHIP_REQUIRE(p != nullptr && out != nullptr, "sdrhip_pipe_pop");
     if (ready_blocks(p) <= 0) return 0;
-    int len = p->kind == PK_DEMOD ? p->demod_blocks.front() : p->block_out;
+    int len = p->is_map() ? p->demod_blocks.front() : p->block_out;
     SDRHIP_REQUIRE(capacity >= len, "sdrhip_pipe_pop: capacity smaller than the block");
     size_t nf = (size_t)len * p->esz_out();
     memcpy(out, p->fifo.data() + p->fifo_head, nf * sizeof(float));
     p->fifo_head += nf;
-    if (p->kind == PK_DEMOD) p->demod_blocks.pop_front();
+    if (p->is_map()) p->demod_blocks.pop_front();
     return len;
 }
 

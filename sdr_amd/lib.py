@@ -97,6 +97,10 @@ lib.sdrhip_fm_chain_set_pipelining.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_enable_timing.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_read_timing.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
+lib.sdrhip_dc_blocker_workspace_bytes.argtypes = [C.c_int64]
+lib.sdrhip_dc_blocker_workspace_bytes.restype = C.c_size_t
+lib.sdrhip_dc_blocker_run.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, _vp, _vp, C.c_size_t, C.c_int]
+
 lib.sdrhip_fm_stream_create.argtypes = [C.POINTER(_vp), _vp, C.c_int, C.c_int]
 lib.sdrhip_fm_stream_destroy.argtypes = [_vp]
 lib.sdrhip_fm_stream_destroy.restype = None
@@ -110,6 +114,7 @@ lib.sdrhip_pipe_fir_filter.argtypes = [C.POINTER(_vp), _vp, C.c_int]
 lib.sdrhip_pipe_fir_decimator.argtypes = [C.POINTER(_vp), _vp, C.c_int]
 lib.sdrhip_pipe_fir_resampler.argtypes = [C.POINTER(_vp), _vp, C.c_int]
 lib.sdrhip_pipe_fm_demod.argtypes = [C.POINTER(_vp)]
+lib.sdrhip_pipe_dc_blocker.argtypes = [C.POINTER(_vp)]
 lib.sdrhip_pipe_push.argtypes = [_vp, _f32p, C.c_int]
 lib.sdrhip_pipe_flush.argtypes = [_vp]
 lib.sdrhip_pipe_pop.argtypes = [_vp, _f32p, C.c_int]
@@ -418,6 +423,8 @@ class Pipe(_Handle):
             check(lib.sdrhip_pipe_fir_resampler(C.byref(self.h), desc.h, block_size_out), "sdrhip_pipe_fir_resampler")
         elif kind == "fm_demod":
             check(lib.sdrhip_pipe_fm_demod(C.byref(self.h)), "sdrhip_pipe_fm_demod")
+        elif kind == "dc_blocker":
+            check(lib.sdrhip_pipe_dc_blocker(C.byref(self.h)), "sdrhip_pipe_dc_blocker")
         else:
             raise ValueError(kind)
         self.kind = kind
@@ -459,6 +466,11 @@ def firResampler(resampler, block_size_out):
 
 def fmDemod():
     return Pipe("fm_demod")
+
+
+def dcBlockingFilter():
+    """Filter.hs:730-739."""
+    return Pipe("dc_blocker")
 
 
 def interleavedIQUnsignedByteToFloat(u8):
