@@ -220,6 +220,10 @@ int sdrhip_scale_run(void *stream, float factor, const float *d_in, float *d_out
  * (the Pipe's carried state; (0,0) at stream start, Demod.hs:41). */
 int sdrhip_fm_demod_run(void *stream, const float *d_in_iq, int64_t in_base, float *d_out,
                         int64_t k_begin, int64_t k_end, float last_re, float last_im);
+/* Diagnostics: how many stream-API launches the general LDS-tiled kernels (kernels_split.hip) have served in
+ * this process -- the tests use it to prove the tiled path, not the one-thread-per-output fallback, ran. */
+long long sdrhip_debug_tiled_launches(void);
+
 /* dcBlocker (c_sources/filter.c:152-161; Pipe dcBlockingFilter, Filter.hs:730-739) on device memory:
  * y[i] = (float)((double)(x[i] - x[i-1]) + 0.997 * (double)y[i-1]), x[-1] = last_sample, y[-1] = last_output.
  * Bit-identical to the sequential loop (speculative chunks, verified and settled on the device).

@@ -145,6 +145,9 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
         } else if (d->corder == CO_L4 && !in_u8 &&
                    launch_filter_cplx4_fast(s, g, d->d_taps, d->Lp, d->d_cross, (const float*)d_in, d_out)) {
             // LDS-tiled complex filter took it
+        } else if (!in_u8 && launch_fir_split(s, g, true, 0, d->corder, d->sym, d->sym ? d->d_taps : d->d_plain,
+                                              d->sym ? d->ntaps_kernel : d->Lp, d->d_cross, (const float*)d_in, d_out, 1.0f, false)) {
+            // lane-split tiled kernel took it (any factor / tap count / SIMD order)
         } else if (in_u8) {
             launch_fir_cplx_u8(s, g, d->corder, d->d_taps, d->ntaps_kernel, d->d_cross, (const uint8_t*)d_in, d_out);
         } else {
@@ -156,6 +159,9 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
         if (d->lanes == 8 &&
             launch_fir_real8_fast(s, g, d->sym, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out, gain, gain != 1.0f)) {
             // LDS-tiled kernel took it (gain fused)
+        } else if (launch_fir_split(s, g, false, d->lanes, CO_SEQ, d->sym, d->sym ? d->d_taps : d->d_plain,
+                                    d->sym ? d->ntaps_kernel : d->Lp, d->d_cross, (const float*)d_in, d_out, gain, gain != 1.0f)) {
+            // lane-split tiled kernel took it (decimators, SSE order; gain fused)
         } else {
             launch_fir_real(s, g, d->lanes, d->sym, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out);
             if (gain != 1.0f) launch_scale(s, gain, d_out, d_out, g.count);
@@ -251,9 +257,13 @@ int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in
     t.ntaps_plain = r->ntaps;
     t.force_seq = 0;
     for (int q = 0; q < r->num_groups; q++) t.fo[q] = r->offsets[q];
-    if (r->cplx) launch_resample_cplx(s, g, r->corder, t, r->d_groups, r->d_plain, d_in, d_out);
-    else if (r->lanes == 8 && launch_resample_3_10_fast(s, g, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
+    if (r->cplx) {
+        if (!launch_resample_split(s, g, true, r->lanes, r->corder, t, r->d_groups, r->d_plain, d_in, d_out))
+            launch_resample_cplx(s, g, r->corder, t, r->d_groups, r->d_plain, d_in, d_out);
+    } else if (r->lanes == 8 && launch_resample_3_10_fast(s, g, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
         // specialised 3-group kernel took it
+    } else if (launch_resample_split(s, g, false, r->lanes, r->corder, t, r->d_groups, r->d_plain, d_in, d_out)) {
+        // lane-split tiled kernel took it (any I/D, SSE order)
     } else launch_resample_real(s, g, r->lanes, t, r->d_groups, r->d_plain, d_in, d_out);
     SDRHIP_CHECK_HIP(hipGetLastError());
     return SDRHIP_OK;
@@ -476,6 +486,8 @@ int sdrhip_fm_demod_run(void* stream, const float* d_in_iq, int64_t in_base, flo
     SDRHIP_CHECK_HIP(hipGetLastError());
     return SDRHIP_OK;
 }
+
+long long sdrhip_debug_tiled_launches(void) { return split_launch_count(); }
 
 size_t sdrhip_dc_blocker_workspace_bytes(int64_t n) { return dc_blocker_workspace_bytes(n); }
 

@@ -1,0 +1,102 @@
+// crossfix.hpp -- generic "Cross" (seam) fix-up kernels shared by the tiled kernels (internal header).
+//
+// The tiled kernels compute every output in the SIMD ("One") order; the few outputs whose window straddles a
+// seam of the reference's input buffers are then rewritten in the sequential order the reference's Haskell
+// fallbacks use (FilterInternal.hs:397-423).  These versions take any D / Lp / I and read global memory
+// directly; the hot configurations have LDS-staged specialisations next to their kernels.
+#pragma once
+#include "kernels.hpp"
+
+namespace sdrhip {
+namespace {
+
+// Cross outputs of a complex filter / decimator: sequential over the Lp plain taps
+// (filterCrossHighLevel with Mult (Complex a) a, FilterInternal.hs:397-408, Util.hs:87-88).
+__global__ void __launch_bounds__(256) k_fir_cplx_crossfix(Geom g, const float* __restrict__ xtaps,
+                                                            const float* __restrict__ in, float* __restrict__ out,
+                                                            int64_t first_seam, int nseams, int per_seam)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseams * per_seam) return;
+    const int si = t / per_seam, ci = t - si * per_seam;
+    const int64_t edge = (first_seam + si) * g.seamBI;
+    const int64_t m = (edge + g.D - 1) / g.D - 1 - ci;
+    if (m < g.k_begin || m >= g.k_begin + g.count) return;
+    const int64_t v = m * g.D;
+    if (!(v < edge && v + g.Lp > edge)) return;
+    const float2* x = reinterpret_cast<const float2*>(in) + (v - g.in_base);
+    float re = 0.0f, im = 0.0f;
+    for (int j = 0; j < g.Lp; j++) {
+        const float2 s = x[j];
+        re = re + s.x * xtaps[j];
+        im = im + s.y * xtaps[j];
+    }
+    *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
+}
+
+// Cross outputs of a real FIR / decimator: sequential over the Lp plain taps
+// (filterCrossHighLevel / decimateCrossHighLevel, FilterInternal.hs:397-408).
+__global__ void __launch_bounds__(256) k_fir_real_crossfix(Geom g, const float* __restrict__ xtaps,
+                                                            const float* __restrict__ in, float* __restrict__ out,
+                                                            int64_t first_seam, int nseams, int per_seam, float gain,
+                                                            int apply_gain)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseams * per_seam) return;
+    const int si = t / per_seam, ci = t - si * per_seam;
+    const int64_t edge = (first_seam + si) * g.seamBI;
+    const int64_t m = (edge + g.D - 1) / g.D - 1 - ci;
+    if (m < g.k_begin || m >= g.k_begin + g.count) return;
+    const int64_t v = m * g.D;
+    if (!(v < edge && v + g.Lp > edge)) return;
+    const float* x = in + (v - g.in_base);
+    float r = 0.0f;
+    for (int j = 0; j < g.Lp; j++) r = r + x[j] * xtaps[j];
+    if (apply_gain) r = r * gain;
+    out[m - g.k_begin] = r;
+}
+
+// Cross outputs of a resampler, real or complex data (resampleCrossHighLevel, FilterInternal.hs:410-423):
+// taps = stride I (drop filterOffset coeffs) over the UNPADDED taps, sequential.
+template <bool CPLX>
+__global__ void __launch_bounds__(256) k_resample_crossfix(Geom g, const float* __restrict__ plain, int ntaps,
+                                                            const float* __restrict__ in, float* __restrict__ out,
+                                                            int64_t first_seam, int nseams, int per_seam)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseams * per_seam) return;
+    const int si = t / per_seam, ci = t - si * per_seam;
+    const int64_t edge = (first_seam + si) * g.seamBI;           // upsampled units
+    const int64_t m = (edge + g.D - 1) / g.D - 1 - ci;
+    if (m < g.k_begin || m >= g.k_begin + g.count) return;
+    const int64_t v = m * g.D;
+    if (!(v < edge && v + g.Lp > edge)) return;
+    const int64_t pos = (v + g.I - 1) / g.I;                     // inOff(m)
+    const int fo = (int)(pos * g.I - v);
+    if constexpr (CPLX) {
+        const float2* x = reinterpret_cast<const float2*>(in) + (pos - g.in_base);
+        float re = 0.0f, im = 0.0f;
+        for (int l = 0, j = fo; j < ntaps; l++, j += g.I) {
+            const float2 sv = x[l];
+            re = re + sv.x * plain[j];
+            im = im + sv.y * plain[j];
+        }
+        *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
+    } else {
+        const float* x = in + (pos - g.in_base);
+        float r = 0.0f;
+        for (int l = 0, j = fo; j < ntaps; l++, j += g.I) r = r + x[l] * plain[j];
+        out[m - g.k_begin] = r;
+    }
+}
+
+// seams (multiples of seamBI) strictly inside the launch's window range
+inline void seam_range(const Geom& g, int64_t& first, int64_t& last)
+{
+    const int64_t v_lo = g.k_begin * g.D, v_hi = (g.k_begin + g.count - 1) * g.D + g.Lp;
+    first = v_lo / g.seamBI + 1;
+    last = (v_hi - 1) / g.seamBI;
+}
+
+}  // namespace
+}  // namespace sdrhip

@@ -83,6 +83,15 @@ size_t dc_blocker_workspace_bytes(int64_t num);
 void launch_dc_blocker(hipStream_t s, int64_t num, float last_sample, float last_output, const float* d_in,
                        float* d_out, float* d_final, void* d_ws, int run_in, const float* d_state = nullptr);
 
+// Lane-split tiled kernels (kernels_split.hip): every SIMD order of the filter / decimator / resampler families,
+// any factor and tap count that fits a tile.  Plain taps (sym: the half taps).  false = not applicable.
+bool launch_fir_split(hipStream_t s, const Geom& g, bool cplx, int lanes, ComplexOrder corder, bool sym, const float* d_taps,
+                      int ntaps, const float* d_cross_taps, const float* d_in, float* d_out, float gain, bool apply_gain);
+bool launch_resample_split(hipStream_t s, const Geom& g, bool cplx, int lanes, ComplexOrder corder, const ResampTable& t,
+                           const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out);
+
+long long split_launch_count();   // diagnostics: launches the lane-split kernels have taken so far
+
 // Fast paths (kernels_fast.hip).  Return false when the configuration is not one
 // they are specialised for; the caller then uses the generic kernel.
 // kernels_chain.hip: fast paths of the low-rate stages

@@ -12,6 +12,7 @@
 // Arithmetic contract as in kernels_generic.hip (-ffp-contract=off, lane orders of the
 // AVX variants: resampleAVXRR resample.c:70-87, filterAVXSymmetricRR filter.c:60-68).
 #include "kernels.hpp"
+#include "crossfix.hpp"
 
 namespace sdrhip {
 
@@ -288,52 +289,6 @@ __global__ void __launch_bounds__(NT) k_filter_cplx4_fast(const float* __restric
     }
 }
 
-// Cross outputs of a complex filter / decimator: sequential over the Lp plain taps
-// (filterCrossHighLevel with Mult (Complex a) a, FilterInternal.hs:397-408, Util.hs:87-88).
-__global__ void __launch_bounds__(256) k_fir_cplx_crossfix(Geom g, const float* __restrict__ xtaps,
-                                                            const float* __restrict__ in, float* __restrict__ out,
-                                                            int64_t first_seam, int nseams, int per_seam)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nseams * per_seam) return;
-    const int si = t / per_seam, ci = t - si * per_seam;
-    const int64_t edge = (first_seam + si) * g.seamBI;
-    const int64_t m = (edge + g.D - 1) / g.D - 1 - ci;
-    if (m < g.k_begin || m >= g.k_begin + g.count) return;
-    const int64_t v = m * g.D;
-    if (!(v < edge && v + g.Lp > edge)) return;
-    const float2* x = reinterpret_cast<const float2*>(in) + (v - g.in_base);
-    float re = 0.0f, im = 0.0f;
-    for (int j = 0; j < g.Lp; j++) {
-        const float2 s = x[j];
-        re = re + s.x * xtaps[j];
-        im = im + s.y * xtaps[j];
-    }
-    *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
-}
-
-// Cross outputs of a real FIR / decimator: sequential over the Lp plain taps
-// (filterCrossHighLevel / decimateCrossHighLevel, FilterInternal.hs:397-408).
-__global__ void __launch_bounds__(256) k_fir_real_crossfix(Geom g, const float* __restrict__ xtaps,
-                                                            const float* __restrict__ in, float* __restrict__ out,
-                                                            int64_t first_seam, int nseams, int per_seam, float gain,
-                                                            int apply_gain)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nseams * per_seam) return;
-    const int si = t / per_seam, ci = t - si * per_seam;
-    const int64_t edge = (first_seam + si) * g.seamBI;
-    const int64_t m = (edge + g.D - 1) / g.D - 1 - ci;
-    if (m < g.k_begin || m >= g.k_begin + g.count) return;
-    const int64_t v = m * g.D;
-    if (!(v < edge && v + g.Lp > edge)) return;
-    const float* x = in + (v - g.in_base);
-    float r = 0.0f;
-    for (int j = 0; j < g.Lp; j++) r = r + x[j] * xtaps[j];
-    if (apply_gain) r = r * gain;
-    out[m - g.k_begin] = r;
-}
-
 // The filter case (D == 1, LP taps): the LP-1 straddlers of a seam have windows one sample apart;
 // one workgroup stages their union (2*LP - 2 floats, coalesced) in LDS and thread c walks window c.
 template <int LP>
@@ -471,12 +426,6 @@ __global__ void __launch_bounds__(256) k_resample_real_crossfix(Geom g, const fl
     out[m - g.k_begin] = r;
 }
 
-inline void seam_range(const Geom& g, int64_t& first, int64_t& last)
-{
-    const int64_t v_lo = g.k_begin * g.D, v_hi = (g.k_begin + g.count - 1) * g.D + g.Lp;
-    first = v_lo / g.seamBI + 1;
-    last = (v_hi - 1) / g.seamBI;
-}
 
 }  // namespace
 

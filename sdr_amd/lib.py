@@ -97,6 +97,8 @@ lib.sdrhip_fm_chain_set_pipelining.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_enable_timing.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_read_timing.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
+lib.sdrhip_debug_tiled_launches.argtypes = []
+lib.sdrhip_debug_tiled_launches.restype = C.c_longlong
 lib.sdrhip_dc_blocker_workspace_bytes.argtypes = [C.c_int64]
 lib.sdrhip_dc_blocker_workspace_bytes.restype = C.c_size_t
 lib.sdrhip_dc_blocker_run.argtypes = [_vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, _vp, _vp, C.c_size_t, C.c_int]

@@ -1,0 +1,130 @@
+"""GPU parity of the general LDS-tiled ("lane-split") kernels (kernels_split.hip): every SIMD order of
+the decimator / filter / resampler families at sizes where the stream API takes the tiled path, against the restated
+Pipes (oracle/pipes_model.py) -- One outputs in the SIMD lane order, seam straddlers in the sequential order."""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from oracle import pipes_model as PM
+import signals as S
+from gpu_util import to_dev, dev_empty_f32, ptr, to_host
+
+pytestmark = pytest.mark.gpu
+
+B = 8192
+NBLK = 24
+
+
+def _split(x, width, block):
+    n = x.size // width
+    return [x[i * block * width:(i + 1) * block * width] for i in range(n // block)]
+
+
+def _run(desc, d_in, out_width, K, seam, cuts=()):
+    out = dev_empty_f32(K * out_width)
+    edges = [0] + list(cuts) + [K]
+    for a, b in zip(edges[:-1], edges[1:]):
+        if b > a:
+            desc.run(ptr(d_in), 0, ptr(out) + 4 * out_width * a, a, b, seam)
+    return to_host(out)
+
+
+def _tiled(hip):
+    return hip.lib.sdrhip_debug_tiled_launches()
+
+
+_PARTIALS = {(PM.ORDER_AVX, False): 8, (PM.ORDER_SSE, False): 4,      # real: 8 / 4 lanes (common.h:34-72)
+             (PM.ORDER_AVX, True): 4, (PM.ORDER_SSE, True): 2}        # complex RC: 4 / 2 complex lanes (decimate.c:84-113)
+
+
+def _fits(taps_walked, order, complex_, resampler=False):
+    """The tiled kernel keeps one tap per partial-sum chunk in registers: at most 64 chunks."""
+    m = _PARTIALS[(order, complex_)]
+    if resampler and complex_:
+        m *= 2                                                       # the RC2 order: 8 / 4 partials (common.h:108-155)
+    return taps_walked // m <= 64
+
+
+@pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE])
+@pytest.mark.parametrize("complex_", [False, True])
+@pytest.mark.parametrize("factor,ntaps", [(2, 77), (4, 128), (5, 31), (8, 77), (10, 200), (16, 127), (32, 64)])
+def test_decimator_families(hip, oracle, order, complex_, factor, ntaps):
+    w = 2 if complex_ else 1
+    x = S.cfloat_block(NBLK * B) if complex_ else S.real_block(NBLK * B)
+    taps = S.gauss_taps(ntaps, factor + ntaps)
+    model = PM.FilterModel(oracle, taps, order, complex_=complex_, factor=factor)
+    blocks, _ = PM.fir_decimator_pipe(model, _split(x, w, B), 1024)
+    exp = np.concatenate(blocks)
+    K = exp.size // w
+    assert K >= 4096
+    d = hip.Decimator(factor, taps, order, complex_=complex_)
+    special = (factor, d.num_coeffs, order, complex_) in ((8, 128, PM.ORDER_AVX, True), (8, 52, PM.ORDER_AVX, True))
+    before = _tiled(hip)
+    got = _run(d, to_dev(x), w, K, B)
+    if _fits(d.num_coeffs, order, complex_) and not special:
+        assert _tiled(hip) > before, "the tiled kernel did not take this launch"
+    assert_bit_equal(got, exp, "one launch")
+    got = _run(d, to_dev(x), w, K, B, cuts=[4097, K - 4099])
+    assert_bit_equal(got, exp, "three launches")
+    # lone buffer: no seams at all
+    got0 = _run(d, to_dev(x), w, K, 0)
+    seq = PM.FilterModel(oracle, taps, order, complex_=complex_, factor=factor)
+    assert_bit_equal(got0[: w * 16], seq.one(16, x), "contiguous (all One)")
+
+
+@pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE])
+@pytest.mark.parametrize("factor,nhalf", [(1, 32), (2, 64), (4, 24), (8, 64)])
+def test_symmetric_real_families(hip, oracle, order, factor, nhalf):
+    if order == PM.ORDER_AVX and factor == 1:
+        pytest.skip("the AVX symmetric filter has its own kernel (k_fir_real8_fast)")
+    x = S.real_block(NBLK * B)
+    half = S.gauss_taps(nhalf, 900 + nhalf)
+    model = PM.FilterModel(oracle, half, order, sym=True, factor=factor)
+    blocks, _ = PM.fir_decimator_pipe(model, _split(x, 1, B), 1024)
+    exp = np.concatenate(blocks)
+    d = hip.Decimator(factor, half, order, sym=True) if factor > 1 else hip.Filter(half, order, sym=True)
+    before = _tiled(hip)
+    got = _run(d, to_dev(x), 1, exp.size, B)
+    assert _tiled(hip) > before
+    assert_bit_equal(got, exp, "symmetric")
+
+
+@pytest.mark.parametrize("order", [PM.ORDER_SSE])
+@pytest.mark.parametrize("complex_", [False, True])
+def test_filter_sse_orders(hip, oracle, order, complex_):
+    w = 2 if complex_ else 1
+    x = S.cfloat_block(4 * B) if complex_ else S.real_block(4 * B)
+    taps = S.gauss_taps(77, 5)
+    model = PM.FilterModel(oracle, taps, order, complex_=complex_)
+    blocks, _ = PM.fir_filter_pipe(model, _split(x, w, B), 1024)
+    exp = np.concatenate(blocks)
+    f = hip.Filter(taps, order, complex_=complex_)
+    before = _tiled(hip)
+    got = _run(f, to_dev(x), w, exp.size // w, B, cuts=[5000])
+    assert _tiled(hip) > before
+    assert_bit_equal(got, exp, "SSE-order filter")
+
+
+@pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE])
+@pytest.mark.parametrize("complex_", [False, True])
+@pytest.mark.parametrize("I,D,ntaps", [(3, 10, 191), (2, 3, 150), (5, 7, 191), (7, 11, 100), (3, 23, 150), (1, 4, 64), (4, 6, 90)])
+def test_resampler_families(hip, oracle, order, complex_, I, D, ntaps):
+    w = 2 if complex_ else 1
+    x = S.cfloat_block(NBLK * B) if complex_ else S.real_block(NBLK * B)
+    taps = S.gauss_taps(ntaps, 10 * I + D)
+    if I == 4:
+        pytest.skip("gcd(I, D) != 1: the reference's own wrapper assumes numGroups == I (SURVEY.md A8)")
+    model = PM.ResamplerModel(oracle, I, D, taps, order, complex_)
+    blocks, _ = PM.fir_resampler_pipe(model, _split(x, w, B), 512)
+    exp = np.concatenate(blocks)
+    K = exp.size // w
+    assert K >= 4096
+    r = hip.Resampler(I, D, taps, order, complex_)
+    is_special = (I, D, order, complex_) == (3, 10, PM.ORDER_AVX, False)
+    before = _tiled(hip)
+    got = _run(r, to_dev(x), w, K, B)
+    if not is_special:
+        assert _tiled(hip) > before, "the tiled kernel did not take this launch"
+    assert_bit_equal(got, exp, "one launch")
+    got = _run(r, to_dev(x), w, K, B, cuts=[4099, 4099 + 4097, K - 5000])
+    assert_bit_equal(got, exp, "cut into launches (every starting group)")

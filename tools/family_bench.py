@@ -31,18 +31,32 @@ def main():
     out = torch.empty(2 * n, device="cuda")
     t127, t191, h64 = S.taps_decim127(), S.taps_resamp191(), S.taps_audio_half64()
     rows = []
+    m = m0 = 1 << 24
 
-    def fir(name, desc, inp, width, K, unit_in):
+    def fir(name, desc, inp, width, K, unit_in, macs_per_out=None):
+        before = L.lib.sdrhip_debug_tiled_launches()
         t = timeit(lambda: desc.run(inp.data_ptr(), 0, out.data_ptr(), 0, K, 8192, stream=st))
-        rows.append((name, unit_in / t / 1e9))
+        tiled = L.lib.sdrhip_debug_tiled_launches() > before
+        if macs_per_out is None:
+            macs_per_out = desc.num_coeffs * width if not hasattr(desc, "in_offset") else None
+        rows.append((name + (" *" if tiled else ""), unit_in / t / 1e9, (K * macs_per_out / t / 1e12) if macs_per_out else None))
 
     for order, oname in ((L.ORDER_AVX, "AVX"), (L.ORDER_SSE, "SSE"), (L.ORDER_SCALAR, "scalar")):
         d = L.Decimator(8, t127, order, complex_=True)
         fir(f"decimate /8 128 taps complex [{oname}]", d, xc, 2, (n - 128) // 8 + 1, n)
     d = L.Decimator(8, t127, L.ORDER_AVX)
     fir("decimate /8 128 taps real [AVX]", d, xr, 1, (n - 128) // 8 + 1, n)
+    d = L.Decimator(8, t127, L.ORDER_SSE)
+    fir("decimate /8 128 taps real [SSE]", d, xr, 1, (n - 128) // 8 + 1, n)
+    d = L.Decimator(4, t127, L.ORDER_AVX)
+    fir("decimate /4 128 taps real [AVX]", d, xr, 1, (n - 128) // 4 + 1, n)
+    d = L.Decimator(2, h64, L.ORDER_AVX, sym=True)
+    fir("decimate /2 64 half-taps symmetric real [AVX]", d, xr, 1, (n - 128) // 2 + 1, n, macs_per_out=64)
+    d = L.Decimator(4, t127, L.ORDER_AVX, complex_=True)
+    fir("decimate /4 128 taps complex [AVX]", d, xc, 2, (m0 - 128) // 4 + 1, m0)
+    d = L.Decimator(10, S.taps_decim51(), L.ORDER_AVX, complex_=True)
+    fir("decimate /10 52 taps complex [AVX]", d, xc, 2, (n - 52) // 10 + 1, n)
     f = L.Filter(t127, L.ORDER_AVX, complex_=True)
-    m = 1 << 24
     fir("filter 128 taps complex [AVX]", f, xc, 2, m - 127, m)
     f = L.Filter(t127, L.ORDER_AVX)
     fir("filter 128 taps real [AVX]", f, xr, 1, m - 127, m)
@@ -52,17 +66,24 @@ def main():
     fir("filter 64 half-taps symmetric real [SSE]", f, xr, 1, m - 127, m)
     r = L.Resampler(3, 10, t191, L.ORDER_AVX)
     fir("resample 3/10 191 taps real [AVX]", r, xr, 1, (n * 3 - 192) // 10 + 1, n)
+    r = L.Resampler(3, 10, t191, L.ORDER_SSE)
+    fir("resample 3/10 191 taps real [SSE]", r, xr, 1, (n * 3 - 192) // 10 + 1, n, macs_per_out=64)
     r = L.Resampler(3, 10, t191, L.ORDER_AVX, complex_=True)
-    fir("resample 3/10 191 taps complex [AVX]", r, xc, 2, (m * 3 - 192) // 10 + 1, m)
+    fir("resample 3/10 191 taps complex [AVX]", r, xc, 2, (m * 3 - 192) // 10 + 1, m, macs_per_out=128)
     r = L.Resampler(5, 7, t191, L.ORDER_AVX)
-    fir("resample 5/7 191 taps real [AVX]", r, xr, 1, (m * 5 - 200) // 7 + 1, m)
+    fir("resample 5/7 191 taps real [AVX]", r, xr, 1, (m * 5 - 200) // 7 + 1, m, macs_per_out=40)
+    r = L.Resampler(2, 3, t191, L.ORDER_AVX)
+    fir("resample 2/3 191 taps real [AVX]", r, xr, 1, (m * 2 - 192) // 3 + 1, m, macs_per_out=96)
+    r = L.Resampler(1, 4, t127, L.ORDER_AVX)
+    fir("resample 1/4 127 taps real [AVX]", r, xr, 1, (m - 128) // 4 + 1, m, macs_per_out=128)
     t = timeit(lambda: L.check(L.lib.sdrhip_fm_demod_run(st, xc.data_ptr(), 0, out.data_ptr(), 0, n, 0.0, 0.0)))
-    rows.append(("fmDemod", n / t / 1e9))
+    rows.append(("fmDemod", n / t / 1e9, None))
     u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda")
     t = timeit(lambda: L.check(L.lib.sdrhip_convert_u8_run(st, u8.data_ptr(), out.data_ptr(), 2 * n)))
-    rows.append(("convert u8 -> cfloat (standalone)", n / t / 1e9))
-    for name, g in rows:
-        print(f"{name:48s} {g:9.1f} G input elements/s")
+    rows.append(("convert u8 -> cfloat (standalone)", n / t / 1e9, None))
+    print("(* = served by the general LDS-tiled kernel, kernels_split.hip; T MAC/s = unfused multiply-add pairs, peak ~36-39)")
+    for name, g, macs in rows:
+        print(f"{name:52s} {g:9.1f} G input elements/s" + (f"  {macs:6.2f} T MAC/s" if macs else ""))
 
 
 if __name__ == "__main__":
