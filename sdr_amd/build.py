@@ -79,7 +79,28 @@ def build(force=False, save_temps=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    build_examples()
     return LIB
+
+
+EXAMPLES = os.path.join(os.path.dirname(HERE), "examples")
+
+
+def build_examples():
+    """Plain-C programs over the C ABI (gcc, no HIP headers): examples/bin/<name>."""
+    bindir = os.path.join(EXAMPLES, "bin")
+    os.makedirs(bindir, exist_ok=True)
+    for f in sorted(os.listdir(EXAMPLES)):
+        if not f.endswith(".c"):
+            continue
+        src, exe = os.path.join(EXAMPLES, f), os.path.join(bindir, f[:-2])
+        if not _stale(exe, [src, LIB, os.path.join(INCLUDE, "sdr_hip.h")]):
+            continue
+        cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-O2", f"-I{INCLUDE}", src, "-o", exe, f"-L{LIBDIR}", "-lsdr_hip",
+               "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,$ORIGIN/../../sdr_amd/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"gcc failed on {src}:\n{r.stdout}\n{r.stderr}")
 
 
 if __name__ == "__main__":
