@@ -256,6 +256,10 @@ void sdrhip_fm_chain_destroy(sdrhip_fm_chain *c);
  * past it do not exist), or -1 for unbounded. */
 int sdrhip_fm_chain_plan(const sdrhip_fm_chain *c, int64_t s0, int64_t s1, int64_t total_in,
                          int64_t *q0, int64_t *q1, int64_t *halo);
+/* Number of audio outputs whose whole receptive field lies inside the first n_samples samples of the
+ * stream, i.e. outputs [0, ready) can be computed from them.  A shard [s0,s1) can compute its outputs
+ * [q0, min(q1, ready(s1))) before its halo has arrived. */
+int64_t sdrhip_fm_chain_ready(const sdrhip_fm_chain *c, int64_t n_samples);
 int64_t sdrhip_fm_chain_max_halo(const sdrhip_fm_chain *c);
 size_t sdrhip_fm_chain_workspace_bytes(const sdrhip_fm_chain *c, int64_t n_in);
 /* d_in_iq[0] is stream sample s0; n_in samples (shard + halo) are readable.

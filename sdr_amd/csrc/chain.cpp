@@ -166,6 +166,19 @@ int sdrhip_fm_chain_plan(const sdrhip_fm_chain* c, int64_t s0, int64_t s1, int64
     return SDRHIP_OK;
 }
 
+int64_t sdrhip_fm_chain_ready(const sdrhip_fm_chain* c, int64_t n_samples)
+{
+    if (!c || n_samples < 0) return -1;
+    if (c->end(0) > n_samples) return 0;
+    int64_t lo = 0, hi = 1;                        // invariant: end(lo) <= n_samples < end(hi); end() is non-decreasing
+    while (c->end(hi) <= n_samples) { lo = hi; hi *= 2; }
+    while (lo + 1 < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (c->end(mid) <= n_samples) lo = mid; else hi = mid;
+    }
+    return hi;
+}
+
 int64_t sdrhip_fm_chain_max_halo(const sdrhip_fm_chain* c)
 {
     if (!c) return -1;
@@ -462,18 +475,10 @@ int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
         memcpy(sl.hin.p, iq, (size_t)n * 2);
     }
 
-    // outputs whose receptive field is complete once this block is in (end() is non-decreasing in q)
+    // outputs whose receptive field is complete once this block is in
     const int64_t N1 = st->N + n;
-    int64_t lo = st->q_done, hi = st->q_done;
-    if (c->end(lo) <= N1) {
-        hi = lo + 1;
-        while (c->end(hi) <= N1) hi = lo + 2 * (hi - lo);
-        while (lo + 1 < hi) {                      // invariant: end(lo) <= N1 < end(hi)
-            const int64_t mid = lo + (hi - lo) / 2;
-            if (c->end(mid) <= N1) lo = mid; else hi = mid;
-        }
-        hi = lo + 1;                                // q_new (exclusive)
-    }
+    int64_t hi = sdrhip_fm_chain_ready(c, N1);
+    if (hi < st->q_done) hi = st->q_done;
     const int64_t q_new = hi;
     // device input = [carried tail | new block]; the tail starts at the first sample the next pending output
     // needs, rounded down to a multiple of 8 samples (16-byte aligned tiles for the LDS-tiled decimator)

@@ -87,6 +87,8 @@ lib.sdrhip_fm_chain_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, _f32p, 
 lib.sdrhip_fm_chain_destroy.argtypes = [_vp]
 lib.sdrhip_fm_chain_destroy.restype = None
 lib.sdrhip_fm_chain_plan.argtypes = [_vp, _i64, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]
+lib.sdrhip_fm_chain_ready.argtypes = [_vp, _i64]
+lib.sdrhip_fm_chain_ready.restype = _i64
 lib.sdrhip_fm_chain_max_halo.argtypes = [_vp]
 lib.sdrhip_fm_chain_max_halo.restype = _i64
 lib.sdrhip_fm_chain_workspace_bytes.argtypes = [_vp, _i64]
@@ -344,6 +346,10 @@ class FmChain(_Handle):
         q0, q1, halo = _i64(), _i64(), _i64()
         check(lib.sdrhip_fm_chain_plan(self.h, s0, s1, total_in, C.byref(q0), C.byref(q1), C.byref(halo)), "sdrhip_fm_chain_plan")
         return q0.value, q1.value, halo.value
+
+    def ready(self, n_samples):
+        """Audio outputs computable from the first n_samples samples of the stream."""
+        return int(lib.sdrhip_fm_chain_ready(self.h, n_samples))
 
     def max_halo(self):
         return lib.sdrhip_fm_chain_max_halo(self.h)

@@ -33,8 +33,21 @@ class ShardPlan:
         self.halo_cap = (cap + 7) // 8 * 8          # same on every rank: fixed-size messages
         self.n_in = shard_len + self.halo_cap        # samples resident per rank (shard + halo)
         self.k2_samples = shard_len + self.halo      # input samples the decimate kernel actually consumes
+        # outputs [q0, q_mid) lie entirely inside the rank's own samples: they can be computed while the
+        # halo is still in flight; only [q_mid, q1) wait for it
+        self.q_mid = max(self.q0, min(self.q1, chain.ready(self.s1)))
         self.left = (rank - 1) % world
         self.right = (rank + 1) % world
+
+
+def halo_exchange_start(buf_u8, plan, dist):
+    """Device-memory variant, asynchronous: returns the requests; `for r in reqs: r.wait()` makes the CURRENT
+    stream wait for the received halo (RCCL runs the transfer on its own stream)."""
+    nb = 2 * plan.halo_cap
+    head = buf_u8[:nb]
+    tail = buf_u8[2 * plan.shard_len: 2 * plan.shard_len + nb]
+    ops = [dist.P2POp(dist.isend, head, plan.left), dist.P2POp(dist.irecv, tail, plan.right)]
+    return dist.batch_isend_irecv(ops)
 
 
 def halo_exchange(buf_u8, plan, dist, via_host=False):

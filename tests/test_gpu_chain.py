@@ -159,3 +159,34 @@ def test_fm_stream_long_run_equals_chain(hip, oracle):
     got = np.concatenate(got)
     assert got.size == q1 // B * B
     assert_bit_equal(got, full[: got.size], "streamed vs resident")
+
+
+def test_chain_split_at_ready(hip, oracle):
+    """Overlapping the halo exchange: a shard's outputs [q0, ready(s1)) need only its own samples (computed here from a
+    buffer whose halo region is still garbage), the rest run once the halo is in; together they equal the unsplit run."""
+    nblk = 48
+    total = nblk * B
+    u8 = S.iq_u8(total)
+    chain = _chain(hip)
+    S_len = total // 3 // 8 * 8
+    halo_cap = (chain.max_halo() + 7) // 8 * 8
+    for r in range(2):
+        s0, s1 = r * S_len, (r + 1) * S_len
+        q0, q1, halo = chain.plan(s0, s1, -1)
+        q_mid = max(q0, min(q1, chain.ready(s1)))
+        assert q0 < q_mid < q1 and q1 - q_mid < 400
+        assert chain.plan(s0, s1, -1)[2] > 0 and chain.plan(s0, s1 - 0, -1)[0] == q0
+        n_in = S_len + halo_cap
+        ref = _run(hip, chain, to_dev(u8[2 * s0: 2 * (s0 + n_in)]), s0, n_in, q0, q1)
+        poisoned = u8[2 * s0: 2 * (s0 + n_in)].copy()
+        poisoned[2 * S_len:] = 255                                  # the halo has not arrived yet
+        part_a = _run(hip, chain, to_dev(poisoned), s0, n_in, q0, q_mid)
+        part_b = _run(hip, chain, to_dev(u8[2 * s0: 2 * (s0 + n_in)]), s0, n_in, q_mid, q1)
+        assert_bit_equal(np.concatenate([part_a, part_b]), ref, f"shard {r}")
+    # ready() is the inverse of the receptive-field end
+    for n in (0, 100, 5000, 8192, 123456):
+        k = chain.ready(n)
+        if k > 0:
+            assert chain.plan(0, n, -1)[1] >= 0
+        q0, q1, h = chain.plan(0, max(n, 1), -1)
+        assert k <= q1
