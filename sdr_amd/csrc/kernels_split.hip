@@ -30,6 +30,9 @@
 #ifndef SPLIT_SPAN_BYTES
 #define SPLIT_SPAN_BYTES 32768
 #endif
+#ifndef SPLIT_U
+#define SPLIT_U 2
+#endif
 #ifndef SPLIT_PIPE
 #define SPLIT_PIPE 1
 #endif
@@ -252,7 +255,7 @@ bool split_enabled()
 }
 
 // Tile geometry: as many cycles as fit a 32 KiB input span (64 KiB when a large decimation factor needs it) and 1024
-// outputs, in whole runs of U groups of G = 64/M outputs (U = 4 independent accumulator chains per lane when the tile is
+// outputs, in whole runs of U groups of G = 64/M outputs (U = 2 independent accumulator chains per lane -- 4 and 8 measured no better -- when the tile is
 // big enough, else 1).
 bool plan_tile(SplitArgs& a, int M, bool cplx, int& U)
 {
@@ -264,7 +267,7 @@ bool plan_tile(SplitArgs& a, int M, bool cplx, int& U)
         if (room < 0) continue;
         int64_t NN = room / a.period + 1;
         if (NN > 1024 / a.NC) NN = 1024 / a.NC;
-        if (NN >= 16 * G) { U = 4; NN = NN / (4 * G) * (4 * G); }
+        if (NN >= 4 * SPLIT_U * G) { U = SPLIT_U; NN = NN / (SPLIT_U * G) * (SPLIT_U * G); }
         else if (bytes == 65536 && NN >= G) { U = 1; NN = NN / G * G; }
         else continue;
         a.NN = (int)NN;
@@ -295,7 +298,7 @@ void launch_variant_u(hipStream_t s, const SplitArgs& a)
     const size_t lds_bytes = ((size_t)((a.span + 7) & ~3) + (size_t)a.NN * a.NC) * esz;
     // Real data, exact tap-chunk counts of the usual filter lengths: guard-free code (measured +20 % on the 128-tap real
     // decimator; on complex data the scheduler hoists more reads than there are registers for and it is 2x slower).
-    constexpr bool EX = U == 4 && !CPLX;
+    constexpr bool EX = U == SPLIT_U && !CPLX;
     if (EX && a.nch == 8) launch_kernel<CPLX, M, ORD, SYM, 8, U, EX>(s, a, grid, lds_bytes);
     else if (EX && a.nch == 16) launch_kernel<CPLX, M, ORD, SYM, 16, U, EX>(s, a, grid, lds_bytes);
     else if (EX && a.nch == 32) launch_kernel<CPLX, M, ORD, SYM, 32, U, EX>(s, a, grid, lds_bytes);
@@ -308,7 +311,7 @@ void launch_variant_u(hipStream_t s, const SplitArgs& a)
 template <bool CPLX, int M, int ORD, bool SYM>
 void launch_variant(hipStream_t s, const SplitArgs& a, int U)
 {
-    if (U == 4) launch_variant_u<CPLX, M, ORD, SYM, 4>(s, a);
+    if (U == SPLIT_U) launch_variant_u<CPLX, M, ORD, SYM, SPLIT_U>(s, a);
     else launch_variant_u<CPLX, M, ORD, SYM, 1>(s, a);
 }
 
