@@ -294,9 +294,16 @@ void sdrhip_fm_stream_destroy(sdrhip_fm_stream *st);
 int sdrhip_fm_stream_push(sdrhip_fm_stream *st, const uint8_t *iq, int n_samples);
 /* Zero-copy variant: the pinned staging buffer (2*max_block_samples bytes) the NEXT push will upload
  * from.  Let the source (e.g. the RTL-SDR read of SDR/RTLSDRStream.hs) write into it, then push that
- * same pointer: the host-side memcpy is skipped.  Valid until that push; NULL on error. */
+ * same pointer: the host-side memcpy is skipped.  Valid until that push; NULL on error.  (With
+ * coalescing it points just past the samples already staged.) */
 uint8_t *sdrhip_fm_stream_input_buffer(sdrhip_fm_stream *st);
 int sdrhip_fm_stream_flush(sdrhip_fm_stream *st);
+/* Latency / throughput knob: stage pushes in the pinned buffer and submit them to the GPU together once
+ * `samples` samples (a multiple of the chain's block; 0 = every push, the default) have accumulated, or on
+ * flush.  One 8192-sample push costs ~80 us of launches whatever its size, so a caller that must keep the
+ * reference's block size (fm.hs:17) gets ~16x the throughput from coalesce = 16 blocks, at 16 blocks of
+ * latency; the audio blocks are the same.  Call with nothing staged. */
+int sdrhip_fm_stream_set_coalesce(sdrhip_fm_stream *st, int samples);
 int sdrhip_fm_stream_pop(sdrhip_fm_stream *st, float *out, int capacity);
 
 /* ------------------------------------------------------------------------ */

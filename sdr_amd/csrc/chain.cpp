@@ -389,7 +389,10 @@ struct sdrhip_fm_stream {
         int64_t n_out = 0;
         bool busy = false;
     } slot[2];
-    int64_t pushes = 0;
+    int64_t pushes = 0;        // submissions so far (slot = pushes & 1)
+    int staged = 0;            // samples copied into the current slot's staging buffer, not yet submitted
+    int coalesce = 0;          // submit once this many samples are staged (0: every push)
+    int capacity() const { return coalesce > max_block ? coalesce : max_block; }
     std::vector<float> fifo;
     size_t head = 0;
 
@@ -450,37 +453,23 @@ int sdrhip_fm_stream_create(sdrhip_fm_stream** out, sdrhip_fm_chain* chain, int 
 
 void sdrhip_fm_stream_destroy(sdrhip_fm_stream* st) { delete st; }
 
-uint8_t* sdrhip_fm_stream_input_buffer(sdrhip_fm_stream* st)
-{
-    if (st == nullptr) { set_error("sdrhip_fm_stream_input_buffer: null stream"); return nullptr; }
-    sdrhip_fm_stream::Slot& sl = st->slot[st->pushes & 1];
-    if (hipEventSynchronize(sl.ev_up) != hipSuccess) { set_error("sdrhip_fm_stream_input_buffer: upload event"); return nullptr; }
-    if (sl.hin.ensure((size_t)st->max_block * 2) != SDRHIP_OK) return nullptr;
-    return (uint8_t*)sl.hin.p;
-}
+}  // extern "C"
 
-int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
+
+// Submit everything staged in the current slot: carried tail + staged samples -> device, chain, audio -> host.
+static int stream_submit(sdrhip_fm_stream* st)
 {
-    SDRHIP_REQUIRE(st != nullptr && iq != nullptr && n > 0 && n <= st->max_block, "sdrhip_fm_stream_push");
     sdrhip_fm_chain* c = st->c;
-    SDRHIP_REQUIRE(c->block == 0 || n % c->block == 0,
-                   "sdrhip_fm_stream_push: the chain reproduces the seams of `block`-sample source buffers (fm.hs:17,24)");
+    const int n = st->staged;
+    if (n == 0) return SDRHIP_OK;
     const int si = (int)(st->pushes & 1);
     sdrhip_fm_stream::Slot& sl = st->slot[si];
     int rc;
-    if ((rc = st->harvest(si)) != SDRHIP_OK) return rc;
-    SDRHIP_CHECK_HIP(hipEventSynchronize(sl.ev_up));   // the slot's previous upload has left the staging buffer
-    if (iq != (const uint8_t*)sl.hin.p || sl.hin.p == nullptr) {   // else: the caller filled our staging buffer in place
-        if ((rc = sl.hin.ensure((size_t)st->max_block * 2)) != SDRHIP_OK) return rc;
-        memcpy(sl.hin.p, iq, (size_t)n * 2);
-    }
-
-    // outputs whose receptive field is complete once this block is in
+    // outputs whose receptive field is complete once these samples are in
     const int64_t N1 = st->N + n;
-    int64_t hi = sdrhip_fm_chain_ready(c, N1);
-    if (hi < st->q_done) hi = st->q_done;
-    const int64_t q_new = hi;
-    // device input = [carried tail | new block]; the tail starts at the first sample the next pending output
+    int64_t q_new = sdrhip_fm_chain_ready(c, N1);
+    if (q_new < st->q_done) q_new = st->q_done;
+    // device input = [carried tail | new samples]; the tail starts at the first sample the next pending output
     // needs, rounded down to a multiple of 8 samples (16-byte aligned tiles for the LDS-tiled decimator)
     int64_t keep_from = c->start(st->q_done) & ~(int64_t)7;
     if (keep_from > st->N) keep_from = st->N & ~(int64_t)7;
@@ -494,7 +483,7 @@ int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
         SDRHIP_CHECK_HIP(hipMemcpyAsync(next.p, (const char*)prev.p + (size_t)(keep_from - st->base) * 2, (size_t)tail * 2,
                                         hipMemcpyDeviceToDevice, st->compute));
     // everything queued so far that reads `prev` (earlier chain runs, this tail copy) precedes this event;
-    // the NEXT push uploads into `prev` and waits for it
+    // the NEXT submission uploads into `prev` and waits for it
     SDRHIP_CHECK_HIP(hipEventRecord(st->ev_tail, st->compute));
     st->tail_pending = true;
     SDRHIP_CHECK_HIP(hipMemcpyAsync((char*)next.p + (size_t)tail * 2, sl.hin.p, (size_t)n * 2, hipMemcpyHostToDevice, st->up));
@@ -522,7 +511,53 @@ int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
     st->q_done = q_new;
     st->N = N1;
     st->pushes++;
-    if ((rc = st->harvest(si ^ 1)) != SDRHIP_OK) return rc;
+    st->staged = 0;
+    return st->harvest(si ^ 1);
+}
+
+// make the current slot's staging buffer writable (its previous upload and download are over)
+static int stream_open_slot(sdrhip_fm_stream* st)
+{
+    sdrhip_fm_stream::Slot& sl = st->slot[st->pushes & 1];
+    int rc;
+    if (st->staged == 0) {
+        if ((rc = st->harvest((int)(st->pushes & 1))) != SDRHIP_OK) return rc;
+        SDRHIP_CHECK_HIP(hipEventSynchronize(sl.ev_up));
+    }
+    return sl.hin.ensure((size_t)st->capacity() * 2);
+}
+
+extern "C" {
+
+int sdrhip_fm_stream_set_coalesce(sdrhip_fm_stream* st, int samples)
+{
+    SDRHIP_REQUIRE(st != nullptr && samples >= 0, "sdrhip_fm_stream_set_coalesce");
+    SDRHIP_REQUIRE(st->staged == 0, "sdrhip_fm_stream_set_coalesce: samples are staged (flush first)");
+    SDRHIP_REQUIRE(st->c->block == 0 || samples % st->c->block == 0, "sdrhip_fm_stream_set_coalesce: whole source blocks only");
+    for (hipStream_t s : {st->up, st->compute, st->down}) SDRHIP_CHECK_HIP(hipStreamSynchronize(s));   // staging buffers may be reallocated
+    st->coalesce = samples;
+    return SDRHIP_OK;
+}
+
+uint8_t* sdrhip_fm_stream_input_buffer(sdrhip_fm_stream* st)
+{
+    if (st == nullptr) { set_error("sdrhip_fm_stream_input_buffer: null stream"); return nullptr; }
+    if (stream_open_slot(st) != SDRHIP_OK) return nullptr;
+    return (uint8_t*)st->slot[st->pushes & 1].hin.p + (size_t)st->staged * 2;
+}
+
+int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
+{
+    SDRHIP_REQUIRE(st != nullptr && iq != nullptr && n > 0 && n <= st->max_block, "sdrhip_fm_stream_push");
+    SDRHIP_REQUIRE(st->c->block == 0 || n % st->c->block == 0,
+                   "sdrhip_fm_stream_push: the chain reproduces the seams of `block`-sample source buffers (fm.hs:17,24)");
+    int rc;
+    if (st->staged + n > st->capacity() && (rc = stream_submit(st)) != SDRHIP_OK) return rc;
+    if ((rc = stream_open_slot(st)) != SDRHIP_OK) return rc;
+    uint8_t* dst = (uint8_t*)st->slot[st->pushes & 1].hin.p + (size_t)st->staged * 2;
+    if (iq != dst) memcpy(dst, iq, (size_t)n * 2);   // else: the caller filled our staging buffer in place
+    st->staged += n;
+    if (st->staged >= st->coalesce && (rc = stream_submit(st)) != SDRHIP_OK) return rc;
     return st->ready();
 }
 
@@ -530,6 +565,7 @@ int sdrhip_fm_stream_flush(sdrhip_fm_stream* st)
 {
     SDRHIP_REQUIRE(st != nullptr, "sdrhip_fm_stream_flush");
     int rc;
+    if ((rc = stream_submit(st)) != SDRHIP_OK) return rc;
     const int first = (int)(st->pushes & 1);
     if ((rc = st->harvest(first)) != SDRHIP_OK) return rc;
     if ((rc = st->harvest(first ^ 1)) != SDRHIP_OK) return rc;

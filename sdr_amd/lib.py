@@ -110,6 +110,7 @@ lib.sdrhip_fm_stream_destroy.argtypes = [_vp]
 lib.sdrhip_fm_stream_destroy.restype = None
 lib.sdrhip_fm_stream_push.argtypes = [_vp, _u8p, C.c_int]
 lib.sdrhip_fm_stream_flush.argtypes = [_vp]
+lib.sdrhip_fm_stream_set_coalesce.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_stream_input_buffer.argtypes = [_vp]
 lib.sdrhip_fm_stream_input_buffer.restype = _vp
 lib.sdrhip_fm_stream_pop.argtypes = [_vp, _f32p, C.c_int]
@@ -386,6 +387,9 @@ class FmStream(_Handle):
         self.chain = chain  # keep alive
         self.block_size_out = block_size_out
         check(lib.sdrhip_fm_stream_create(C.byref(self.h), chain.h, max_block_samples, block_size_out), "sdrhip_fm_stream_create")
+
+    def set_coalesce(self, samples):
+        check(lib.sdrhip_fm_stream_set_coalesce(self.h, samples), "sdrhip_fm_stream_set_coalesce")
 
     def _pop(self, ready):
         outs = []

@@ -190,3 +190,29 @@ def test_chain_split_at_ready(hip, oracle):
             assert chain.plan(0, n, -1)[1] >= 0
         q0, q1, h = chain.plan(0, max(n, 1), -1)
         assert k <= q1
+
+
+@pytest.mark.parametrize("coalesce_blocks", [4, 16])
+def test_fm_stream_coalesce(hip, oracle, coalesce_blocks):
+    """Coalescing 8192-sample pushes inside the operator changes when the audio appears, not what it is."""
+    nblk = 100
+    u8 = S.iq_u8_fm(nblk * B)
+    exp = _model(oracle, u8, nblk)
+    chain = _chain(hip)
+    st = hip.FmStream(chain, B, B)
+    st.set_coalesce(coalesce_blocks * B)
+    got = []
+    for i in range(nblk):
+        if i % 3 == 0:
+            view = st.input_buffer(B)
+            view[:] = u8[2 * i * B: 2 * (i + 1) * B]
+            got += st.push_inplace(view)
+        else:
+            got += st.push(u8[2 * i * B: 2 * (i + 1) * B])
+    got += st.flush()
+    got = np.concatenate(got)
+    assert got.size >= exp.size
+    assert_bit_equal(got[: exp.size], exp, "coalesced stream")
+    with pytest.raises(hip.SdrHipError):
+        st.push(u8[: 2 * B])
+        st.set_coalesce(2 * B)                     # samples staged: refuse

@@ -67,6 +67,21 @@ def fm_stream(blocks_per_push, pushes):
           f"({dt / pushes * 1e6:.0f} us/push); zero-copy input {pushes * blocks_per_push * B / dz / 1e6:10.1f} Msamples/s")
 
 
+def fm_stream_coalesced(coalesce_blocks, pushes=4000):
+    chain = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, B)
+    st = L.FmStream(chain, B, B)
+    st.set_coalesce(coalesce_blocks * B)
+    for _ in range(4 * coalesce_blocks):
+        st.push_inplace(st.input_buffer(B))
+    t0 = time.perf_counter()
+    for _ in range(pushes):
+        st.push_inplace(st.input_buffer(B))
+    st.flush()
+    dt = time.perf_counter() - t0
+    print(f"sdrhip_fm_stream, 8192-sample pushes coalesced x{coalesce_blocks:3d}: {pushes * B / dt / 1e6:10.1f} Msamples/s "
+          f"({dt / pushes * 1e6:.1f} us/push incl. the ctypes call)")
+
+
 def pipe_blocks(nblocks=512):
     dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
     pipe = L.firDecimator(dec, B)
@@ -111,5 +126,7 @@ if __name__ == "__main__":
     chain_streamed()
     for bpp, pushes in ((1, 2000), (16, 1000), (256, 200), (4096, 24)):
         fm_stream(bpp, pushes)
+    for cb in (4, 16, 64):
+        fm_stream_coalesced(cb)
     pipe_blocks()
     resampler_pipe_cfg4()
