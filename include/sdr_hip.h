@@ -35,7 +35,12 @@
  *            virtual window lies inside one input block, and
  *    "Cross" (computed by the pure-Haskell sequential kernel,
  *            FilterInternal.hs:397-423) when it straddles a multiple of B*I
- * -- exactly the split Filter.hs:536-727 makes.  seam_block = 0 means one
+ * -- exactly the split Filter.hs:536-727 makes, including its one irregular
+ * case: when the first output that no longer fits a block already has its
+ * first INPUT sample ceil(m*D/I) in the next block (only possible for I > 1
+ * with filters shorter than the decimation step), the Pipe does not cross
+ * over at that boundary (Filter.hs:707-709) and that output is the next
+ * block's first "One".  seam_block = 0 means one
  * contiguous buffer: every output is "One" (what a single FFI call computes).
  *
  * Errors: drop-in symbols cannot report (void returns): on a HIP failure they

@@ -226,6 +226,11 @@ int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in
     SDRHIP_REQUIRE(k_end >= k_begin && k_end - k_begin < (int64_t)0x7fffffff, "resamp_run");
     SDRHIP_REQUIRE(k_begin >= 0, "resamp_run");
     SDRHIP_REQUIRE(seam_block <= 0 || seam_block * r->I >= r->Lp, "resamp_run: seam block shorter than the filter (Filter.hs:691)");
+    // With a padded filter shorter than the decimation step the reference's Pipe drops more inputs than a buffer holds
+    // (`VG.drop usedInput bufIn`, Filter.hs:702-703) and silently loses its place in the stream at every buffer
+    // boundary: there is no stream result to reproduce, so blocked streams refuse the configuration.
+    SDRHIP_REQUIRE(seam_block <= 0 || r->Lp >= r->D, "resamp_run: padded filter shorter than the decimation step: the reference Pipe "
+                                                      "mis-steps at buffer boundaries (Filter.hs:702-709); use seam_block = 0");
     if (k_end == k_begin) return SDRHIP_OK;
     SDRHIP_REQUIRE(d_in != nullptr && d_out != nullptr, "resamp_run");
     {

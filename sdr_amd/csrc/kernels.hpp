@@ -28,6 +28,20 @@ struct Geom {
     int64_t seamBI;    // seam_block * I; 0 = contiguous (all One); < 0 = every output Cross
 };
 
+// Does the reference's Pipe enter its crossover (sequential) code at the buffer boundary `edge` (upsampled units, a
+// multiple of seamBI)?  m* = the first output whose window no longer fits the buffer ending at `edge`; the Pipe crosses
+// over iff m*'s first input sample, ceil(m* D / I), still lies in that buffer -- and then computes EVERY output whose
+// virtual start m D is before the edge sequentially (firResampler: `outputsComputable`, Filter.hs:712-716).  Otherwise
+// (`VG.length bufIn' == 0 -> simple next`, Filter.hs:707-709; only possible when I > 1) m* is simply the first SIMD
+// output of the next buffer and the seam has no sequential outputs at all.  For I == 1 both tests coincide.
+__host__ __device__ inline bool seam_has_crossover(int64_t edge, int I, int D, int Lp)
+{
+    if (I == 1) return true;
+    const int64_t m_star = edge >= Lp ? (edge - Lp) / D + 1 : 0;
+    const int64_t first_in = (m_star * D + I - 1) / I;
+    return first_in * I < edge;
+}
+
 // Real data ------------------------------------------------------------------
 // taps: `ntaps` floats (multiple of lanes).  sym: taps are the HALF filter.
 // cross_taps: Lp floats used by the sequential "Cross" outputs (may be null when seamBI == 0).

@@ -176,6 +176,8 @@ int sdrhip_pipe_fir_decimator(sdrhip_pipe** pp, const sdrhip_decimator* d, int b
 int sdrhip_pipe_fir_resampler(sdrhip_pipe** pp, const sdrhip_resampler* r, int block_size_out)
 {
     SDRHIP_REQUIRE(pp && r && block_size_out > 0, "sdrhip_pipe_fir_resampler");
+    SDRHIP_REQUIRE(r->Lp >= r->D, "sdrhip_pipe_fir_resampler: padded filter shorter than the decimation step: the reference Pipe "
+                                  "mis-steps at buffer boundaries (Filter.hs:702-709)");
     int rc = pipe_new(pp, PK_RESAMPLER);
     if (rc != SDRHIP_OK) return rc;
     sdrhip_pipe* p = *pp;
@@ -266,6 +268,9 @@ int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
     // that is not yet done straddles that boundary (Cross)
     int64_t m_split = ceil_div64(E_prev * p->I, p->D);
     if (m_split < p->m_done) m_split = p->m_done;
+    // ... unless the Pipe does not cross over at this boundary at all: the first pending output already has its first
+    // input in the new block (`VG.length bufIn' == 0 -> simple next`, Filter.hs:707-709; resamplers only)
+    if (E_prev > 0 && !seam_has_crossover(E_prev * p->I, p->I, p->D, p->Lp)) m_split = p->m_done;
     // the reference's `assert "filter 1" / "decimate 1" / "resample 1"`: after the
     // crossover the rest of the new buffer must still hold one whole filter
     if (m_end <= m_split) {

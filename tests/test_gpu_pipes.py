@@ -133,3 +133,62 @@ def test_fm_receiver_as_composed_pipes(hip, oracle):
         for o in fl():
             feed(i + 1, o, stages)
     _cmp(audio, exp, "composed FM receiver")
+
+
+def test_resampler_pipe_random_sweep(hip, oracle):
+    """Seeded random resampler Pipes on ragged host blocks, short filters included: where the first output that no longer
+    fits a block already starts in the next one the reference Pipe does not cross over (Filter.hs:707-709)."""
+    rng = np.random.default_rng(77)
+    ran = 0
+    for trial in range(40):
+        complex_ = bool(rng.integers(0, 2))
+        order = [PM.ORDER_AVX, PM.ORDER_SSE, PM.ORDER_SCALAR][rng.integers(0, 3)]
+        w = 2 if complex_ else 1
+        while True:
+            I, D = int(rng.integers(1, 7)), int(rng.integers(2, 26))
+            if D > I and np.gcd(I, D) == 1:
+                break
+        simd = {PM.ORDER_AVX: 8, PM.ORDER_SSE: 4, PM.ORDER_SCALAR: 1}[order]
+        ntaps = int(rng.integers(I + 1, 30 * I))
+        if -(-ntaps // (I * simd)) * (I * simd) < D:
+            ntaps = D + int(rng.integers(0, 10))
+        taps = S.gauss_taps(ntaps, 500 + trial)
+        lp = -(-ntaps // (I * simd)) * (I * simd)
+        min_block = -(-lp // I) + D
+        sizes = [int(s) for s in rng.integers(min_block, min_block + 3000, size=12)]
+        x = S.cfloat_block(sum(sizes), seed=600 + trial) if complex_ else S.real_block(sum(sizes), seed=600 + trial)
+        blocks = _cut(x, w, sizes)
+        bso = int(rng.integers(50, 900))
+        try:
+            exp, _ = PM.fir_resampler_pipe(PM.ResamplerModel(oracle, I, D, taps, order, complex_), blocks, bso)
+        except PM.PipeAssert:
+            continue
+        r = hip.Resampler(I, D, taps, order, complex_)
+        _cmp(_drive(hip.firResampler(r, bso), blocks), exp,
+             f"trial {trial}: {I}/{D}, {ntaps} taps, order {order}, complex {complex_}, blocks {sizes[:4]}..")
+        ran += 1
+    assert ran >= 25
+
+
+def test_decimator_pipe_random_sweep(hip, oracle):
+    rng = np.random.default_rng(78)
+    ran = 0
+    for trial in range(30):
+        complex_ = bool(rng.integers(0, 2))
+        order = [PM.ORDER_AVX, PM.ORDER_SSE, PM.ORDER_SCALAR][rng.integers(0, 3)]
+        w = 2 if complex_ else 1
+        ntaps = int(rng.integers(2, 200))
+        factor = int(rng.integers(1, min(ntaps, 20) + 1))
+        taps = S.gauss_taps(ntaps, 700 + trial)
+        sizes = [int(s) for s in rng.integers(ntaps + 8 + factor, ntaps + 4000, size=10)]
+        x = S.cfloat_block(sum(sizes), seed=800 + trial) if complex_ else S.real_block(sum(sizes), seed=800 + trial)
+        blocks = _cut(x, w, sizes)
+        bso = int(rng.integers(50, 900))
+        try:
+            exp, _ = PM.fir_decimator_pipe(PM.FilterModel(oracle, taps, order, complex_=complex_, factor=factor), blocks, bso)
+        except PM.PipeAssert:
+            continue
+        d = hip.Decimator(factor, taps, order, complex_=complex_)
+        _cmp(_drive(hip.firDecimator(d, bso), blocks), exp, f"trial {trial}: /{factor}, {ntaps} taps, order {order}, complex {complex_}")
+        ran += 1
+    assert ran >= 20

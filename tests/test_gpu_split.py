@@ -128,3 +128,97 @@ def test_resampler_families(hip, oracle, order, complex_, I, D, ntaps):
     assert_bit_equal(got, exp, "one launch")
     got = _run(r, to_dev(x), w, K, B, cuts=[4099, 4099 + 4097, K - 5000])
     assert_bit_equal(got, exp, "cut into launches (every starting group)")
+
+
+@pytest.mark.parametrize("complex_", [False, True])
+@pytest.mark.parametrize("factor,ntaps", [(64, 128), (128, 256), (100, 192)])
+def test_large_factor_tiles(hip, oracle, complex_, factor, ntaps):
+    """Large decimation factors: few cycles fit a tile (the 64 KiB span / one-output-per-lane path), or none (fallback)."""
+    w = 2 if complex_ else 1
+    nblk = (4200 * factor + ntaps) // B + 2
+    x = S.cfloat_block(nblk * B, seed=31) if complex_ else S.real_block(nblk * B, seed=32)
+    taps = S.gauss_taps(ntaps, factor)
+    model = PM.FilterModel(oracle, taps, PM.ORDER_AVX, complex_=complex_, factor=factor)
+    blocks, _ = PM.fir_decimator_pipe(model, _split(x, w, B), 512)
+    exp = np.concatenate(blocks)
+    K = exp.size // w
+    assert K >= 4096
+    d = hip.Decimator(factor, taps, PM.ORDER_AVX, complex_=complex_)
+    got = _run(d, to_dev(x), w, K, B, cuts=[4099])
+    assert_bit_equal(got, exp, f"factor {factor}")
+
+
+def test_random_sweep(hip, oracle):
+    """Seeded random configurations: family, order, factor / ratio, tap count, launch cuts and seam block."""
+    rng = np.random.default_rng(20260928)
+    ran = 0
+    for trial in range(90):
+        complex_ = bool(rng.integers(0, 2))
+        order = [PM.ORDER_AVX, PM.ORDER_SSE][rng.integers(0, 2)]
+        w = 2 if complex_ else 1
+        seam = int(rng.choice([2048, 4096, 8192]))
+        kind = rng.integers(0, 3)
+        nblk = 160 * 8192 // seam // 4
+        x = S.cfloat_block(nblk * seam, seed=100 + trial) if complex_ else S.real_block(nblk * seam, seed=100 + trial)
+        try:
+            blocks, desc, label, w, x = _random_case(hip, oracle, rng, trial, kind, complex_, order, w, seam, nblk, x)
+        except PM.PipeAssert:
+            continue                                               # the reference's own Pipe rejects this shape (Filter.hs asserts)
+        if not blocks:
+            continue
+        exp = np.concatenate(blocks)
+        K = exp.size // w
+        cuts = sorted(int(c) for c in rng.integers(1, K, size=2)) if K > 3 else []
+        got = _run(desc, to_dev(x), w, K, seam, cuts=cuts)
+        assert_bit_equal(got, exp, label)
+        ran += 1
+    assert ran >= 60
+
+
+def _random_case(hip, oracle, rng, trial, kind, complex_, order, w, seam, nblk, x):
+    if True:
+        if kind == 0:                                              # decimator
+            factor = int(rng.integers(1, 24))
+            ntaps = int(rng.integers(3, min(300, seam // 2)))
+            taps = S.gauss_taps(ntaps, 7000 + trial)
+            model = PM.FilterModel(oracle, taps, order, complex_=complex_, factor=factor)
+            blocks, _ = PM.fir_decimator_pipe(model, _split(x, w, seam), 512)
+            desc = hip.Decimator(factor, taps, order, complex_=complex_)
+            label = f"trial {trial}: decimate /{factor}, {ntaps} taps, order {order}, complex {complex_}, seam {seam}"
+        elif kind == 1:                                            # symmetric real decimator / filter
+            complex_, w = False, 1
+            x = S.real_block(nblk * seam, seed=100 + trial)
+            factor = int(rng.integers(1, 9))
+            nhalf = 8 * int(rng.integers(1, 20))
+            half = S.gauss_taps(nhalf, 8000 + trial)
+            model = PM.FilterModel(oracle, half, order, sym=True, factor=factor)
+            blocks, _ = PM.fir_decimator_pipe(model, _split(x, 1, seam), 512)
+            desc = hip.Decimator(factor, half, order, sym=True) if factor > 1 else hip.Filter(half, order, sym=True)
+            label = f"trial {trial}: symmetric /{factor}, {nhalf} half taps, order {order}, seam {seam}"
+        else:                                                      # resampler, gcd(I, D) = 1
+            while True:
+                I, D = int(rng.integers(1, 9)), int(rng.integers(2, 30))
+                if D > I and np.gcd(I, D) == 1:
+                    break
+            ntaps = int(rng.integers(I + 1, 40 * I))
+            if -(-ntaps // (I * 4)) * (I * 4) < D:                 # padded filter shorter than the decimation step:
+                ntaps = D + int(rng.integers(0, 20 * I))           # the reference Pipe mis-steps there (see test below)
+            taps = S.gauss_taps(ntaps, 9000 + trial)
+            model = PM.ResamplerModel(oracle, I, D, taps, order, complex_)
+            blocks, _ = PM.fir_resampler_pipe(model, _split(x, w, seam), 512)
+            desc = hip.Resampler(I, D, taps, order, complex_)
+            label = f"trial {trial}: resample {I}/{D}, {ntaps} taps, order {order}, complex {complex_}, seam {seam}"
+    return blocks, desc, label, w, x
+
+
+def test_degenerate_resampler_is_refused(hip):
+    """Padded filter shorter than the decimation step: the reference's Pipe drops past the end of its buffer and loses its
+    place (Filter.hs:702-709), so there is no blocked-stream result to reproduce; a single buffer is still fine."""
+    r = hip.Resampler(1, 29, S.gauss_taps(16, 1), hip.ORDER_AVX)
+    x = to_dev(S.real_block(4 * B))
+    out = dev_empty_f32(1024)
+    r.run(ptr(x), 0, ptr(out), 0, 1000, 0)                          # contiguous: allowed
+    with pytest.raises(hip.SdrHipError):
+        r.run(ptr(x), 0, ptr(out), 0, 1000, B)
+    with pytest.raises(hip.SdrHipError):
+        hip.firResampler(r, 512)
