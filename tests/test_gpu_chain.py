@@ -216,3 +216,70 @@ def test_fm_stream_coalesce(hip, oracle, coalesce_blocks):
     with pytest.raises(hip.SdrHipError):
         st.push(u8[: 2 * B])
         st.set_coalesce(2 * B)                     # samples staged: refuse
+
+
+def test_chain_random_sweep(hip, oracle):
+    """Seeded random receivers (decimation, tap counts, resampling ratio, gain, source block size, SIMD order): the
+    device-resident chain in one launch, the same chain sharded in three, and the host-block stream operator all give the
+    audio of the restated reference pipeline."""
+    rng = np.random.default_rng(4242)
+    ran = 0
+    for trial in range(24):
+        order = [PM.ORDER_AVX, PM.ORDER_SSE][rng.integers(0, 2)]
+        simd = 8 if order == PM.ORDER_AVX else 4
+        block = int(rng.choice([2048, 4096, 8192]))
+        factor = int(rng.integers(2, 17))
+        n_decim = int(rng.integers(factor + 4, 200))
+        while True:
+            I, D = int(rng.integers(1, 6)), int(rng.integers(2, 16))
+            if D > I and np.gcd(I, D) == 1:
+                break
+        n_resamp = int(rng.integers(max(D, 2 * I), 40 * I + D))
+        n_half = simd * int(rng.integers(1, 12))
+        gain = float(np.float32(rng.uniform(0.05, 3.0)))
+        decim_taps, resamp_taps, half = S.gauss_taps(n_decim, 1000 + trial), S.gauss_taps(n_resamp, 2000 + trial), S.gauss_taps(n_half, 3000 + trial, 0.2)
+        # enough source blocks for a few audio blocks
+        per_audio = block * factor * D / I
+        nblk = int(3.3 * per_audio / block) + 4
+        if nblk * block > 6_000_000:
+            continue
+        u8 = S.iq_u8(nblk * block, seed=5000 + trial)
+        blocks = [u8[2 * i * block: 2 * (i + 1) * block] for i in range(nblk)]
+        try:
+            exp = PM.fm_receiver(oracle, blocks, decim_taps, factor, resamp_taps, I, D, half, gain, block, order)
+        except PM.PipeAssert:
+            continue
+        if not exp:
+            continue
+        exp = np.concatenate(exp)
+        label = f"trial {trial}: /{factor} {n_decim} taps, {I}/{D} {n_resamp} taps, {n_half} half taps, block {block}, order {order}"
+        chain = hip.FmChain(factor, decim_taps, I, D, resamp_taps, half, gain, block, order)
+        total = nblk * block
+        q0, q1, halo = chain.plan(0, total, total)
+        assert q0 == 0 and halo == 0 and q1 >= exp.size, label
+        d_u8 = to_dev(u8)
+        got = _run(hip, chain, d_u8, 0, total, 0, q1)
+        assert_bit_equal(got[: exp.size], exp, label + " (one launch)")
+        # three shards with right halos
+        S_len = total // 3 // 8 * 8
+        pieces = []
+        for r in range(3):
+            s0 = r * S_len
+            s1 = total if r == 2 else (r + 1) * S_len
+            a, b, h = chain.plan(s0, s1, total)
+            n_in = min(total, s1 + h) - s0
+            pieces.append(_run(hip, chain, to_dev(u8[2 * s0: 2 * (s0 + n_in)]), s0, n_in, a, b))
+        assert_bit_equal(np.concatenate(pieces), got, label + " (3 shards)")
+        # host-block stream operator, two source blocks per push
+        st = hip.FmStream(chain, 2 * block, block)
+        outs = []
+        for i in range(0, nblk - 1, 2):
+            outs += st.push(u8[2 * i * block: 2 * (i + 2) * block])
+        outs += st.flush()
+        outs = np.concatenate(outs) if outs else np.zeros(0, np.float32)
+        n = min(outs.size, exp.size)
+        assert n >= exp.size - block, label
+        assert_bit_equal(outs[:n], exp[:n], label + " (stream)")
+        ran += 1
+    print(f"chain sweep: {ran} random receivers compared")
+    assert ran >= 12
