@@ -300,7 +300,8 @@ int sdrhip_fm_stream_push(sdrhip_fm_stream *st, const uint8_t *iq, int n_samples
 /* Zero-copy variant: the pinned staging buffer (2*max_block_samples bytes) the NEXT push will upload
  * from.  Let the source (e.g. the RTL-SDR read of SDR/RTLSDRStream.hs) write into it, then push that
  * same pointer: the host-side memcpy is skipped.  Valid until that push; NULL on error.  (With
- * coalescing it points just past the samples already staged.) */
+ * coalescing it points just past the samples already staged; there is always room for
+ * max_block_samples more.) */
 uint8_t *sdrhip_fm_stream_input_buffer(sdrhip_fm_stream *st);
 int sdrhip_fm_stream_flush(sdrhip_fm_stream *st);
 /* Latency / throughput knob: stage pushes in the pinned buffer and submit them to the GPU together once

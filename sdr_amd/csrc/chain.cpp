@@ -542,6 +542,8 @@ int sdrhip_fm_stream_set_coalesce(sdrhip_fm_stream* st, int samples)
 uint8_t* sdrhip_fm_stream_input_buffer(sdrhip_fm_stream* st)
 {
     if (st == nullptr) { set_error("sdrhip_fm_stream_input_buffer: null stream"); return nullptr; }
+    // the caller may write up to max_block samples: make room for all of them behind what is already staged
+    if (st->staged + st->max_block > st->capacity() && stream_submit(st) != SDRHIP_OK) return nullptr;
     if (stream_open_slot(st) != SDRHIP_OK) return nullptr;
     return (uint8_t*)st->slot[st->pushes & 1].hin.p + (size_t)st->staged * 2;
 }

@@ -283,3 +283,26 @@ def test_chain_random_sweep(hip, oracle):
         ran += 1
     print(f"chain sweep: {ran} random receivers compared")
     assert ran >= 12
+
+
+def test_fm_stream_coalesce_ragged_inplace(hip, oracle):
+    """Zero-copy pushes of 1-3 source blocks with a coalescing target that is not a multiple of any of them: the staging
+    buffer always has room for a whole push behind what is already staged."""
+    nblk = 120
+    u8 = S.iq_u8(nblk * B)
+    exp = _model(oracle, u8, nblk)
+    chain = _chain(hip)
+    st = hip.FmStream(chain, 3 * B, B)
+    st.set_coalesce(7 * B)
+    got, i, k = [], 0, 0
+    while i < nblk:
+        n = min([1, 3, 2, 3][k % 4], nblk - i)
+        k += 1
+        view = st.input_buffer(3 * B)[: 2 * n * B]
+        view[:] = u8[2 * i * B: 2 * (i + n) * B]
+        got += st.push_inplace(view)
+        i += n
+    got += st.flush()
+    got = np.concatenate(got)
+    assert got.size >= exp.size
+    assert_bit_equal(got[: exp.size], exp, "ragged coalesced zero-copy stream")
