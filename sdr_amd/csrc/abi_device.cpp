@@ -29,8 +29,13 @@ int upload_floats(float** d, const std::vector<float>& h)
     return SDRHIP_OK;
 }
 
+// First use uploads the taps.  Descriptors are immutable afterwards and may be shared by host threads, so the one
+// mutation there is goes under a lock (d_taps / d_groups are published last).
+static std::mutex g_upload_mu;
+
 int FirDesc::ensure_device() const
 {
+    std::lock_guard<std::mutex> lk(g_upload_mu);
     if (d_taps) return SDRHIP_OK;
     int rc;
     if ((rc = upload_floats(&d_cross, h_plain)) != SDRHIP_OK) return rc;
@@ -39,10 +44,11 @@ int FirDesc::ensure_device() const
 }
 int ResampDesc::ensure_device() const
 {
+    std::lock_guard<std::mutex> lk(g_upload_mu);
     if (d_groups) return SDRHIP_OK;
     int rc;
-    if ((rc = upload_floats(&d_groups, h_groups)) != SDRHIP_OK) return rc;
-    return upload_floats(&d_plain, h_plain);
+    if ((rc = upload_floats(&d_plain, h_plain)) != SDRHIP_OK) return rc;
+    return upload_floats(&d_groups, h_groups);
 }
 
 FirDesc::~FirDesc()

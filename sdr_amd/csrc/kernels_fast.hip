@@ -22,6 +22,8 @@
 //   * taps are wave-uniform -> scalar loads / SGPR operands.
 //   "Cross" outputs (seam straddlers, sequential order) are rewritten afterwards by
 //   a tiny fix-up kernel on the same stream: ~1.5 % of outputs.
+#include <atomic>
+
 #include "kernels.hpp"
 
 namespace sdrhip {
@@ -349,7 +351,7 @@ template <int D, int P, int R, int NT, bool U8>
 void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, float* out)
 {
     using T = Tile<D, P, R, NT>;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // idempotent: a race only repeats the call
     auto kern = k_decimate_c4<D, P, R, NT, U8>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

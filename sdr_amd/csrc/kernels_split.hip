@@ -281,7 +281,7 @@ template <bool CPLX, int M, int ORD, bool SYM, int NCHMAX, int U, bool EXACT>
 void launch_kernel(hipStream_t s, const SplitArgs& a, unsigned grid, size_t lds_bytes)
 {
     auto kern = k_split<CPLX, M, ORD, SYM, NCHMAX, U, EXACT>;
-    static bool attr_set = false;   // per instantiation: tiles of large decimation factors exceed the 64 KiB default cap
+    static std::atomic<bool> attr_set{false};   // per instantiation: tiles of large decimation factors exceed the 64 KiB default cap
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_set = true;

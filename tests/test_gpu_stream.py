@@ -154,3 +154,37 @@ def test_argument_errors(hip):
         hip.Filter(taps[:30], hip.ORDER_AVX, sym=True)  # half taps not a multiple of 8
     with pytest.raises(hip.SdrHipError):
         hip.Resampler(10, 3, taps)                      # needs decimation > interpolation
+
+
+def test_shared_descriptor_from_several_host_threads(hip, oracle):
+    """A descriptor is immutable after creation except for the lazy tap upload on first use, which is locked: host threads
+    may share it, each launching on its own HIP stream (ctypes drops the GIL during the calls)."""
+    import threading
+    import torch
+    x = S.cfloat_block(16 * B)
+    taps = S.taps_decim127()
+    K = (16 * B - 128) // 8 + 1
+    ref_dec = hip.Decimator(8, taps, hip.ORDER_AVX, complex_=True)
+    exp = _run_ranges(ref_dec, to_dev(x), 16 * B, 2, K, B, [])
+    for attempt in range(4):
+        dec = hip.Decimator(8, taps, hip.ORDER_AVX, complex_=True)      # fresh: nothing uploaded yet
+        d_in = to_dev(x)
+        outs = [dev_empty_f32(2 * K) for _ in range(6)]
+        streams = [torch.cuda.Stream() for _ in outs]
+        torch.cuda.synchronize()
+        errs = []
+
+        def work(i):
+            try:
+                dec.run(ptr(d_in), 0, ptr(outs[i]), 0, K, B, stream=streams[i].cuda_stream)
+            except Exception as e:                                      # noqa: BLE001
+                errs.append(e)
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(len(outs))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+        for i, o in enumerate(outs):
+            assert_bit_equal(to_host(o), exp, f"attempt {attempt}, thread {i}")
