@@ -26,11 +26,35 @@ class SdrHipError(RuntimeError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own copy of libamdhip64 / libhsa-runtime64 and looks it up by
+    file name, libsdr_hip.so asks for the system copy by SONAME; whichever loads second then brings a second runtime into
+    the process and loses the GPU ("no ROCm-capable device").  If torch is installed, map ITS copies first (by path, without
+    importing torch): our library's SONAME lookup then resolves to them, and a later `import torch` finds the very same
+    files already mapped.  Without torch (a plain C host program, examples/fm_replay.c) the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise SdrHipError(
             f"{LIB_PATH} not found: build it with `python -m sdr_amd.build` "
             "(there is deliberately no CPU fallback)")
+    _share_torch_hip_runtime()
     return C.CDLL(LIB_PATH)
 
 

@@ -2,7 +2,7 @@
 implementation (speculative chunks + verification) vs the oracle, bit for bit, including the settling path."""
 import numpy as np
 import pytest
-import torch  # before the HIP library: two HIP runtimes in one process must be loaded torch-first
+import torch
 
 from conftest import assert_bit_equal
 

@@ -37,3 +37,21 @@ def test_fm_replay_matches_reference_pipeline(tmp_path, oracle, blocks_per_push)
     assert exp.size >= 2 * B
     assert got.size >= exp.size and got.size % B == 0      # the stream may be one block ahead of the four chained Pipes
     assert_bit_equal(got[: exp.size], exp, "fm_replay audio")
+
+
+def test_library_before_torch_in_one_process():
+    """`build()` imports the package (and with it libsdr_hip.so) before `smoke()` imports torch: both must see the GPU
+    (one shared HIP runtime, sdr_amd/lib.py:_share_torch_hip_runtime)."""
+    import sys
+    code = ("import sdr_amd.lib as L\n"
+            "import torch\n"
+            "assert torch.cuda.is_available()\n"
+            "x = torch.arange(8, dtype=torch.float32, device='cuda')\n"
+            "import __graft_entry__ as g\n"
+            "g.smoke()\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "libs = {l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l}\n"
+            "assert len(libs) == 1, libs\n"
+            "print('ok', L.device_name())\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
