@@ -212,8 +212,13 @@ void sdrhip_resampler_destroy(sdrhip_resampler *r);
 int64_t sdrhip_resampler_in_offset(const sdrhip_resampler *r, int64_t m);
 int sdrhip_resampler_filter_offset(const sdrhip_resampler *r, int64_t m);
 int sdrhip_resampler_group(const sdrhip_resampler *r, int64_t m);
+/* out_block: the output block size of the Pipe being reproduced (firResampler's blockSizeOut; 0 =
+ * unbounded).  It matters for one output in ~10^4 seams: inside a crossover the reference computes
+ * the output whose virtual start lies in the last I-1 zero-stuffed positions before the boundary
+ * sequentially, unless its output block was full just before it (Filter.hs:715,722-724). */
 int sdrhip_resampler_run(const sdrhip_resampler *r, void *stream, const float *d_in, int64_t in_base,
-                         float *d_out, int64_t k_begin, int64_t k_end, int64_t seam_block);
+                         float *d_out, int64_t k_begin, int64_t k_end, int64_t seam_block,
+                         int64_t out_block);
 
 /* ---- element-wise stages -------------------------------------------------- */
 /* interleavedIQUnsignedByteToFloat (Util.hs:104-138 / convert.c): n_bytes u8 -> n_bytes f32 */

@@ -226,7 +226,7 @@ int resamp_create(ResampDesc* r, int order, bool cplx, int I, int D, const float
 }
 
 int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in_base, float* d_out,
-               int64_t k_begin, int64_t k_end, int64_t seam_block)
+               int64_t k_begin, int64_t k_end, int64_t seam_block, int64_t out_block)
 {
     SDRHIP_REQUIRE(r != nullptr, "resamp_run");
     SDRHIP_REQUIRE(k_end >= k_begin && k_end - k_begin < (int64_t)0x7fffffff, "resamp_run");
@@ -253,6 +253,7 @@ int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in
     g.D = r->D;
     g.Lp = r->Lp;
     g.seamBI = seam_block < 0 ? -1 : seam_block * r->I;
+    g.outB = out_block > 0 ? out_block : 0;
     ResampTable t;
     t.ngroups = r->num_groups;
     t.group0 = r->group(k_begin);
@@ -460,9 +461,9 @@ int64_t sdrhip_resampler_in_offset(const sdrhip_resampler* r, int64_t m) { retur
 int sdrhip_resampler_filter_offset(const sdrhip_resampler* r, int64_t m) { return r ? r->filter_offset(m) : SDRHIP_ERR_ARG; }
 int sdrhip_resampler_group(const sdrhip_resampler* r, int64_t m) { return r ? r->group(m) : SDRHIP_ERR_ARG; }
 int sdrhip_resampler_run(const sdrhip_resampler* r, void* stream, const float* d_in, int64_t in_base, float* d_out,
-                         int64_t k_begin, int64_t k_end, int64_t seam_block)
+                         int64_t k_begin, int64_t k_end, int64_t seam_block, int64_t out_block)
 {
-    return resamp_run(r, (hipStream_t)stream, d_in, in_base, d_out, k_begin, k_end, seam_block);
+    return resamp_run(r, (hipStream_t)stream, d_in, in_base, d_out, k_begin, k_end, seam_block, out_block);
 }
 
 // ---- element-wise -----------------------------------------------------------------

@@ -303,7 +303,7 @@ int sdrhip_fm_chain_run(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
         if ((rc = end_span(1, st, b)) != SDRHIP_OK) return rc;
         // K4: polyphase resample
         if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;
-        if ((rc = resamp_run(&c->resamp, st, d_y, r.ky0, d_z, r.m0, r.m1, c->block)) != SDRHIP_OK) return rc;
+        if ((rc = resamp_run(&c->resamp, st, d_y, r.ky0, d_z, r.m0, r.m1, c->block, c->block)) != SDRHIP_OK) return rc;
         if ((rc = end_span(2, st, b)) != SDRHIP_OK) return rc;
         // K5: symmetric audio filter (+ fm.hs:40 `P.map (VG.map (* 0.2))` as the kernel's epilogue: a separate
         // f32 multiply of the rounded output)

@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(256) k_resample_crossfix(Geom g, const float* 
     const int64_t v = m * g.D;
     if (!(v < edge && v + g.Lp > edge)) return;
     if (!seam_has_crossover(edge, g.I, g.D, g.Lp)) return;       // the Pipe goes straight to the next buffer here
+    if (late_output_is_one(m, edge, g.I, g.D, g.outB)) return;   // first output of an output block, first input beyond the seam
     const int64_t pos = (v + g.I - 1) / g.I;                     // inOff(m)
     const int fo = (int)(pos * g.I - v);
     if constexpr (CPLX) {

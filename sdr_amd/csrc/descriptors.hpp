@@ -65,8 +65,10 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
             int64_t k_begin, int64_t k_end, int64_t seam_block, float gain = 1.0f);
 
 int resamp_create(ResampDesc* r, int order, bool cplx, int I, int D, const float* coeffs, int ncoeffs);
+// out_block: the Pipe's output block size (blockSizeOut; 0 = unbounded) -- it decides one corner case of the seam
+// classification (kernels.hpp: late_output_is_one)
 int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in_base, float* d_out,
-               int64_t k_begin, int64_t k_end, int64_t seam_block);
+               int64_t k_begin, int64_t k_end, int64_t seam_block, int64_t out_block = 0);
 
 }  // namespace sdrhip
 

@@ -26,6 +26,7 @@ struct Geom {
     int     D;         // decimation
     int     Lp;        // Pipe-visible (padded) length in upsampled units
     int64_t seamBI;    // seam_block * I; 0 = contiguous (all One); < 0 = every output Cross
+    int64_t outB = 0;  // the Pipe's output block size (0 = unbounded): see late_output_is_one below
 };
 
 // Does the reference's Pipe enter its crossover (sequential) code at the buffer boundary `edge` (upsampled units, a
@@ -40,6 +41,19 @@ __host__ __device__ inline bool seam_has_crossover(int64_t edge, int I, int D, i
     const int64_t m_star = edge >= Lp ? (edge - Lp) / D + 1 : 0;
     const int64_t first_in = (m_star * D + I - 1) / I;
     return first_in * I < edge;
+}
+
+// Inside a crossover the Pipe computes every output whose virtual start precedes the boundary -- but only as far as
+// its OUTPUT block has room (`count = min outputsComputable (space bufferOut)`, Filter.hs:715); when it comes back with a
+// fresh output block it re-decides by the first input sample (`inputUsed >= VG.length bufLast -> simple`, Filter.hs:722-724).
+// So the one output whose virtual start lies in the last I-1 zero-stuffed positions before the boundary (first input
+// already in the next buffer) is sequential -- unless it is the first output of an output block, in which case it is the
+// next buffer's first SIMD output.  outB = the output block size (global output index m = 0 starts a block).
+__host__ __device__ inline bool late_output_is_one(int64_t m, int64_t edge, int I, int D, int64_t outB)
+{
+    if (I == 1 || outB <= 0 || m % outB != 0) return false;
+    const int64_t first_in = (m * D + I - 1) / I;
+    return first_in * I >= edge;
 }
 
 // Real data ------------------------------------------------------------------

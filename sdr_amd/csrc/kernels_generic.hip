@@ -27,6 +27,7 @@ __device__ __forceinline__ bool is_cross(const Geom& g, int64_t m)
     const int64_t v = m * (int64_t)g.D;
     const int64_t edge = (v / g.seamBI + 1) * g.seamBI;
     if (v + g.Lp <= edge) return false;
+    if (late_output_is_one(m, edge, g.I, g.D, g.outB)) return false;
     return seam_has_crossover(edge, g.I, g.D, g.Lp);
 }
 

@@ -271,6 +271,9 @@ int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
     // ... unless the Pipe does not cross over at this boundary at all: the first pending output already has its first
     // input in the new block (`VG.length bufIn' == 0 -> simple next`, Filter.hs:707-709; resamplers only)
     if (E_prev > 0 && !seam_has_crossover(E_prev * p->I, p->I, p->D, p->Lp)) m_split = p->m_done;
+    // ... and the last of them, when its first input is already in the new block, only if the output block had room for
+    // it (kernels.hpp: late_output_is_one)
+    if (m_split > p->m_done && late_output_is_one(m_split - 1, E_prev * p->I, p->I, p->D, p->block_out)) m_split--;
     // the reference's `assert "filter 1" / "decimate 1" / "resample 1"`: after the
     // crossover the rest of the new buffer must still hold one whole filter
     if (m_end <= m_split) {

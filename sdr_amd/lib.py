@@ -99,7 +99,7 @@ lib.sdrhip_resampler_in_offset.argtypes = [_vp, _i64]
 lib.sdrhip_resampler_in_offset.restype = _i64
 lib.sdrhip_resampler_filter_offset.argtypes = [_vp, _i64]
 lib.sdrhip_resampler_group.argtypes = [_vp, _i64]
-lib.sdrhip_resampler_run.argtypes = [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64]
+lib.sdrhip_resampler_run.argtypes = [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64]
 
 lib.sdrhip_convert_u8_run.argtypes = [_vp, _vp, _vp, _i64]
 lib.sdrhip_convert_i16_run.argtypes = [_vp, _vp, _vp, _i64]
@@ -351,8 +351,9 @@ class Resampler(_Handle):
     def group(self, m):
         return lib.sdrhip_resampler_group(self.h, m)
 
-    def run(self, d_in, in_base, d_out, k_begin, k_end, seam_block=0, stream=None):
-        check(lib.sdrhip_resampler_run(self.h, stream, d_in, in_base, d_out, k_begin, k_end, seam_block), "sdrhip_resampler_run")
+    def run(self, d_in, in_base, d_out, k_begin, k_end, seam_block=0, stream=None, out_block=0):
+        check(lib.sdrhip_resampler_run(self.h, stream, d_in, in_base, d_out, k_begin, k_end, seam_block, out_block),
+              "sdrhip_resampler_run")
 
 
 class FmChain(_Handle):

@@ -10,6 +10,9 @@ import signals as S
 
 pytestmark = pytest.mark.gpu
 
+# SDRHIP_SWEEP_SCALE=20 turns the seeded random sweeps into a soak test (more trials, same seeds first)
+SWEEP_SCALE = max(1, int(__import__("os").environ.get("SDRHIP_SWEEP_SCALE", "1")))
+
 B = 8192
 
 
@@ -140,7 +143,7 @@ def test_resampler_pipe_random_sweep(hip, oracle):
     fits a block already starts in the next one the reference Pipe does not cross over (Filter.hs:707-709)."""
     rng = np.random.default_rng(77)
     ran = 0
-    for trial in range(40):
+    for trial in range(40 * SWEEP_SCALE):
         complex_ = bool(rng.integers(0, 2))
         order = [PM.ORDER_AVX, PM.ORDER_SSE, PM.ORDER_SCALAR][rng.integers(0, 3)]
         w = 2 if complex_ else 1
@@ -173,7 +176,7 @@ def test_resampler_pipe_random_sweep(hip, oracle):
 def test_decimator_pipe_random_sweep(hip, oracle):
     rng = np.random.default_rng(78)
     ran = 0
-    for trial in range(30):
+    for trial in range(30 * SWEEP_SCALE):
         complex_ = bool(rng.integers(0, 2))
         order = [PM.ORDER_AVX, PM.ORDER_SSE, PM.ORDER_SCALAR][rng.integers(0, 3)]
         w = 2 if complex_ else 1

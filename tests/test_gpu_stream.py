@@ -19,14 +19,15 @@ def _split(x, width, block):
     return [x[i * block * width:(i + 1) * block * width] for i in range(n // block)]
 
 
-def _run_ranges(desc, d_in, in_total, out_width, K, seam, cuts, u8=False):
+def _run_ranges(desc, d_in, in_total, out_width, K, seam, cuts, u8=False, out_block=0):
     """Run [0,K) as several launches cut at `cuts`, each with its own in_base/slice of the input."""
     out = dev_empty_f32(K * out_width)
     edges = [0] + list(cuts) + [K]
+    kw = {"out_block": out_block} if out_block else {}
     for a, b in zip(edges[:-1], edges[1:]):
         if b <= a:
             continue
-        (desc.run_u8 if u8 else desc.run)(ptr(d_in), 0, ptr(out) + 4 * out_width * a, a, b, seam)
+        (desc.run_u8 if u8 else desc.run)(ptr(d_in), 0, ptr(out) + 4 * out_width * a, a, b, seam, **kw)
     return to_host(out)
 
 
@@ -104,9 +105,9 @@ def test_resampler_stream(hip, oracle, order, complex_):
     exp = np.concatenate(blocks)
     r = hip.Resampler(3, 10, taps, order, complex_)
     assert r.num_coeffs == model.num_coeffs
-    got = _run_ranges(r, to_dev(x), 4 * B, w, exp.size // w, B, [])
+    got = _run_ranges(r, to_dev(x), 4 * B, w, exp.size // w, B, [], out_block=512)
     assert_bit_equal(got, exp, "contiguous")
-    got = _run_ranges(r, to_dev(x), 4 * B, w, exp.size // w, B, [1, 2, 2439, 2458, 5000])
+    got = _run_ranges(r, to_dev(x), 4 * B, w, exp.size // w, B, [1, 2, 2439, 2458, 5000], out_block=512)
     assert_bit_equal(got, exp, "cut into launches")
 
 
@@ -120,7 +121,7 @@ def test_resampler_other_ratios(hip, oracle, I, D):
     r = hip.Resampler(I, D, taps, hip.ORDER_AVX)
     for m in (0, 1, 5, 1000):
         assert r.in_offset(m) == -((-m * D) // I)
-    got = _run_ranges(r, to_dev(x), 3 * 4096, 1, exp.size, 4096, [77])
+    got = _run_ranges(r, to_dev(x), 3 * 4096, 1, exp.size, 4096, [77], out_block=128)
     assert_bit_equal(got, exp, f"{I}/{D}")
 
 
