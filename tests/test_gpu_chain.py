@@ -273,16 +273,25 @@ def test_chain_random_sweep(hip, oracle):
             n_in = min(total, s1 + h) - s0
             pieces.append(_run(hip, chain, to_dev(u8[2 * s0: 2 * (s0 + n_in)]), s0, n_in, a, b))
         assert_bit_equal(np.concatenate(pieces), got, label + " (3 shards)")
-        # host-block stream operator, two source blocks per push
-        st = hip.FmStream(chain, 2 * block, block)
-        outs = []
-        for i in range(0, nblk - 1, 2):
-            outs += st.push(u8[2 * i * block: 2 * (i + 2) * block])
+        # host-block stream operator: random push sizes (1-4 source blocks), random coalescing, zero-copy now and then
+        st = hip.FmStream(chain, 4 * block, block)
+        if rng.integers(0, 2):
+            st.set_coalesce(int(rng.integers(1, 9)) * block)
+        outs, i = [], 0
+        while i < nblk:
+            k = min(int(rng.integers(1, 5)), nblk - i)
+            chunk = u8[2 * i * block: 2 * (i + k) * block]
+            if rng.integers(0, 3) == 0:
+                view = st.input_buffer(4 * block)[: chunk.size]
+                view[:] = chunk
+                outs += st.push_inplace(view)
+            else:
+                outs += st.push(chunk)
+            i += k
         outs += st.flush()
         outs = np.concatenate(outs) if outs else np.zeros(0, np.float32)
-        n = min(outs.size, exp.size)
-        assert n >= exp.size - block, label
-        assert_bit_equal(outs[:n], exp[:n], label + " (stream)")
+        assert outs.size >= exp.size and outs.size % block == 0, label
+        assert_bit_equal(outs[: exp.size], exp, label + " (stream)")
         ran += 1
     print(f"chain sweep: {ran} random receivers compared")
     assert ran >= 12

@@ -219,3 +219,62 @@ def test_reference_test_suite_maximum_size(hip, oracle):
     assert_bit_equal(hip.DropIn.filt("filterAVXSymmetricRR", num, h[:512], x), oracle.filter_sym_rr(8, num, h[:512], x), "sym")
     nd = (n - ntaps) // 23 + 1
     assert_bit_equal(hip.DropIn.decim("decimateAVXRC", nd, 23, duplicate(h), xc, True), oracle.decimate_rc(4, nd, 23, duplicate(h), xc), "decimateAVXRC /23")
+
+
+SWEEP_SCALE = max(1, int(__import__("os").environ.get("SDRHIP_SWEEP_SCALE", "1")))
+
+
+def test_dropin_random_sweep_against_the_reference_build(hip, oracle, ref):
+    """Every drop-in filter / decimator / resampler symbol with seeded random shapes, straight against the reference's
+    own compiled C (oracle/_ref) -- no restatement in between."""
+    rng = np.random.default_rng(31337)
+    fir = [  # (symbol, complex, taps multiple, duplicated, symmetric)
+        ("RR", False, 1, False, False), ("SSERR", False, 4, False, False), ("AVXRR", False, 8, False, False),
+        ("SSESymmetricRR", False, 4, False, True), ("AVXSymmetricRR", False, 8, False, True),
+        ("RC", True, 1, False, False), ("SSERC", True, 2, True, False), ("AVXRC", True, 4, True, False),
+        ("SSERC2", True, 4, False, False), ("AVXRC2", True, 8, False, False),
+        ("SSESymmetricRC", True, 4, False, True), ("AVXSymmetricRC", True, 8, False, True)]
+    res = [("resample2RR", False, 1), ("resampleSSERR", False, 4), ("resampleAVXRR", False, 8),
+           ("resample2RC", True, 1), ("resampleSSERC", True, 4), ("resampleAVXRC", True, 8)]
+    done = 0
+    for trial in range(120 * SWEEP_SCALE):
+        if rng.integers(0, 4) < 3:
+            name, cplx, mult, dup, sym = fir[rng.integers(0, len(fir))]
+            decimate = bool(rng.integers(0, 2))
+            factor = int(rng.integers(1, 13)) if decimate else 1
+            nt = mult * int(rng.integers(1, 1 + 256 // mult))          # taps as the kernel walks them (half taps when sym)
+            full = 2 * nt if sym else nt
+            num = int(rng.integers(1, 3000))
+            n_in = (num - 1) * factor + full
+            w = 2 if cplx else 1
+            x = rng.uniform(-10, 10, w * n_in).astype(np.float32)
+            h = rng.uniform(-10, 10, nt).astype(np.float32)
+            passed = duplicate(h) if dup else h
+            symbol = ("decimate" if decimate else "filter") + name
+            if decimate:
+                got = hip.DropIn.decim(symbol, num, factor, passed, x, cplx)
+                exp = ref.decim(symbol, num, factor, passed, x, cplx)
+            else:
+                got = hip.DropIn.filt(symbol, num, passed, x, cplx)
+                exp = ref.filt(symbol, num, passed, x, cplx)
+            assert_bit_equal(got, exp, f"trial {trial}: {symbol} num={num} factor={factor} taps={nt}")
+        else:
+            symbol, cplx, simd = res[rng.integers(0, len(res))]
+            while True:
+                I, D = int(rng.integers(1, 9)), int(rng.integers(2, 30))
+                if D > I and np.gcd(I, D) == 1:
+                    break
+            ntaps = int(rng.integers(I, 60 * I))
+            h = rng.uniform(-10, 10, ntaps).astype(np.float32)
+            prep = oracle.prepare_coeffs(simd, I, D, h)
+            num = int(rng.integers(1, 2000))
+            g0 = int(rng.integers(0, prep["num_groups"]))
+            n_in = num * (D // I + 2) + prep["groups"].shape[1] + 16
+            w = 2 if cplx else 1
+            x = rng.uniform(-10, 10, w * n_in).astype(np.float32)
+            got, g = hip.DropIn.resample(symbol, num, prep["num_coeffs"], g0, prep["increments"], prep["groups"], x, cplx)
+            exp, ge = ref.resample(symbol, num, prep, g0, x, cplx)
+            assert g == ge, f"trial {trial}: {symbol} end group {g} vs {ge}"
+            assert_bit_equal(got, exp, f"trial {trial}: {symbol} {I}/{D} taps={ntaps} num={num} g0={g0}")
+        done += 1
+    assert done == 120 * SWEEP_SCALE

@@ -189,3 +189,31 @@ def test_shared_descriptor_from_several_host_threads(hip, oracle):
         assert not errs, errs
         for i, o in enumerate(outs):
             assert_bit_equal(to_host(o), exp, f"attempt {attempt}, thread {i}")
+
+
+def test_fm_demod_random_bit_patterns(hip, oracle):
+    """fmDemod on arbitrary float bit patterns (denormals, infinities, NaNs, huge ratios): the device kernel follows the
+    restated GHC formula (Data.Complex multiply, RealFloat atan2, fdlibm atanf) through every special case.  NaN results
+    are compared as NaN (payloads are not part of the contract), everything else bit for bit."""
+    import torch
+    rng = np.random.default_rng(2718)
+    n = 1 << 18
+    bits = rng.integers(0, 1 << 32, 2 * n, dtype=np.uint64).astype(np.uint32)
+    # half of the samples get moderate exponents so that not everything overflows to inf/NaN
+    mod = rng.integers(0, 2, 2 * n).astype(bool)
+    e = rng.integers(100, 150, 2 * n).astype(np.uint32)
+    bits[mod] = (bits[mod] & np.uint32(0x807FFFFF)) | (e[mod] << np.uint32(23))
+    x = bits.view(np.float32)
+    exp = oracle.fm_demod(x)
+    d_in = to_dev(x)
+    out = dev_empty_f32(n)
+    hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
+    got = to_host(out)
+    nan_e, nan_g = np.isnan(exp), np.isnan(got)
+    assert np.array_equal(nan_e, nan_g), f"NaN pattern differs at {np.nonzero(nan_e != nan_g)[0][:5]}"
+    ok = ~nan_e
+    assert ok.sum() > n // 4
+    assert_bit_equal(got[ok], exp[ok], "fmDemod on random bit patterns")
+    got2 = hip.DropIn.fm_demod(x)
+    assert np.array_equal(np.isnan(got2), nan_e)
+    assert_bit_equal(got2[ok], exp[ok], "fmDemodF (drop-in) on random bit patterns")
