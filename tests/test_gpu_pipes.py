@@ -195,3 +195,35 @@ def test_decimator_pipe_random_sweep(hip, oracle):
         _cmp(_drive(hip.firDecimator(d, bso), blocks), exp, f"trial {trial}: /{factor}, {ntaps} taps, order {order}, complex {complex_}")
         ran += 1
     assert ran >= 20
+
+
+def test_filter_pipe_random_sweep(hip, oracle):
+    """firFilter on ragged host blocks: plain real / complex and symmetric real filters, all orders."""
+    rng = np.random.default_rng(79)
+    ran = 0
+    for trial in range(30 * SWEEP_SCALE):
+        order = [PM.ORDER_AVX, PM.ORDER_SSE, PM.ORDER_SCALAR][rng.integers(0, 3)]
+        kind = rng.integers(0, 3)                                   # 0 real, 1 complex, 2 symmetric real
+        if kind == 2 and order == PM.ORDER_SCALAR:
+            order = PM.ORDER_SSE                                    # the reference has no scalar symmetric kernels
+        complex_ = kind == 1
+        w = 2 if complex_ else 1
+        if kind == 2:
+            simd = 8 if order == PM.ORDER_AVX else 4
+            taps = S.gauss_taps(simd * int(rng.integers(1, 16)), 900 + trial)
+            full = 2 * taps.size
+        else:
+            taps = S.gauss_taps(int(rng.integers(2, 200)), 900 + trial)
+            full = taps.size + 8
+        sizes = [int(s) for s in rng.integers(full + 8, full + 5000, size=10)]
+        x = S.cfloat_block(sum(sizes), seed=950 + trial) if complex_ else S.real_block(sum(sizes), seed=950 + trial)
+        blocks = _cut(x, w, sizes)
+        bso = int(rng.integers(50, 1500))
+        try:
+            exp, _ = PM.fir_filter_pipe(PM.FilterModel(oracle, taps, order, complex_=complex_, sym=(kind == 2)), blocks, bso)
+        except PM.PipeAssert:
+            continue
+        f = hip.Filter(taps, order, complex_=complex_, sym=(kind == 2))
+        _cmp(_drive(hip.firFilter(f, bso), blocks), exp, f"trial {trial}: kind {kind}, {taps.size} taps, order {order}")
+        ran += 1
+    assert ran >= 20
