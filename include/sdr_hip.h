@@ -334,6 +334,14 @@ int sdrhip_pipe_dc_blocker(sdrhip_pipe **p);                                    
 int sdrhip_pipe_push(sdrhip_pipe *p, const float *block, int n);
 /* Transfers are double-buffered, so results lag one push behind: flush waits for
  * the in-flight block and returns the number of complete output blocks ready. */
+/* Throughput knobs of the filter / decimator / resampler pipes (results never depend on them):
+ *  - set_coalesce(blocks): equal-sized pushes are staged in the pinned buffer and submitted `blocks` at a
+ *    time (one upload, one run over the batch with its interior seams, one download); a push of another
+ *    size ends the uniform run.  0 / 1 = every push on its own.
+ *  - input_buffer(n): the pinned staging memory the next push of n elements will be uploaded from; fill it
+ *    and push that pointer to skip the host-side copy. */
+int sdrhip_pipe_set_coalesce(sdrhip_pipe *p, int blocks);
+float *sdrhip_pipe_input_buffer(sdrhip_pipe *p, int n);
 int sdrhip_pipe_flush(sdrhip_pipe *p);
 /* Pop one ready block into out (capacity in elements); returns its length, 0 if none. */
 int sdrhip_pipe_pop(sdrhip_pipe *p, float *out, int capacity);

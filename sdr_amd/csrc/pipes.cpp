@@ -49,6 +49,11 @@ struct sdrhip_pipe {
     int64_t E_prev = 0;     // global end of the previous block
     int64_t m_done = 0;     // outputs computed so far
     float last_re = 0.0f, last_im = 0.0f;  // fmDemod carry (Demod.hs:41,46)
+    // coalescing of equal-sized pushes (FIR-like stages): samples staged in the current slot, not yet submitted
+    int staged = 0;
+    int coalesce = 0;          // blocks per submission (0/1: every push)
+    int uniform_n = 0;         // size of the first block; all_uniform: every block so far had it
+    bool all_uniform = true;
 
     struct Slot {
         PinBuf hin, hout;
@@ -141,6 +146,158 @@ static int ready_blocks(const sdrhip_pipe* p)
     return (int)(p->fifo_size() / ((size_t)p->block_out * p->esz_out()));
 }
 
+// Submit the n elements staged in the current slot's pinned buffer.  uniform_seam > 0: they are whole blocks of that size
+// and so was everything before them, so the seams of the reference's input buffers are the multiples of uniform_seam and
+// ONE stream-API run covers the batch (interior seams included).  uniform_seam == 0: a single block of arbitrary size: the
+// outputs straddling the boundary with the previous block first (all Cross), then the ones inside the new block (all One).
+static int fir_submit(sdrhip_pipe* p, int n, int64_t uniform_seam)
+{
+    const int si = (int)(p->pushes & 1);
+    sdrhip_pipe::Slot& sl = p->slot[si];
+    int rc;
+    const size_t ein = (size_t)p->esz_in() * 4, eout = (size_t)p->esz_out() * 4;
+    const int64_t E_prev = p->E_prev, E = E_prev + n;
+    // outputs computable once these samples are in: window end <= E*I
+    int64_t m_end = (E * p->I >= p->Lp) ? (E * p->I - p->Lp) / p->D + 1 : 0;
+    // first output starting at/after the previous boundary: everything before it
+    // that is not yet done straddles that boundary (Cross)
+    int64_t m_split = ceil_div64(E_prev * p->I, p->D);
+    if (m_split < p->m_done) m_split = p->m_done;
+    // ... unless the Pipe does not cross over at this boundary at all: the first pending output already has its first
+    // input in the new block (`VG.length bufIn' == 0 -> simple next`, Filter.hs:707-709; resamplers only)
+    if (E_prev > 0 && !seam_has_crossover(E_prev * p->I, p->I, p->D, p->Lp)) m_split = p->m_done;
+    // ... and the last of them, when its first input is already in the new block, only if the output block had room for
+    // it (kernels.hpp: late_output_is_one)
+    if (m_split > p->m_done && late_output_is_one(m_split - 1, E_prev * p->I, p->I, p->D, p->block_out)) m_split--;
+    // device input = [tail of previous | new samples]
+    const int64_t keep_from = p->in_offset(p->m_done);  // first input any pending output needs
+    const int64_t tail = E_prev - keep_from > 0 ? E_prev - keep_from : 0;
+    DevBuf& prev = p->din[p->cur];
+    DevBuf& next = p->din[p->cur ^ 1];
+    if ((rc = next.ensure((size_t)(tail + n) * ein)) != SDRHIP_OK) return rc;
+    // the previous submission's tail copy READ `next` (it was that submission's `prev`): the upload
+    // below must not overwrite it first
+    if (p->tail_pending) SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->up, p->ev_tail, 0));
+    p->tail_pending = false;
+    if (tail > 0) {
+        SDRHIP_CHECK_HIP(hipMemcpyAsync(next.p, (const char*)prev.p + (size_t)(keep_from - p->base) * ein,
+                                        (size_t)tail * ein, hipMemcpyDeviceToDevice, p->stream));
+        SDRHIP_CHECK_HIP(hipEventRecord(p->ev_tail, p->stream));
+        p->tail_pending = true;
+    }
+    // `next` was last read by the kernels of submission i-2, which has been harvested, so the
+    // upload may start while submission i-1's kernels are still running on the compute stream
+    SDRHIP_CHECK_HIP(hipMemcpyAsync((char*)next.p + (size_t)tail * ein, sl.hin.p, (size_t)n * ein,
+                                    hipMemcpyHostToDevice, p->up));
+    SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, p->up));
+    SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->stream, sl.ev_up, 0));
+    p->cur ^= 1;
+    p->base = tail > 0 ? keep_from : E_prev;
+    p->have = tail + n;
+
+    const int64_t n_out = m_end - p->m_done;
+    sl.n_out = 0;
+    if (n_out > 0) {
+        if ((rc = sl.dout.ensure((size_t)n_out * eout)) != SDRHIP_OK) return rc;
+        if ((rc = sl.hout.ensure((size_t)n_out * eout)) != SDRHIP_OK) return rc;
+        float* dout = (float*)sl.dout.p;
+        const float* din = (const float*)next.p;
+        if (uniform_seam > 0) {
+            if (p->kind == PK_RESAMPLER)
+                rc = resamp_run(p->rs, p->stream, din, p->base, dout, p->m_done, m_end, uniform_seam, p->block_out);
+            else
+                rc = fir_run(p->fir, p->stream, din, false, p->base, dout, p->m_done, m_end, uniform_seam);
+            if (rc != SDRHIP_OK) return rc;
+        } else {
+            const int64_t ncross = m_split - p->m_done;
+            if (p->kind == PK_RESAMPLER) {
+                if (ncross > 0 && (rc = resamp_run(p->rs, p->stream, din, p->base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
+                if ((rc = resamp_run(p->rs, p->stream, din, p->base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
+            } else {
+                if (ncross > 0 && (rc = fir_run(p->fir, p->stream, din, false, p->base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
+                if ((rc = fir_run(p->fir, p->stream, din, false, p->base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
+            }
+        }
+        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, p->stream));
+        SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->down, sl.ev_k, 0));
+        SDRHIP_CHECK_HIP(hipMemcpyAsync(sl.hout.p, sl.dout.p, (size_t)n_out * eout, hipMemcpyDeviceToHost, p->down));
+        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, p->down));
+        sl.n_out = n_out * p->esz_out();
+        sl.busy = true;
+    }
+    p->m_done = m_end;
+    p->E_prev = E;
+    p->pushes++;
+    p->staged = 0;
+    return harvest(p, si ^ 1);
+}
+
+// make the current slot's pinned staging buffer writable and big enough
+static int fir_open_slot(sdrhip_pipe* p, size_t elems)
+{
+    sdrhip_pipe::Slot& sl = p->slot[p->pushes & 1];
+    int rc;
+    if (p->staged == 0) {
+        if ((rc = harvest(p, (int)(p->pushes & 1))) != SDRHIP_OK) return rc;
+        SDRHIP_CHECK_HIP(hipEventSynchronize(sl.ev_up));   // the slot's previous upload has left the buffer
+    }
+    if (sl.hin.cap < elems * p->esz_in() * 4) {
+        // growing must keep what is already staged
+        PinBuf bigger;
+        if ((rc = bigger.ensure(elems * p->esz_in() * 4)) != SDRHIP_OK) return rc;
+        if (p->staged > 0) memcpy(bigger.p, sl.hin.p, (size_t)p->staged * p->esz_in() * 4);
+        std::swap(sl.hin.p, bigger.p);
+        std::swap(sl.hin.cap, bigger.cap);
+    }
+    return SDRHIP_OK;
+}
+
+// the reference's `assert "filter 1" / "decimate 1" / "resample 1"` for a block of n elements arriving at E_at: after the
+// crossover the rest of the new buffer must still hold one whole filter
+static int fir_check_block(const sdrhip_pipe* p, int64_t E_at, int64_t m_pending, int n)
+{
+    const int64_t E = E_at + n;
+    const int64_t m_end = (E * p->I >= p->Lp) ? (E * p->I - p->Lp) / p->D + 1 : 0;
+    int64_t m_split = ceil_div64(E_at * p->I, p->D);
+    if (m_split < m_pending) m_split = m_pending;
+    if (m_end <= m_split) {
+        set_error("pipe: input block of %d elements is shorter than the filter (numCoeffs %d): the reference asserts "
+                  "(Filter.hs:544,586,691)", n, p->Lp);
+        return SDRHIP_ERR_ARG;
+    }
+    return SDRHIP_OK;
+}
+
+static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
+{
+    int rc;
+    const size_t ein = (size_t)p->esz_in() * 4;
+    if (p->uniform_n == 0) p->uniform_n = n;
+    if (n != p->uniform_n) p->all_uniform = false;
+    const bool coalescing = p->coalesce > 1 && p->all_uniform;
+    if (!coalescing && p->staged > 0) {
+        // a block of another size ends the uniform run: what is staged goes out as one uniform batch first
+        if ((rc = fir_submit(p, p->staged, p->uniform_n)) != SDRHIP_OK) return rc;
+    }
+    // the block must be acceptable to the reference's Pipe where it arrives
+    const int64_t m_pending = p->staged > 0 ? ((p->E_prev + p->staged) * p->I >= p->Lp ? ((p->E_prev + p->staged) * p->I - p->Lp) / p->D + 1 : 0)
+                                             : p->m_done;
+    if ((rc = fir_check_block(p, p->E_prev + p->staged, m_pending, n)) != SDRHIP_OK) return rc;
+    const int cap = coalescing ? p->coalesce * p->uniform_n : n;
+    if ((rc = fir_open_slot(p, (size_t)(cap > p->staged + n ? cap : p->staged + n))) != SDRHIP_OK) return rc;
+    float* dst = (float*)p->slot[p->pushes & 1].hin.p + (size_t)p->staged * p->esz_in();
+    if (block != dst) memcpy(dst, block, (size_t)n * ein);   // else: the caller filled the staging buffer in place
+    p->staged += n;
+    if (!coalescing) {
+        // equal-sized blocks from the start: the seams are the multiples of that size and one run covers Cross and One
+        // outputs alike; otherwise (ragged blocks) the two-part submission
+        if ((rc = fir_submit(p, p->staged, p->all_uniform ? p->uniform_n : 0)) != SDRHIP_OK) return rc;
+    } else if (p->staged >= p->coalesce * p->uniform_n) {
+        if ((rc = fir_submit(p, p->staged, p->uniform_n)) != SDRHIP_OK) return rc;
+    }
+    return ready_blocks(p);
+}
+
 extern "C" {
 
 int sdrhip_pipe_fir_filter(sdrhip_pipe** pp, const sdrhip_filter* f, int block_size_out)
@@ -218,6 +375,7 @@ int sdrhip_pipe_dc_blocker(sdrhip_pipe** pp)
 int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
 {
     SDRHIP_REQUIRE(p != nullptr && block != nullptr && n > 0, "sdrhip_pipe_push");
+    if (!p->is_map()) return fir_like_push(p, block, n);
     const int si = (int)(p->pushes & 1);
     sdrhip_pipe::Slot& sl = p->slot[si];
     int rc;
@@ -261,82 +419,34 @@ int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
     }
 
     // ---- FIR-like stages --------------------------------------------------------
-    const int64_t E_prev = p->E_prev, E = E_prev + n;
-    // outputs computable once this block is in: window end <= E*I
-    int64_t m_end = (E * p->I >= p->Lp) ? (E * p->I - p->Lp) / p->D + 1 : 0;
-    // first output starting at/after the previous boundary: everything before it
-    // that is not yet done straddles that boundary (Cross)
-    int64_t m_split = ceil_div64(E_prev * p->I, p->D);
-    if (m_split < p->m_done) m_split = p->m_done;
-    // ... unless the Pipe does not cross over at this boundary at all: the first pending output already has its first
-    // input in the new block (`VG.length bufIn' == 0 -> simple next`, Filter.hs:707-709; resamplers only)
-    if (E_prev > 0 && !seam_has_crossover(E_prev * p->I, p->I, p->D, p->Lp)) m_split = p->m_done;
-    // ... and the last of them, when its first input is already in the new block, only if the output block had room for
-    // it (kernels.hpp: late_output_is_one)
-    if (m_split > p->m_done && late_output_is_one(m_split - 1, E_prev * p->I, p->I, p->D, p->block_out)) m_split--;
-    // the reference's `assert "filter 1" / "decimate 1" / "resample 1"`: after the
-    // crossover the rest of the new buffer must still hold one whole filter
-    if (m_end <= m_split) {
-        set_error("pipe: input block of %d elements is shorter than the filter (numCoeffs %d): the reference asserts "
-                  "(Filter.hs:544,586,691)", n, p->Lp);
-        return SDRHIP_ERR_ARG;
-    }
-    // device input = [tail of previous | new block]
-    const int64_t keep_from = p->in_offset(p->m_done);  // first input any pending output needs
-    const int64_t tail = E_prev - keep_from > 0 ? E_prev - keep_from : 0;
-    DevBuf& prev = p->din[p->cur];
-    DevBuf& next = p->din[p->cur ^ 1];
-    if ((rc = next.ensure((size_t)(tail + n) * ein)) != SDRHIP_OK) return rc;
-    // the previous push's tail copy READ `next` (it was that push's `prev`): the upload
-    // below must not overwrite it first
-    if (p->tail_pending) SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->up, p->ev_tail, 0));
-    p->tail_pending = false;
-    if (tail > 0) {
-        SDRHIP_CHECK_HIP(hipMemcpyAsync(next.p, (const char*)prev.p + (size_t)(keep_from - p->base) * ein,
-                                        (size_t)tail * ein, hipMemcpyDeviceToDevice, p->stream));
-        SDRHIP_CHECK_HIP(hipEventRecord(p->ev_tail, p->stream));
-        p->tail_pending = true;
-    }
-    // `next` was last read by the kernels of push i-2, which has been harvested, so the
-    // upload may start while push i-1's kernels are still running on the compute stream
-    SDRHIP_CHECK_HIP(hipMemcpyAsync((char*)next.p + (size_t)tail * ein, sl.hin.p, (size_t)n * ein,
-                                    hipMemcpyHostToDevice, p->up));
-    SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, p->up));
-    SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->stream, sl.ev_up, 0));
-    p->cur ^= 1;
-    p->base = tail > 0 ? keep_from : E_prev;
-    p->have = tail + n;
+    // (not reached: FIR-like stages return through fir_like_push above)
+    return SDRHIP_ERR_STATE;
+}
 
-    const int64_t n_out = m_end - p->m_done;
-    if ((rc = sl.dout.ensure((size_t)n_out * eout)) != SDRHIP_OK) return rc;
-    if ((rc = sl.hout.ensure((size_t)n_out * eout)) != SDRHIP_OK) return rc;
-    float* dout = (float*)sl.dout.p;
-    const float* din = (const float*)next.p;
-    const int64_t ncross = m_split - p->m_done;
-    if (p->kind == PK_RESAMPLER) {
-        if (ncross > 0 && (rc = resamp_run(p->rs, p->stream, din, p->base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
-        if ((rc = resamp_run(p->rs, p->stream, din, p->base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
-    } else {
-        if (ncross > 0 && (rc = fir_run(p->fir, p->stream, din, false, p->base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
-        if ((rc = fir_run(p->fir, p->stream, din, false, p->base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
-    }
-    SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, p->stream));
-    SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->down, sl.ev_k, 0));
-    SDRHIP_CHECK_HIP(hipMemcpyAsync(sl.hout.p, sl.dout.p, (size_t)n_out * eout, hipMemcpyDeviceToHost, p->down));
-    SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, p->down));
-    sl.n_out = n_out * p->esz_out();
-    sl.busy = true;
-    p->m_done = m_end;
-    p->E_prev = E;
-    p->pushes++;
-    if ((rc = harvest(p, si ^ 1)) != SDRHIP_OK) return rc;
-    return ready_blocks(p);
+int sdrhip_pipe_set_coalesce(sdrhip_pipe* p, int blocks)
+{
+    SDRHIP_REQUIRE(p != nullptr && blocks >= 0, "sdrhip_pipe_set_coalesce");
+    SDRHIP_REQUIRE(!p->is_map(), "sdrhip_pipe_set_coalesce: filter / decimator / resampler pipes only");
+    SDRHIP_REQUIRE(p->staged == 0, "sdrhip_pipe_set_coalesce: blocks are staged (flush first)");
+    p->coalesce = blocks;
+    return SDRHIP_OK;
+}
+
+float* sdrhip_pipe_input_buffer(sdrhip_pipe* p, int n)
+{
+    if (p == nullptr || n <= 0 || p->is_map()) { set_error("sdrhip_pipe_input_buffer: filter / decimator / resampler pipes, n > 0"); return nullptr; }
+    const bool coalescing = p->coalesce > 1 && p->all_uniform && (p->uniform_n == 0 || p->uniform_n == n);
+    if (!coalescing && p->staged > 0 && fir_submit(p, p->staged, p->uniform_n) != SDRHIP_OK) return nullptr;
+    const int cap = coalescing && p->uniform_n ? p->coalesce * p->uniform_n : n;
+    if (fir_open_slot(p, (size_t)(cap > p->staged + n ? cap : p->staged + n)) != SDRHIP_OK) return nullptr;
+    return (float*)p->slot[p->pushes & 1].hin.p + (size_t)p->staged * p->esz_in();
 }
 
 int sdrhip_pipe_flush(sdrhip_pipe* p)
 {
     SDRHIP_REQUIRE(p != nullptr, "sdrhip_pipe_flush");
     int rc;
+    if (p->staged > 0 && (rc = fir_submit(p, p->staged, p->uniform_n)) != SDRHIP_OK) return rc;
     // oldest first
     int first = (int)(p->pushes & 1);
     if ((rc = harvest(p, first)) != SDRHIP_OK) return rc;

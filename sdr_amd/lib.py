@@ -144,6 +144,9 @@ lib.sdrhip_pipe_fir_decimator.argtypes = [C.POINTER(_vp), _vp, C.c_int]
 lib.sdrhip_pipe_fir_resampler.argtypes = [C.POINTER(_vp), _vp, C.c_int]
 lib.sdrhip_pipe_fm_demod.argtypes = [C.POINTER(_vp)]
 lib.sdrhip_pipe_dc_blocker.argtypes = [C.POINTER(_vp)]
+lib.sdrhip_pipe_set_coalesce.argtypes = [_vp, C.c_int]
+lib.sdrhip_pipe_input_buffer.argtypes = [_vp, C.c_int]
+lib.sdrhip_pipe_input_buffer.restype = _vp
 lib.sdrhip_pipe_push.argtypes = [_vp, _f32p, C.c_int]
 lib.sdrhip_pipe_flush.argtypes = [_vp]
 lib.sdrhip_pipe_pop.argtypes = [_vp, _f32p, C.c_int]
@@ -473,6 +476,16 @@ class Pipe(_Handle):
         self._cap = max(getattr(self, "_cap", 0), self.block_size_out, n)
         ready = check(lib.sdrhip_pipe_push(self.h, _fp(b), n), "sdrhip_pipe_push")
         return self._pop(ready)
+
+    def set_coalesce(self, blocks):
+        check(lib.sdrhip_pipe_set_coalesce(self.h, blocks), "sdrhip_pipe_set_coalesce")
+
+    def input_buffer(self, n):
+        """numpy view (n elements; interleaved pairs for complex stages) of the pinned staging memory of the next push."""
+        ptr = lib.sdrhip_pipe_input_buffer(self.h, n)
+        if not ptr:
+            raise SdrHipError(lib.sdrhip_last_error().decode())
+        return np.ctypeslib.as_array(C.cast(ptr, _f32p), shape=(n * (2 if self.complex_in else 1),))
 
     def flush(self):
         ready = check(lib.sdrhip_pipe_flush(self.h), "sdrhip_pipe_flush")

@@ -227,3 +227,63 @@ def test_filter_pipe_random_sweep(hip, oracle):
         _cmp(_drive(hip.firFilter(f, bso), blocks), exp, f"trial {trial}: kind {kind}, {taps.size} taps, order {order}")
         ran += 1
     assert ran >= 20
+
+
+def test_uniform_block_pipes_coalesced_sweep(hip, oracle):
+    """Equal-sized blocks (the reference's normal diet): every push on its own, coalesced k at a time, and through the
+    zero-copy staging buffer -- then a block of another size ends the uniform run.  Same output blocks every way."""
+    rng = np.random.default_rng(80)
+    ran = 0
+    for trial in range(30 * SWEEP_SCALE):
+        kind = ["decimator", "resampler", "symfilter"][rng.integers(0, 3)]
+        order = [PM.ORDER_AVX, PM.ORDER_SSE][rng.integers(0, 2)]
+        complex_ = bool(rng.integers(0, 2)) and kind != "symfilter"
+        w = 2 if complex_ else 1
+        U = int(rng.choice([1024, 2048, 4096, 8192]))
+        nblk = int(rng.integers(6, 20))
+        ragged_tail = [int(rng.integers(U // 2 + 300, 2 * U))] if rng.integers(0, 2) else []
+        sizes = [U] * nblk + ragged_tail + ([U] * 2 if ragged_tail else [])
+        x = S.cfloat_block(sum(sizes), seed=1200 + trial) if complex_ else S.real_block(sum(sizes), seed=1200 + trial)
+        blocks = _cut(x, w, sizes)
+        bso = int(rng.integers(100, 3000))
+        try:
+            if kind == "decimator":
+                taps = S.gauss_taps(int(rng.integers(4, 200)), 1300 + trial)
+                factor = int(rng.integers(1, min(taps.size, 16) + 1))
+                exp, _ = PM.fir_decimator_pipe(PM.FilterModel(oracle, taps, order, complex_=complex_, factor=factor), blocks, bso)
+                mk = lambda: hip.firDecimator(hip.Decimator(factor, taps, order, complex_=complex_), bso)
+            elif kind == "resampler":
+                while True:
+                    I, D = int(rng.integers(1, 7)), int(rng.integers(2, 24))
+                    if D > I and np.gcd(I, D) == 1:
+                        break
+                simd = 8 if order == PM.ORDER_AVX else 4
+                ntaps = int(rng.integers(I + 1, 30 * I))
+                if -(-ntaps // (I * simd)) * (I * simd) < D:
+                    ntaps = D + int(rng.integers(0, 10))
+                taps = S.gauss_taps(ntaps, 1300 + trial)
+                exp, _ = PM.fir_resampler_pipe(PM.ResamplerModel(oracle, I, D, taps, order, complex_), blocks, bso)
+                mk = lambda: hip.firResampler(hip.Resampler(I, D, taps, order, complex_), bso)
+            else:
+                simd = 8 if order == PM.ORDER_AVX else 4
+                half = S.gauss_taps(simd * int(rng.integers(1, 12)), 1300 + trial)
+                exp, _ = PM.fir_filter_pipe(PM.FilterModel(oracle, half, order, sym=True), blocks, bso)
+                mk = lambda: hip.firFilter(hip.Filter(half, order, sym=True), bso)
+        except PM.PipeAssert:
+            continue
+        label = f"trial {trial}: {kind}, order {order}, complex {complex_}, U {U}, {nblk} blocks, tail {ragged_tail}"
+        _cmp(_drive(mk(), blocks), exp, label + " (push by push)")
+        pipe = mk()
+        pipe.set_coalesce(int(rng.integers(2, 9)))
+        got = []
+        for i, b in enumerate(blocks):
+            if i % 3 == 1:
+                view = pipe.input_buffer(b.size // w)
+                view[:] = b
+                got += pipe.push(view)
+            else:
+                got += pipe.push(b)
+        got += pipe.flush()
+        _cmp(got, exp, label + " (coalesced, zero-copy every third push)")
+        ran += 1
+    assert ran >= 20

@@ -121,6 +121,30 @@ def resampler_pipe_cfg4(nblocks=256):
     print(f"firResampler Pipe 3/10 on 65536-sample host blocks: {nblocks * 65536 / dt / 1e6:10.1f} Msamples/s ({dt / nblocks * 1e6:.1f} us/block)")
 
 
+def pipes_coalesced():
+    """Level-1 operators fed the reference's block sizes, coalesced inside the operator, zero-copy staging."""
+    cases = [("firDecimator /8 128 taps, 8192-sample cfloat blocks", lambda: L.firDecimator(L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True), B), 8192, 2),
+             ("firResampler 3/10 191 taps, 65536-float blocks (configs[3])", lambda: L.firResampler(L.Resampler(3, 10, S.taps_resamp191(), L.ORDER_AVX), 8192), 65536, 1),
+             ("firFilter 64 half-taps symmetric, 8192-float blocks", lambda: L.firFilter(L.Filter(S.taps_audio_half64(), L.ORDER_AVX, sym=True), B), 8192, 1)]
+    for name, mk, n, w in cases:
+        for co in (1, 16, 128):
+            pipe = mk()
+            if co > 1:
+                pipe.set_coalesce(co)
+            src = np.random.default_rng(5).uniform(-1, 1, n * w).astype(np.float32)
+            for _ in range(2 * co + 4):
+                pipe.push(src)
+            pushes = max(256, 8 * co)
+            t0 = time.perf_counter()
+            for _ in range(pushes):
+                v = pipe.input_buffer(n)
+                v[:] = src                       # the source writes into pinned memory (here: a host memcpy)
+                pipe.push(v)
+            pipe.flush()
+            dt = time.perf_counter() - t0
+            print(f"{name}, coalesce {co:3d}: {pushes * n / dt / 1e6:9.1f} M elements/s ({dt / pushes * 1e6:.1f} us/push)")
+
+
 if __name__ == "__main__":
     print(L.device_name())
     chain_streamed()
@@ -129,4 +153,5 @@ if __name__ == "__main__":
     for cb in (4, 16, 64):
         fm_stream_coalesced(cb)
     pipe_blocks()
+    pipes_coalesced()
     resampler_pipe_cfg4()
