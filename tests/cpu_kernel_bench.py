@@ -1,7 +1,7 @@
 """Single-thread rates of the reference's own C kernels (oracle/_ref) on this host, at the block sizes of
 BASELINE.json's configs: what one pipeline thread of the reference sustains per stage."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # lives under tests/: only tests, smoke() and bench.py's cpu_baseline may touch oracle/
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from oracle.oracle import Oracle, Ref, have_ref
