@@ -24,6 +24,8 @@
 #include "crossfix.hpp"
 #include "kernels.hpp"
 
+// Tuning knobs (build with SDRHIP_SPLIT_DEFS="-DSPLIT_CB=2 ..." to experiment; DESIGN.md lists what was measured):
+// chunks per guarded block, input-span bytes per tile, outputs per lane.
 #ifndef SPLIT_CB
 #define SPLIT_CB 4
 #endif
@@ -32,9 +34,6 @@
 #endif
 #ifndef SPLIT_U
 #define SPLIT_U 2
-#endif
-#ifndef SPLIT_PIPE
-#define SPLIT_PIPE 1
 #endif
 
 namespace sdrhip {
