@@ -17,9 +17,16 @@ EXE = os.path.join(ROOT, "examples", "bin", "fm_replay")
 B = 8192
 
 
+def _ensure_exe():
+    if not os.path.exists(EXE):
+        from sdr_amd import build as B
+        B.build()                      # builds the library if needed and the plain-C examples (gcc)
+    assert os.path.exists(EXE), "examples/bin/fm_replay missing: run `python -m sdr_amd.build`"
+
+
 @pytest.mark.parametrize("blocks_per_push", [1, 7, 64])
 def test_fm_replay_matches_reference_pipeline(tmp_path, oracle, blocks_per_push):
-    assert os.path.exists(EXE), "examples/bin/fm_replay missing: run `python -m sdr_amd.build`"
+    _ensure_exe()
     nblk = 100
     u8 = S.iq_u8_fm(nblk * B)
     cap = tmp_path / "capture.u8"
@@ -60,6 +67,7 @@ def test_library_before_torch_in_one_process():
 def _udp_attempt(tmp_path, u8, prefix, attempt):
     import socket
     import time
+    _ensure_exe()
     out = tmp_path / f"audio_udp_{attempt}.f32"
     probe = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
     probe.bind(("127.0.0.1", 0))
