@@ -169,7 +169,20 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+                probe = torch.zeros(1, device="cuda")
+                dist.all_reduce(probe)               # creates the communicator now: an RCCL problem shows up here, not mid-run
+                torch.cuda.synchronize()
+            except Exception as e:                   # noqa: BLE001 -- SURVEY 8(e) fallback: same halos through host memory
+                sys.stderr.write(f"bench: RCCL initialisation failed ({e!r}); falling back to gloo (halo through host memory)\n")
+                try:
+                    dist.destroy_process_group()
+                except Exception:                    # noqa: BLE001
+                    pass
+                backend = "gloo"
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
@@ -223,8 +236,17 @@ def main():
 
     # Clock / power-state ramp: the first ~15 ms of sustained work on a fresh process run 10 % slow
     # (interleaved A/B in tools/pipeline_test.py); spin the same step for ~0.3 s before the W warmup steps.
+    # With several ranks every step is a send/recv with the neighbours, so all ranks must run the SAME number of steps: the
+    # decision to go on is taken collectively (a time-based loop per rank can differ by one step and then deadlocks).
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.3:
+    while True:
+        go = time.perf_counter() - t_ramp < 0.3
+        if world > 1:
+            flag = torch.tensor([1 if go else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            go = bool(flag.item())
+        if not go:
+            break
         step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
