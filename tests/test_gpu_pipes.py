@@ -106,9 +106,11 @@ def test_pipe_short_block_asserts(hip, oracle):
         PM.fir_filter_pipe(PM.FilterModel(oracle, S.gauss_taps(128, 1), PM.ORDER_AVX), [S.real_block(100)], 256)
 
 
-def test_fm_receiver_as_composed_pipes(hip, oracle):
-    """fm.hs:34-41 composed from the four Pipe operators, host blocks end to end."""
-    nblk = 60
+@pytest.mark.parametrize("coalesce", [0, 4])
+def test_fm_receiver_as_composed_pipes(hip, oracle, coalesce):
+    """fm.hs:34-41 composed from the four Pipe operators, host blocks end to end (INTEGRATION.md level 1), push by push
+    and with the operators coalescing their equal-sized input blocks."""
+    nblk = 100 if coalesce else 60
     u8 = S.iq_u8_fm(nblk * B)
     blocks = [u8[2 * i * B:2 * (i + 1) * B] for i in range(nblk)]
     exp = PM.fm_receiver(oracle, blocks, S.taps_decim127(), 8, S.taps_resamp191(), 3, 10, S.taps_audio_half64(), 0.2)
@@ -117,6 +119,9 @@ def test_fm_receiver_as_composed_pipes(hip, oracle):
     demod = hip.fmDemod()
     resp = hip.firResampler(hip.Resampler(3, 10, S.taps_resamp191(), hip.ORDER_AVX), B)
     filt = hip.firFilter(hip.Filter(S.taps_audio_half64(), hip.ORDER_AVX, sym=True), B)
+    if coalesce:
+        for pipe in (deci, resp, filt):
+            pipe.set_coalesce(coalesce)
     audio = []
 
     def feed(stage_idx, blk, stages):
