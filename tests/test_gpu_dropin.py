@@ -163,7 +163,7 @@ def test_resample_config4(hip, oracle, ref):
 
 
 def test_fm_demod(hip, oracle):
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SWEEP_SEED)
     x = rng.uniform(-1, 1, 2 * 100000).astype(np.float32)
     # special values: zeros, negative zeros, axes, repeated samples, denormals, huge ratios
     sp = np.array([0, 0, -0.0, 0, 0, -0.0, -0.0, -0.0, 1, 0, -1, 0, 0, 1, 0, -1, -1, -0.0, 1e-40, 1e-40,
@@ -222,12 +222,13 @@ def test_reference_test_suite_maximum_size(hip, oracle):
 
 
 SWEEP_SCALE = max(1, int(__import__("os").environ.get("SDRHIP_SWEEP_SCALE", "1")))
+SWEEP_SEED = int(__import__("os").environ.get("SDRHIP_SWEEP_SEED", "0"))        # other seeds for soak runs
 
 
 def test_dropin_random_sweep_against_the_reference_build(hip, oracle, ref):
     """Every drop-in filter / decimator / resampler symbol with seeded random shapes, straight against the reference's
     own compiled C (oracle/_ref) -- no restatement in between."""
-    rng = np.random.default_rng(31337)
+    rng = np.random.default_rng(31337 + SWEEP_SEED)
     fir = [  # (symbol, complex, taps multiple, duplicated, symmetric)
         ("RR", False, 1, False, False), ("SSERR", False, 4, False, False), ("AVXRR", False, 8, False, False),
         ("SSESymmetricRR", False, 4, False, True), ("AVXSymmetricRR", False, 8, False, True),

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 # SDRHIP_SWEEP_SCALE=20 turns the seeded random sweeps into a soak test (more trials, same seeds first)
 SWEEP_SCALE = max(1, int(__import__("os").environ.get("SDRHIP_SWEEP_SCALE", "1")))
+SWEEP_SEED = int(__import__("os").environ.get("SDRHIP_SWEEP_SEED", "0"))        # other seeds for soak runs
 
 B = 8192
 
@@ -146,7 +147,7 @@ def test_fm_receiver_as_composed_pipes(hip, oracle, coalesce):
 def test_resampler_pipe_random_sweep(hip, oracle):
     """Seeded random resampler Pipes on ragged host blocks, short filters included: where the first output that no longer
     fits a block already starts in the next one the reference Pipe does not cross over (Filter.hs:707-709)."""
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SWEEP_SEED)
     ran = 0
     for trial in range(40 * SWEEP_SCALE):
         complex_ = bool(rng.integers(0, 2))
@@ -179,7 +180,7 @@ def test_resampler_pipe_random_sweep(hip, oracle):
 
 
 def test_decimator_pipe_random_sweep(hip, oracle):
-    rng = np.random.default_rng(78)
+    rng = np.random.default_rng(78 + SWEEP_SEED)
     ran = 0
     for trial in range(30 * SWEEP_SCALE):
         complex_ = bool(rng.integers(0, 2))
@@ -204,7 +205,7 @@ def test_decimator_pipe_random_sweep(hip, oracle):
 
 def test_filter_pipe_random_sweep(hip, oracle):
     """firFilter on ragged host blocks: plain real / complex and symmetric real filters, all orders."""
-    rng = np.random.default_rng(79)
+    rng = np.random.default_rng(79 + SWEEP_SEED)
     ran = 0
     for trial in range(30 * SWEEP_SCALE):
         order = [PM.ORDER_AVX, PM.ORDER_SSE, PM.ORDER_SCALAR][rng.integers(0, 3)]
@@ -237,7 +238,7 @@ def test_filter_pipe_random_sweep(hip, oracle):
 def test_uniform_block_pipes_coalesced_sweep(hip, oracle):
     """Equal-sized blocks (the reference's normal diet): every push on its own, coalesced k at a time, and through the
     zero-copy staging buffer -- then a block of another size ends the uniform run.  Same output blocks every way."""
-    rng = np.random.default_rng(80)
+    rng = np.random.default_rng(80 + SWEEP_SEED)
     ran = 0
     for trial in range(30 * SWEEP_SCALE):
         kind = ["decimator", "resampler", "symfilter"][rng.integers(0, 3)]
