@@ -25,6 +25,13 @@ struct sdrhip_fm_chain {
     FirDesc audio;     // symmetric real
     float gain = 1.0f;
     int64_t block = 0;
+    // The fused convert + decimate kernel (k_decimate_c4) covers the AVX order, decimation 8, up to 128 taps.  Any other
+    // first stage converts the u8 IQ to cfloat in the workspace first (convert.c as its own kernel, 10 B per sample) and
+    // then runs the tiled cfloat decimator -- two passes, but not the one-thread-per-output u8 fallback.
+    bool fused_first_stage() const
+    {
+        return decim.corder == CO_L4 && decim.factor == 8 && decim.Lp >= 8 && decim.Lp <= 128 && decim.Lp % 4 == 0;
+    }
 
     // Optional software pipelining inside one run (sdrhip_fm_chain_set_pipelining): the outputs are cut
     // into `nsub` sub-batches; the decimate kernel of sub-batch i+1 runs on the caller's stream while
@@ -196,13 +203,15 @@ size_t sdrhip_fm_chain_workspace_bytes(const sdrhip_fm_chain* c, int64_t n_in)
     int64_t nk = n_in / c->decim.factor + 4;
     int64_t nm = nk * c->resamp.I / c->resamp.D + 4;
     // + the overlap each of the (up to 16) sub-batches recomputes and its alignment padding
-    return align_up((size_t)nk * 8, 256) + align_up((size_t)nk * 4, 256) + align_up((size_t)nm * 4, 256) + 256 + 16 * (64 << 10);
+    const size_t conv = c->fused_first_stage() ? 0 : align_up((size_t)(n_in + 16) * 8, 256) + 16 * align_up((size_t)(c->decim.Lp + 16) * 8, 256);
+    return conv + align_up((size_t)nk * 8, 256) + align_up((size_t)nk * 4, 256) + align_up((size_t)nm * 4, 256) + 256 + 16 * (64 << 10);
 }
 
 namespace {
 struct SubRange {
     int64_t q0, q1, m0, m1, ky0, ky1, kd0, kd1;
-    size_t off_d, off_y, off_z;
+    size_t off_x, off_d, off_y, off_z;   // converted input (unfused first stage only), decimated, demodulated, resampled
+    int64_t xa, xb;                      // samples [xa, xb) of the stream are converted into off_x
 };
 }  // namespace
 
@@ -233,6 +242,14 @@ int sdrhip_fm_chain_run(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
         r.ky1 = c->resamp.in_offset(r.m1 - 1) + c->y_reach();                           // demod outputs
         r.kd0 = r.ky0 > 0 ? r.ky0 - 1 : 0;                                               // decimator outputs
         r.kd1 = r.ky1;
+        r.off_x = off;
+        r.xa = r.xb = 0;
+        if (!c->fused_first_stage()) {
+            const int64_t a = r.kd0 * c->decim.factor;
+            r.xa = s0 + ((a - s0) & ~(int64_t)7);                   // 16-byte aligned in the u8 stream
+            r.xb = (r.kd1 - 1) * c->decim.factor + c->decim.Lp;
+            off += align_up((size_t)(r.xb - r.xa) * 8, 256);
+        }
         r.off_d = off;
         r.off_y = r.off_d + align_up((size_t)(r.kd1 - r.kd0) * 8, 256);
         r.off_z = r.off_y + align_up((size_t)(r.ky1 - r.ky0) * 4, 256);
@@ -291,7 +308,13 @@ int sdrhip_fm_chain_run(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
         hipEvent_t b = nullptr;
         // K1+K2 on the caller's stream: u8 -> cfloat -> decimate (convert.c:37-50 fused into decimate.c:105-113)
         if ((rc = begin_span(0, s, &b)) != SDRHIP_OK) return rc;
-        if ((rc = fir_run(&c->decim, s, d_in_iq, true, s0, d_d, r.kd0, r.kd1, c->block)) != SDRHIP_OK) return rc;
+        if (c->fused_first_stage()) {
+            if ((rc = fir_run(&c->decim, s, d_in_iq, true, s0, d_d, r.kd0, r.kd1, c->block)) != SDRHIP_OK) return rc;
+        } else {
+            float* d_x = (float*)(ws + r.off_x);
+            launch_convert_u8(s, d_in_iq + 2 * (r.xa - s0), d_x, 2 * (r.xb - r.xa));
+            if ((rc = fir_run(&c->decim, s, d_x, false, r.xa, d_d, r.kd0, r.kd1, c->block)) != SDRHIP_OK) return rc;
+        }
         if ((rc = end_span(0, s, b)) != SDRHIP_OK) return rc;
         if (two_streams) {
             SDRHIP_CHECK_HIP(hipEventRecord(c->ev_k2[i], s));

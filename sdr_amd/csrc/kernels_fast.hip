@@ -66,12 +66,16 @@ __device__ __forceinline__ typename TapVec<TC>::type load_tap_chunk(const float*
 // They arrive 8 at a time, one chunk ahead of first use: a scalar-load wait is a
 // full lgkmcnt(0) drain (SMEM returns out of order) that also stalls the LDS
 // pipeline, so there must be few of them -- P/8 per tile instead of one per tap pair.
-template <int D, int P, int R, class T>
-__device__ __forceinline__ void mac_window(const float2* __restrict__ win, const float* __restrict__ taps, float2 (&acc)[R][4])
+// GUARD: the filter actually has nch_eff * TC <= P taps (run-time, wave-uniform); blocks and (block, output) pairs that
+// only meet taps beyond them are skipped, so one instantiation serves every shorter filter with exactly the arithmetic of
+// an exact-length kernel (nothing is multiplied by padding).
+template <int D, int P, int R, class T, int TC, bool GUARD>
+__device__ __forceinline__ void mac_window(const float2* __restrict__ win, const float* __restrict__ taps, float2 (&acc)[R][4],
+                                           int nch_eff)
 {
-    constexpr int TC = (P % 8 == 0) ? 8 : 4;    // taps per scalar load == samples per block
-    static_assert(P % TC == 0 && T::WIN % TC == 0, "window and taps are walked in blocks of TC");
+    static_assert(P % TC == 0 && T::WIN % TC == 0 && D % TC == 0, "window and taps are walked in blocks of TC");
     constexpr int NCH = P / TC;
+    const int nb_eff = GUARD ? nch_eff + (R - 1) * (D / TC) : 0;   // sample blocks that still meet a live tap
     constexpr int NB = T::WIN / TC;             // sample blocks per thread
     typename TapVec<TC>::type tc[NCH];
     float4 buf[2][TC / 2];                      // LDS reads are double-buffered one block ahead
@@ -80,8 +84,9 @@ __device__ __forceinline__ void mac_window(const float2* __restrict__ win, const
     for (int i = 0; i < TC / 2; i++) buf[0][i] = *reinterpret_cast<const float4*>(&win[2 * i + 2 * ((2 * i) / T::CHUNK)]);
 #pragma unroll
     for (int b = 0; b < NB; b++) {
+        if (GUARD && b >= nb_eff) continue;         // wave-uniform: nothing left for this block
         // the fence inside load_tap_chunk keeps these reads (block b+1) here, ahead of block b's MACs
-        if (b + 1 < NCH) tc[b + 1] = load_tap_chunk<TC>(taps, b + 1);
+        if (b + 1 < NCH && (!GUARD || b + 1 < nch_eff)) tc[b + 1] = load_tap_chunk<TC>(taps, b + 1);   // never past the filter's own taps
         else asm volatile("" ::: "memory");
         if (b + 1 < NB) {
 #pragma unroll
@@ -90,20 +95,43 @@ __device__ __forceinline__ void mac_window(const float2* __restrict__ win, const
                 buf[(b + 1) & 1][i] = *reinterpret_cast<const float4*>(&win[s + 2 * (s / T::CHUNK)]);
             }
         }
+        if constexpr (!GUARD) {
 #pragma unroll
-        for (int i = 0; i < TC / 2; i++) {
-            const float4 v2 = buf[b & 1][i];
-            const float2 v[2] = {make_float2(v2.x, v2.y), make_float2(v2.z, v2.w)};
+            for (int i = 0; i < TC / 2; i++) {
+                const float4 v2 = buf[b & 1][i];
+                const float2 v[2] = {make_float2(v2.x, v2.y), make_float2(v2.z, v2.w)};
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const int ss = TC * b + 2 * i + e;
+                for (int e = 0; e < 2; e++) {
+                    const int ss = TC * b + 2 * i + e;
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int j = ss - r * D;
-                    if (j >= 0 && j < P) {
-                        const float h = tc[j / TC][j % TC];
-                        acc[r][j & 3].x = acc[r][j & 3].x + h * v[e].x;
-                        acc[r][j & 3].y = acc[r][j & 3].y + h * v[e].y;
+                    for (int r = 0; r < R; r++) {
+                        const int j = ss - r * D;
+                        if (j >= 0 && j < P) {
+                            const float h = tc[j / TC][j % TC];
+                            acc[r][j & 3].x = acc[r][j & 3].x + h * v[e].x;
+                            acc[r][j & 3].y = acc[r][j & 3].y + h * v[e].y;
+                        }
+                    }
+                }
+            }
+        } else {
+            // output r meets tap chunk cb = b - r*D/TC in this block: live iff 0 <= cb < nch_eff (per output the taps are
+            // still walked in increasing order, which is all the summation order asks for)
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int cb = b - r * (D / TC);
+                if (cb < 0 || cb >= NCH) continue;
+                if (cb >= nch_eff) continue;        // wave-uniform
+#pragma unroll
+                for (int i = 0; i < TC / 2; i++) {
+                    const float4 v2 = buf[b & 1][i];
+                    const float2 v[2] = {make_float2(v2.x, v2.y), make_float2(v2.z, v2.w)};
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const int jj = 2 * i + e;   // tap cb*TC + jj
+                        const float h = tc[cb][jj];
+                        acc[r][jj & 3].x = acc[r][jj & 3].x + h * v[e].x;
+                        acc[r][jj & 3].y = acc[r][jj & 3].y + h * v[e].y;
                     }
                 }
             }
@@ -187,9 +215,10 @@ struct Stage {
     }
 };
 
-template <int D, int P, int R, int NT, bool U8>
+template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false>
 __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in, int64_t x0 /* sample index of output 0's window in `in` */,
-                                                    int count, const float* __restrict__ taps, float* __restrict__ out)
+                                                    int count, const float* __restrict__ taps, float* __restrict__ out,
+                                                    int p_eff /* GUARD: taps of the filter (multiple of TC, <= P); else unused */)
 {
     using T = Tile<D, P, R, NT>;
     static_assert(D % 4 == 0, "lane of a tap must not depend on the output within a thread");
@@ -207,7 +236,7 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
     if (tile >= ntiles) return;
     const int out0 = tile * T::OUTS;
     const int64_t s0 = (int64_t)out0 * D;                     // first sample of the tile, relative to x0
-    const int64_t total_avail = (int64_t)(count - 1) * D + P; // samples that exist from x0 on
+    const int64_t total_avail = (int64_t)(count - 1) * D + (GUARD ? p_eff : P); // samples that exist from x0 on
     int64_t av = total_avail - s0;
     int avail = av > T::SPAN ? T::SPAN : (int)av;
 
@@ -227,7 +256,7 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
 #pragma unroll
         for (int k = 0; k < 4; k++) acc[r][k] = make_float2(0.0f, 0.0f);
 
-    mac_window<D, P, R, T>(win, taps, acc);
+    mac_window<D, P, R, T, TC, GUARD>(win, taps, acc, GUARD ? p_eff / TC : 0);
 
     const int o = out0 + threadIdx.x * R;
     float2 res[R];
@@ -252,11 +281,13 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
 // windows that overlap almost entirely, so a group of PER threads stages their union
 // (Lp + (PER-1)*D samples, converted once) in LDS with coalesced loads and each
 // thread then walks its own window.  SPW seams per workgroup.
-template <bool U8, int D, int LP, int PER, int SPW>
+template <bool U8, int D, int LP, int PER, int SPW, bool RT = false>
 __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const float* __restrict__ xtaps,
                                                                    const void* __restrict__ in, float* __restrict__ out,
                                                                    int64_t first_seam, int nseams)
 {
+    // RT: the filter has g.Lp <= LP taps (run-time); the staging layout is still the one of LP taps
+    const int lp = RT ? g.Lp : LP;
     static_assert(D == 8 && PER == 16 && LP <= 128, "LDS layout below is worked out for 16 candidate slots 8 samples apart");
     constexpr int UNI = LP + (PER - 1) * D;          // samples in the union of one seam's windows
     // layout: one float2 of padding after every 8 samples (candidate c then starts at 9c float2 = 18c
@@ -267,7 +298,7 @@ __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const
     __shared__ float2 lds[SPW * ROW];
     const int tid = threadIdx.x;
     const int seam0 = blockIdx.x * SPW;
-    const int64_t lo = g.k_begin * D - g.in_base, hi = (g.k_begin + g.count - 1) * (int64_t)D + LP - g.in_base;
+    const int64_t lo = g.k_begin * D - g.in_base, hi = (g.k_begin + g.count - 1) * (int64_t)D + lp - g.in_base;
     {
         // staging: the PER lanes of a seam load its union with 16-byte vectors, all seams of the
         // workgroup at once (one HBM round trip).  The union starts at a multiple of 8 samples, i.e.
@@ -334,25 +365,34 @@ __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const
     const int64_t m = m_hi - (PER - 1) + ci;
     if (m < g.k_begin || m >= g.k_begin + g.count) return;
     const int64_t vm = m * D;
-    if (!(vm < edge && vm + LP > edge)) return;
+    if (!(vm < edge && vm + lp > edge)) return;
     const float2* w = lds + sl * ROW + ci * (D + 1);
     float re = 0.0f, im = 0.0f;
+    if constexpr (RT) {
+        for (int j = 0; j < lp; j++) {
+            const float2 x = w[j + j / 8];
+            const float h = xtaps[j];
+            re = re + x.x * h;
+            im = im + x.y * h;
+        }
+    } else {
 #pragma unroll
-    for (int j = 0; j < LP; j++) {
-        const float2 x = w[j + j / 8];
-        const float h = xtaps[j];
-        re = re + x.x * h;
-        im = im + x.y * h;
+        for (int j = 0; j < LP; j++) {
+            const float2 x = w[j + j / 8];
+            const float h = xtaps[j];
+            re = re + x.x * h;
+            im = im + x.y * h;
+        }
     }
     *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
 }
 
-template <int D, int P, int R, int NT, bool U8>
+template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false>
 void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, float* out)
 {
     using T = Tile<D, P, R, NT>;
     static std::atomic<bool> attr_set{false};   // idempotent: a race only repeats the call
-    auto kern = k_decimate_c4<D, P, R, NT, U8>;
+    auto kern = k_decimate_c4<D, P, R, NT, U8, TC, GUARD>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)T::LDS_BYTES);
@@ -361,7 +401,7 @@ void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, 
     int tiles = (g.count + T::OUTS - 1) / T::OUTS;
     int grid = ((tiles + 63) / 64) * 64;       // whole groups of 64: the kernel permutes blockIdx -> tile within a group
     int64_t x0 = g.k_begin * D - g.in_base;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, taps, out);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, taps, out, g.Lp);
 }
 
 }  // namespace
@@ -370,7 +410,10 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
                              const void* d_in, bool in_is_u8, float* d_out)
 {
     if (g.I != 1 || g.count <= 0 || g.seamBI < 0) return false;
-    if (!(g.D == 8 && (P == 128 || P == 52) && g.Lp == P)) return false;
+    // exact kernels for 128 and 52 taps; every other length up to 128 (multiples of 4: mkDecimatorC pads to that) runs on
+    // the 128-tap kernel with run-time guards that skip the tap blocks the shorter filter does not have
+    if (!(g.D == 8 && P >= 8 && P <= 128 && P % 4 == 0 && g.Lp == P)) return false;
+    const bool guarded = !(P == 128 || P == 52);
     if (g.seamBI != 0 && d_cross_taps == nullptr) return false;
     int64_t x0 = g.k_begin * g.D - g.in_base;
     // vector loads need 16-byte aligned tile starts (tiles begin at multiples of 8 samples from x0)
@@ -385,7 +428,15 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
     // R = 4 (the compiler's SGPR allocation for the sliding tap window collapses into spills), 512-thread
     // workgroups (same rate), and a persistent kernel that prefetches the next tile into registers during the
     // MAC phase (same rate: with random data the kernel is power/clock-limited, the exposed load phase is ~4 %).
-    if (P == 52) {
+    if (guarded) {
+        if (P % 8 == 0) {
+            if (in_is_u8) launch_c4<8, 128, 2, 256, true, 8, true>(s, g, d_plain_taps, d_in, d_out);
+            else launch_c4<8, 128, 2, 256, false, 8, true>(s, g, d_plain_taps, d_in, d_out);
+        } else {
+            if (in_is_u8) launch_c4<8, 128, 2, 256, true, 4, true>(s, g, d_plain_taps, d_in, d_out);
+            else launch_c4<8, 128, 2, 256, false, 4, true>(s, g, d_plain_taps, d_in, d_out);
+        }
+    } else if (P == 52) {
         // the tap count of the reference FM example's RF decimation filter (51 -> 52)
         if (in_is_u8) launch_c4<8, 52, 2, 256, true>(s, g, d_plain_taps, d_in, d_out);
         else launch_c4<8, 52, 2, 256, false>(s, g, d_plain_taps, d_in, d_out);
@@ -404,7 +455,10 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
             constexpr int PER = 16, SPW = 16;          // 16 candidate slots per seam (ceil((128-1)/8))
             dim3 grid((nseams + SPW - 1) / SPW), block(PER * SPW);
 #define FIX(U, LPV) hipLaunchKernelGGL((k_decimate_c_crossfix<U, 8, LPV, PER, SPW>), grid, block, 0, s, g, d_cross_taps, d_in, d_out, first, nseams)
-            if (P == 52) { if (in_is_u8) FIX(true, 52); else FIX(false, 52); }
+            if (guarded) {
+                if (in_is_u8) hipLaunchKernelGGL((k_decimate_c_crossfix<true, 8, 128, PER, SPW, true>), grid, block, 0, s, g, d_cross_taps, d_in, d_out, first, nseams);
+                else hipLaunchKernelGGL((k_decimate_c_crossfix<false, 8, 128, PER, SPW, true>), grid, block, 0, s, g, d_cross_taps, d_in, d_out, first, nseams);
+            } else if (P == 52) { if (in_is_u8) FIX(true, 52); else FIX(false, 52); }
             else { if (in_is_u8) FIX(true, 128); else FIX(false, 128); }
 #undef FIX
         }
