@@ -12,8 +12,9 @@ namespace {
 
 // Cross outputs of a complex filter / decimator: sequential over the Lp plain taps
 // (filterCrossHighLevel with Mult (Complex a) a, FilterInternal.hs:397-408, Util.hs:87-88).
+template <bool U8 = false>
 __global__ void __launch_bounds__(256) k_fir_cplx_crossfix(Geom g, const float* __restrict__ xtaps,
-                                                            const float* __restrict__ in, float* __restrict__ out,
+                                                            const void* __restrict__ in, float* __restrict__ out,
                                                             int64_t first_seam, int nseams, int per_seam)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -24,12 +25,21 @@ __global__ void __launch_bounds__(256) k_fir_cplx_crossfix(Geom g, const float* 
     if (m < g.k_begin || m >= g.k_begin + g.count) return;
     const int64_t v = m * g.D;
     if (!(v < edge && v + g.Lp > edge)) return;
-    const float2* x = reinterpret_cast<const float2*>(in) + (v - g.in_base);
     float re = 0.0f, im = 0.0f;
-    for (int j = 0; j < g.Lp; j++) {
-        const float2 s = x[j];
-        re = re + s.x * xtaps[j];
-        im = im + s.y * xtaps[j];
+    if constexpr (U8) {   // interleaved u8 IQ: convert.c's (u - 128) / 128 on the way in (exact)
+        const uchar2* x = reinterpret_cast<const uchar2*>(in) + (v - g.in_base);
+        for (int j = 0; j < g.Lp; j++) {
+            const uchar2 u = x[j];
+            re = re + (((float)u.x - 128.0f) * (1.0f / 128.0f)) * xtaps[j];
+            im = im + (((float)u.y - 128.0f) * (1.0f / 128.0f)) * xtaps[j];
+        }
+    } else {
+        const float2* x = reinterpret_cast<const float2*>(in) + (v - g.in_base);
+        for (int j = 0; j < g.Lp; j++) {
+            const float2 s = x[j];
+            re = re + s.x * xtaps[j];
+            im = im + s.y * xtaps[j];
+        }
     }
     *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
 }

@@ -500,7 +500,7 @@ bool launch_filter_cplx4_fast(hipStream_t s, const Geom& g, const float* d_dup_t
             const int nseams = (int)(last - first + 1);
             const int per = P - 1;
             const int64_t total = (int64_t)nseams * per;
-            hipLaunchKernelGGL(k_fir_cplx_crossfix, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, d_cross_taps, d_in, d_out,
+            hipLaunchKernelGGL(k_fir_cplx_crossfix<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, d_cross_taps, d_in, d_out,
                                first, nseams, per);
         }
     }

@@ -402,7 +402,7 @@ bool launch_fir_split(hipStream_t s, const Geom& g, bool cplx, int lanes, Comple
             const int64_t total = (int64_t)nseams * per;
             const dim3 grid((unsigned)((total + 255) / 256));
             if (cplx)
-                hipLaunchKernelGGL(k_fir_cplx_crossfix, grid, dim3(256), 0, s, g, d_cross_taps, d_in, d_out, first, nseams, per);
+                hipLaunchKernelGGL(k_fir_cplx_crossfix<false>, grid, dim3(256), 0, s, g, d_cross_taps, d_in, d_out, first, nseams, per);
             else
                 hipLaunchKernelGGL(k_fir_real_crossfix, grid, dim3(256), 0, s, g, d_cross_taps, d_in, d_out, first, nseams, per, gain,
                                    apply_gain ? 1 : 0);

@@ -44,14 +44,15 @@ def main():
     for order, oname in ((L.ORDER_AVX, "AVX"), (L.ORDER_SSE, "SSE"), (L.ORDER_SCALAR, "scalar")):
         d = L.Decimator(8, t127, order, complex_=True)
         fir(f"decimate /8 128 taps complex [{oname}]", d, xc, 2, (n - 128) // 8 + 1, n)
-    for nt in (31, 63, 95, 100):
-        d = L.Decimator(8, S.gauss_taps(nt, nt), L.ORDER_AVX, complex_=True)
-        fir(f"decimate /8 {d.num_coeffs} taps complex [AVX] (guarded k_decimate_c4)", d, xc, 2, (n - d.num_coeffs) // 8 + 1, n)
-        u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda")
-        K = (n - d.num_coeffs) // 8 + 1
+    u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda")
+    for D, nt in ((8, 31), (8, 63), (8, 95), (8, 100), (4, 63), (4, 127), (16, 63), (16, 127)):
+        nn = n if D >= 8 else m0 * 2
+        d = L.Decimator(D, S.gauss_taps(nt, nt), L.ORDER_AVX, complex_=True)
+        K = (nn - d.num_coeffs) // D + 1
+        fir(f"decimate /{D} {d.num_coeffs} taps complex [AVX] (guarded k_decimate_c4)", d, xc, 2, K, nn)
         t = timeit(lambda: d.run_u8(u8.data_ptr(), 0, out.data_ptr(), 0, K, 8192, stream=st))
-        rows.append((f"decimate /8 {d.num_coeffs} taps complex [AVX], u8 IQ in", n / t / 1e9, K * d.num_coeffs * 2 / t / 1e12))
-        del u8
+        rows.append((f"decimate /{D} {d.num_coeffs} taps complex [AVX], u8 IQ in", nn / t / 1e9, K * d.num_coeffs * 2 / t / 1e12))
+    del u8
     d = L.Decimator(8, t127, L.ORDER_AVX)
     fir("decimate /8 128 taps real [AVX]", d, xr, 1, (n - 128) // 8 + 1, n)
     d = L.Decimator(8, t127, L.ORDER_SSE)
