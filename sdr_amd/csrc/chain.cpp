@@ -25,13 +25,13 @@ struct sdrhip_fm_chain {
     FirDesc audio;     // symmetric real
     float gain = 1.0f;
     int64_t block = 0;
-    // The fused convert + decimate kernel (k_decimate_c4) covers the AVX order, decimation 4 / 8 / 16, up to 128 taps.  Any other
+    // The fused convert + decimate kernel (k_decimate_c4) covers the AVX order, decimation 4 / 8 / 16, up to 128 (4) or 256 (8, 16) taps.  Any other
     // first stage converts the u8 IQ to cfloat in the workspace first (convert.c as its own kernel, 10 B per sample) and
     // then runs the tiled cfloat decimator -- two passes, but not the one-thread-per-output u8 fallback.
     bool fused_first_stage() const
     {
         const int D = decim.factor;
-        return decim.corder == CO_L4 && (D == 4 || D == 8 || D == 16) && decim.Lp > D && decim.Lp <= 128 && decim.Lp % 4 == 0;
+        return decim.corder == CO_L4 && (D == 4 || D == 8 || D == 16) && decim.Lp > D && decim.Lp <= (D == 4 ? 128 : 256) && decim.Lp % 4 == 0;
     }
 
     // Optional software pipelining inside one run (sdrhip_fm_chain_set_pipelining): the outputs are cut

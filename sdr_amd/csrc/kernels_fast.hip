@@ -414,7 +414,9 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
     // Decimation 8: exact kernels for 128 and 52 taps; every other length up to 128 (multiples of 4: mkDecimatorC pads
     // to that) runs on the 128-tap kernel with run-time guards that skip the tap blocks the shorter filter does not have.
     // Decimation 4 and 16: the guarded 128-tap kernel as well.
-    if (!((g.D == 8 || g.D == 4 || g.D == 16) && P >= 8 && P <= 128 && P % 4 == 0 && g.Lp == P && P > g.D)) return false;
+    // Decimation 8 and 16 with 129..256 taps: guarded instantiations of a 256-tap kernel.
+    const int pmax = g.D == 4 ? 128 : 256;
+    if (!((g.D == 8 || g.D == 4 || g.D == 16) && P >= 8 && P <= pmax && P % 4 == 0 && g.Lp == P && P > g.D)) return false;
     const bool guarded = !(g.D == 8 && (P == 128 || P == 52));
     if (g.seamBI != 0 && d_cross_taps == nullptr) return false;
     int64_t x0 = g.k_begin * g.D - g.in_base;
@@ -431,11 +433,13 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
     // workgroups (same rate), and a persistent kernel that prefetches the next tile into registers during the
     // MAC phase (same rate: with random data the kernel is power/clock-limited, the exposed load phase is ~4 %).
     if (guarded) {
-#define GUARDED(DV, TCV) do { if (in_is_u8) launch_c4<DV, 128, 2, 256, true, TCV, true>(s, g, d_plain_taps, d_in, d_out); \
-                              else launch_c4<DV, 128, 2, 256, false, TCV, true>(s, g, d_plain_taps, d_in, d_out); } while (0)
-        if (g.D == 4) GUARDED(4, 4);
-        else if (g.D == 16) { if (P % 8 == 0) GUARDED(16, 8); else GUARDED(16, 4); }
-        else { if (P % 8 == 0) GUARDED(8, 8); else GUARDED(8, 4); }
+#define GUARDED(DV, PV, TCV) do { if (in_is_u8) launch_c4<DV, PV, 2, 256, true, TCV, true>(s, g, d_plain_taps, d_in, d_out); \
+                                  else launch_c4<DV, PV, 2, 256, false, TCV, true>(s, g, d_plain_taps, d_in, d_out); } while (0)
+        if (g.D == 4) GUARDED(4, 128, 4);
+        else if (g.D == 16 && P <= 128) { if (P % 8 == 0) GUARDED(16, 128, 8); else GUARDED(16, 128, 4); }
+        else if (g.D == 16) { if (P % 8 == 0) GUARDED(16, 256, 8); else GUARDED(16, 256, 4); }
+        else if (P <= 128) { if (P % 8 == 0) GUARDED(8, 128, 8); else GUARDED(8, 128, 4); }
+        else { if (P % 8 == 0) GUARDED(8, 256, 8); else GUARDED(8, 256, 4); }
 #undef GUARDED
     } else if (P == 52) {
         // the tap count of the reference FM example's RF decimation filter (51 -> 52)
@@ -456,7 +460,7 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
             constexpr int PER = 16, SPW = 16;          // 16 candidate slots per seam (ceil((128-1)/8))
             dim3 grid((nseams + SPW - 1) / SPW), block(PER * SPW);
 #define FIX(U, LPV) hipLaunchKernelGGL((k_decimate_c_crossfix<U, 8, LPV, PER, SPW>), grid, block, 0, s, g, d_cross_taps, d_in, d_out, first, nseams)
-            if (g.D != 8) {   // the generic one-thread-per-straddler kernel (crossfix.hpp)
+            if (g.D != 8 || P > 128) {   // the generic one-thread-per-straddler kernel (crossfix.hpp)
                 const int per = (g.Lp - 1 + g.D - 1) / g.D;
                 const int64_t total = (int64_t)nseams * per;
                 const dim3 ggrid((unsigned)((total + 255) / 256));

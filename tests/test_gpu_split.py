@@ -65,7 +65,7 @@ def test_decimator_families(hip, oracle, order, complex_, factor, ntaps):
     assert K >= 4096
     d = hip.Decimator(factor, taps, order, complex_=complex_)
     # complex AVX decimators by 4 / 8 / 16 with up to 128 taps have their own kernel (k_decimate_c4, exact or guarded)
-    special = factor in (4, 8, 16) and order == PM.ORDER_AVX and complex_ and factor < d.num_coeffs <= 128
+    special = factor in (4, 8, 16) and order == PM.ORDER_AVX and complex_ and factor < d.num_coeffs <= (128 if factor == 4 else 256)
     before = _tiled(hip)
     got = _run(d, to_dev(x), w, K, B)
     if _fits(d.num_coeffs, order, complex_) and not special:

@@ -220,13 +220,15 @@ def test_fm_demod_random_bit_patterns(hip, oracle):
 
 
 @pytest.mark.parametrize("factor", [8, 4, 16])
-@pytest.mark.parametrize("ntaps", [9, 12, 31, 51, 60, 77, 100, 121, 127])
+@pytest.mark.parametrize("ntaps", [9, 12, 31, 51, 60, 77, 100, 121, 127, 130, 200, 253])
 def test_decimator_by_8_any_length_up_to_128(hip, oracle, ntaps, factor):
     """The FM chain's decimator kernel serves every tap count up to 128 (exact kernels for 128 and 52, run-time guarded
     blocks otherwise) and the decimation factors 4, 8 and 16: cfloat and u8 input, seams, cut launches -- and it is that
     kernel, not a fallback, that runs."""
     if -(-ntaps // 4) * 4 <= factor:
         pytest.skip("the reference Pipe needs more taps than the decimation step")
+    if factor == 4 and ntaps > 128:
+        pytest.skip("decimation 4 has no 256-tap instantiation (general tiled kernel)")
     nblk = 12 if factor < 16 else 24
     u8 = S.iq_u8(nblk * B, seed=ntaps)
     x = oracle.convert_u8(u8)
