@@ -54,6 +54,7 @@ struct sdrhip_pipe {
     int coalesce = 0;          // blocks per submission (0/1: every push)
     int uniform_n = 0;         // size of the first block; all_uniform: every block so far had it
     bool all_uniform = true;
+    int lent = 0;              // elements behind `staged` the caller may have filled through sdrhip_pipe_input_buffer
 
     struct Slot {
         PinBuf hin, hout;
@@ -242,10 +243,13 @@ static int fir_open_slot(sdrhip_pipe* p, size_t elems)
         SDRHIP_CHECK_HIP(hipEventSynchronize(sl.ev_up));   // the slot's previous upload has left the buffer
     }
     if (sl.hin.cap < elems * p->esz_in() * 4) {
-        // growing must keep what is already staged
+        // growing must keep what is already staged -- and what the caller wrote in place behind it (a block handed out by
+        // sdrhip_pipe_input_buffer and not pushed yet)
         PinBuf bigger;
         if ((rc = bigger.ensure(elems * p->esz_in() * 4)) != SDRHIP_OK) return rc;
-        if (p->staged > 0) memcpy(bigger.p, sl.hin.p, (size_t)p->staged * p->esz_in() * 4);
+        size_t keep = (size_t)(p->staged + p->lent) * p->esz_in() * 4;
+        if (keep > sl.hin.cap) keep = sl.hin.cap;
+        if (keep > 0) memcpy(bigger.p, sl.hin.p, keep);
         std::swap(sl.hin.p, bigger.p);
         std::swap(sl.hin.cap, bigger.cap);
     }
@@ -272,9 +276,18 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
 {
     int rc;
     const size_t ein = (size_t)p->esz_in() * 4;
-    if (p->uniform_n == 0) p->uniform_n = n;
-    if (n != p->uniform_n) p->all_uniform = false;
-    const bool coalescing = p->coalesce > 1 && p->all_uniform;
+    // the size of the first ACCEPTED block is the uniform size: a block the checks below refuse must not latch it
+    const int uni = p->uniform_n == 0 ? n : p->uniform_n;
+    const bool all_uniform = p->all_uniform && n == uni;
+    const bool coalescing = p->coalesce > 1 && all_uniform;
+    if ((int64_t)p->coalesce * uni > (int64_t)1 << 30) {
+        set_error("pipe: %d coalesced blocks of %d elements exceed the staging limit", p->coalesce, uni);
+        return SDRHIP_ERR_ARG;
+    }
+    // zero-copy push: `block` is the staging buffer's own write position (sdrhip_pipe_input_buffer); noted before the
+    // buffer can be re-allocated below (growth keeps the lent region, so the data is then already in place)
+    const bool in_place = p->slot[p->pushes & 1].hin.p != nullptr &&
+                          block == (const float*)p->slot[p->pushes & 1].hin.p + (size_t)p->staged * p->esz_in();
     if (!coalescing && p->staged > 0) {
         // a block of another size ends the uniform run: what is staged goes out as one uniform batch first
         if ((rc = fir_submit(p, p->staged, p->uniform_n)) != SDRHIP_OK) return rc;
@@ -283,16 +296,19 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
     const int64_t m_pending = p->staged > 0 ? ((p->E_prev + p->staged) * p->I >= p->Lp ? ((p->E_prev + p->staged) * p->I - p->Lp) / p->D + 1 : 0)
                                              : p->m_done;
     if ((rc = fir_check_block(p, p->E_prev + p->staged, m_pending, n)) != SDRHIP_OK) return rc;
-    const int cap = coalescing ? p->coalesce * p->uniform_n : n;
+    p->uniform_n = uni;
+    p->all_uniform = all_uniform;
+    const int64_t cap = coalescing ? (int64_t)p->coalesce * p->uniform_n : n;
     if ((rc = fir_open_slot(p, (size_t)(cap > p->staged + n ? cap : p->staged + n))) != SDRHIP_OK) return rc;
     float* dst = (float*)p->slot[p->pushes & 1].hin.p + (size_t)p->staged * p->esz_in();
-    if (block != dst) memcpy(dst, block, (size_t)n * ein);   // else: the caller filled the staging buffer in place
+    if (!in_place) memcpy(dst, block, (size_t)n * ein);   // else: the caller filled the staging buffer in place
+    p->lent = 0;
     p->staged += n;
     if (!coalescing) {
         // equal-sized blocks from the start: the seams are the multiples of that size and one run covers Cross and One
         // outputs alike; otherwise (ragged blocks) the two-part submission
         if ((rc = fir_submit(p, p->staged, p->all_uniform ? p->uniform_n : 0)) != SDRHIP_OK) return rc;
-    } else if (p->staged >= p->coalesce * p->uniform_n) {
+    } else if (p->staged >= (int64_t)p->coalesce * p->uniform_n) {
         if ((rc = fir_submit(p, p->staged, p->uniform_n)) != SDRHIP_OK) return rc;
     }
     return ready_blocks(p);
@@ -428,6 +444,8 @@ int sdrhip_pipe_set_coalesce(sdrhip_pipe* p, int blocks)
     SDRHIP_REQUIRE(p != nullptr && blocks >= 0, "sdrhip_pipe_set_coalesce");
     SDRHIP_REQUIRE(!p->is_map(), "sdrhip_pipe_set_coalesce: filter / decimator / resampler pipes only");
     SDRHIP_REQUIRE(p->staged == 0, "sdrhip_pipe_set_coalesce: blocks are staged (flush first)");
+    SDRHIP_REQUIRE(blocks <= 1 || p->uniform_n == 0 || (int64_t)blocks * p->uniform_n <= (int64_t)1 << 30,
+                   "sdrhip_pipe_set_coalesce: coalesced batch too large");
     p->coalesce = blocks;
     return SDRHIP_OK;
 }
@@ -437,8 +455,12 @@ float* sdrhip_pipe_input_buffer(sdrhip_pipe* p, int n)
     if (p == nullptr || n <= 0 || p->is_map()) { set_error("sdrhip_pipe_input_buffer: filter / decimator / resampler pipes, n > 0"); return nullptr; }
     const bool coalescing = p->coalesce > 1 && p->all_uniform && (p->uniform_n == 0 || p->uniform_n == n);
     if (!coalescing && p->staged > 0 && fir_submit(p, p->staged, p->uniform_n) != SDRHIP_OK) return nullptr;
-    const int cap = coalescing && p->uniform_n ? p->coalesce * p->uniform_n : n;
+    // a fresh pipe has no uniform size yet: the block about to be pushed defines it, so size the buffer for a whole
+    // coalesced batch of such blocks now (growing it at the push would move the block the caller is about to fill)
+    const int64_t cap = coalescing ? (int64_t)p->coalesce * (p->uniform_n ? p->uniform_n : n) : n;
+    if (cap > (int64_t)1 << 30) { set_error("sdrhip_pipe_input_buffer: coalesced batch too large"); return nullptr; }
     if (fir_open_slot(p, (size_t)(cap > p->staged + n ? cap : p->staged + n)) != SDRHIP_OK) return nullptr;
+    p->lent = n;
     return (float*)p->slot[p->pushes & 1].hin.p + (size_t)p->staged * p->esz_in();
 }
 
