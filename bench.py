@@ -235,7 +235,7 @@ def main():
             overlap = False
 
     # Clock / power-state ramp: the first ~15 ms of sustained work on a fresh process run 10 % slow
-    # (interleaved A/B in tools/pipeline_test.py); spin the same step for ~0.3 s before the W warmup steps.
+    # (interleaved A/B in tools/pipeline_ab.py); spin the same step for ~0.3 s before the W warmup steps.
     # With several ranks every step is a send/recv with the neighbours, so all ranks must run the SAME number of steps: the
     # decision to go on is taken collectively (a time-based loop per rank can differ by one step and then deadlocks).
     t_ramp = time.perf_counter()

@@ -148,134 +148,194 @@ __device__ __forceinline__ void compute_tile(const float2* __restrict__ lds, con
     for (int r = 0; r + 1 < R; r += 2) dst[r / 2] = make_float4(res[r].x, res[r].y, res[r + 1].x, res[r + 1].y);
 }
 
-// V1: persistent workgroups, next tile's loads in flight in registers during the MAC phase
-template <int D, int P, int R, int NT, bool NTL, int WPE>
-__global__ void __launch_bounds__(NT, WPE) k_dec_persist_reg(const float* __restrict__ in, int ntiles, const float* __restrict__ taps,
-                                                        float* __restrict__ out)
+
+// ------------------------------------------------------------------------------------------------
+// mac_window2: the same arithmetic as mac_window (kernels_fast.hip) with the wait/issue order pinned.
+//   block b:  [W] pin buf[b] and tc[b] (the compiler must put its s_waitcnt HERE: everything outstanding was issued a whole
+//             block of MACs ago)  ->  issue tc[b+1], LDS(b+DEPTH)  ->  MACs of block b.
+// mac_window issues the next reads first and then meets the wait for the CURRENT block's operands, and because a scalar
+// load is outstanding that wait is lgkmcnt(0): it also waits for the reads it has just issued.
+// Probes: NOLDS (the window is read once, every block reuses it) and NOSMEM (taps are literals) time the loop without
+// one of its two operand streams; their results are wrong on purpose.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void pin_f4(float4 (&v)[N])
+{
+    static_assert(N == 4, "four float4 per block");
+    asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[0].z), "+v"(v[0].w), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[1].z), "+v"(v[1].w),
+                      "+v"(v[2].x), "+v"(v[2].y), "+v"(v[2].z), "+v"(v[2].w), "+v"(v[3].x), "+v"(v[3].y), "+v"(v[3].z), "+v"(v[3].w)
+                 :: "memory");
+}
+
+template <int D, int P, int R, class T, int DEPTH, bool PIN, bool NOLDS, bool NOSMEM>
+__device__ __forceinline__ void mac_window2(const float2* __restrict__ win, const float* __restrict__ taps, float2 (&acc)[R][4])
+{
+    constexpr int TC = 8;
+    constexpr int NCH = P / TC;
+    constexpr int NB = T::WIN / TC;
+    constexpr int NBUF = DEPTH + 1;
+    typedef typename TapVec<TC>::type tapv;
+    tapv tc[NCH];
+    float4 buf[NBUF][TC / 2];
+    auto tap_chunk = [&](int c) -> tapv {
+        if constexpr (NOSMEM) {
+            tapv t;
+#pragma unroll
+            for (int k = 0; k < TC; k++) t[k] = 0.001f * (float)(c * TC + k + 1);
+            return t;
+        } else {
+            return load_tap_chunk<TC>(taps, c);
+        }
+    };
+#define LDS_BLOCK(BB, DST)                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < TC / 2; i_++) {                                                 \
+        const int s_ = TC * (NOLDS ? 0 : (BB)) + 2 * i_;                                                    \
+        (DST)[i_] = *reinterpret_cast<const float4*>(&win[s_ + 2 * (s_ / T::CHUNK)]);                       \
+    }
+    tc[0] = tap_chunk(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) { LDS_BLOCK(d, buf[d % NBUF]); }
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        if constexpr (PIN) {
+            pin_f4(buf[b % NBUF]);
+            if constexpr (!NOSMEM) { if (b < NCH) asm volatile("" : "+s"(tc[b]) :: "memory"); }
+        }
+        if (b + 1 < NCH) tc[b + 1] = tap_chunk(b + 1);
+        if constexpr (!NOLDS) {
+            if (b + DEPTH < NB) { LDS_BLOCK(b + DEPTH, buf[(b + DEPTH) % NBUF]); }
+        } else {
+            if (b + DEPTH < NB) {
+#pragma unroll
+                for (int i = 0; i < TC / 2; i++) buf[(b + DEPTH) % NBUF][i] = buf[b % NBUF][i];
+            }
+        }
+        if constexpr (PIN) asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TC / 2; i++) {
+            const float4 v2 = buf[b % NBUF][i];
+            const float2 v[2] = {make_float2(v2.x, v2.y), make_float2(v2.z, v2.w)};
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int ss = TC * b + 2 * i + e;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int j = ss - r * D;
+                    if (j >= 0 && j < P) {
+                        const float h = tc[j / TC][j % TC];
+                        acc[r][j & 3].x = acc[r][j & 3].x + h * v[e].x;
+                        acc[r][j & 3].y = acc[r][j & 3].y + h * v[e].y;
+                    }
+                }
+            }
+        }
+    }
+#undef LDS_BLOCK
+}
+
+template <int D, int P, int R, class T, int VAR>
+__device__ __forceinline__ void compute_tile_v(const float2* __restrict__ lds, const float* __restrict__ taps, float* __restrict__ out, int out0)
+{
+    const float2* win = lds + T::lds_idx(threadIdx.x * T::CHUNK);
+    float2 acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[r][k] = make_float2(0.0f, 0.0f);
+    if constexpr (VAR == 0) mac_window<D, P, R, T, 8, false>(win, taps, acc, 0);
+    else if constexpr (VAR == 1) mac_window2<D, P, R, T, 1, true, false, false>(win, taps, acc);
+    else if constexpr (VAR == 2) mac_window2<D, P, R, T, 2, true, false, false>(win, taps, acc);
+    else if constexpr (VAR == 3) mac_window2<D, P, R, T, 1, false, false, false>(win, taps, acc);
+    else if constexpr (VAR == 4) mac_window2<D, P, R, T, 1, true, true, false>(win, taps, acc);    // probe: no LDS stream
+    else if constexpr (VAR == 5) mac_window2<D, P, R, T, 1, true, false, true>(win, taps, acc);    // probe: no scalar loads
+    else if constexpr (VAR == 6) mac_window2<D, P, R, T, 1, true, true, true>(win, taps, acc);     // probe: neither
+    else mac_window2<D, P, R, T, 3, true, false, false>(win, taps, acc);
+    const int o = out0 + threadIdx.x * R;
+    float2 res[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        res[r].x = (acc[r][0].x + acc[r][1].x) + (acc[r][2].x + acc[r][3].x);
+        res[r].y = (acc[r][0].y + acc[r][1].y) + (acc[r][2].y + acc[r][3].y);
+    }
+    float4* dst = reinterpret_cast<float4*>(out + 2 * (int64_t)o);
+#pragma unroll
+    for (int r = 0; r + 1 < R; r += 2) dst[r / 2] = make_float4(res[r].x, res[r].y, res[r + 1].x, res[r + 1].y);
+}
+
+// MAC phase alone (stale LDS), variant VAR
+struct ClkProbe { unsigned long long cyc, rt; unsigned int n; unsigned int pad; };
+__device__ __forceinline__ void probe_begin(unsigned long long& c0, unsigned long long& r0)
+{
+    c0 = __builtin_readcyclecounter();      // s_memtime: shader clock
+    r0 = wall_clock64();                     // s_memrealtime: constant 100 MHz
+}
+__device__ __forceinline__ void probe_end(ClkProbe* pr, unsigned long long c0, unsigned long long r0)
+{
+    if (pr != nullptr && (blockIdx.x & 63) == 0 && threadIdx.x == 0) {
+        const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+        atomicAdd(&pr->cyc, c1 - c0);
+        atomicAdd(&pr->rt, r1 - r0);
+        atomicAdd(&pr->n, 1u);
+    }
+}
+
+template <int D, int P, int R, int NT, int VAR>
+__global__ void __launch_bounds__(NT) k_mac_only(int ntiles, const float* __restrict__ taps, float* __restrict__ out, ClkProbe* pr)
 {
     using T = Tile<D, P, R, NT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
-    const int nwg = gridDim.x;
-    auto tile_of = [&](int it) { const int g = it * nwg + blockIdx.x; return (g & ~63) + ((g & 7) << 3) + ((g >> 3) & 7); };
+    const int b = blockIdx.x;
+    const int tile = (b & ~63) + ((b & 7) << 3) + ((b >> 3) & 7);
+    if (tile >= ntiles) return;
+    unsigned long long c0, r0;
+    probe_begin(c0, r0);
+    compute_tile_v<D, P, R, T, VAR>(lds, taps, out, tile * T::OUTS);
+    probe_end(pr, c0, r0);
+}
+
+// fills every workgroup's LDS with zeros (the next MAC-only kernel then multiplies constant data: low switching activity)
+template <int NT>
+__global__ void __launch_bounds__(NT) k_lds_fill(int nwords, unsigned int pattern_mul)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned int* w = reinterpret_cast<unsigned int*>(smem_raw);
+    for (int i = threadIdx.x; i < nwords; i += NT) {
+        unsigned int x = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        // random floats in [-1, 1): sign + exponent of 0.5..1 + random mantissa, or zero
+        w[i] = pattern_mul ? ((x & 0x807fffffu) | 0x3f000000u) : 0u;
+    }
+    __syncthreads();
+    if (w[threadIdx.x] == 0x12345678u) w[0] = 1;   // keep the stores
+}
+
+// the production structure (one tile per workgroup, register staging) around MAC variant VAR; NTL: non-temporal loads
+template <int D, int P, int R, int NT, int VAR, bool NTL>
+__global__ void __launch_bounds__(NT) k_dec_v(const float* __restrict__ in, int ntiles, const float* __restrict__ taps, float* __restrict__ out)
+{
+    using T = Tile<D, P, R, NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    const int b = blockIdx.x;
+    const int tile = (b & ~63) + ((b & 7) << 3) + ((b >> 3) & 7);
+    if (tile >= ntiles) return;
     constexpr int NV = (T::SPAN + 1) / 2;
     constexpr int PER = (NV + NT - 1) / NT;
-    uint4 r[PER];
-    auto load = [&](int tile) {
-        const uint4* src = reinterpret_cast<const uint4*>(in + 2 * (int64_t)tile * T::OUTS * D);
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            const int v = threadIdx.x + i * NT;
-            if (i + 1 < PER || v < NV) r[i] = ld16<NTL>(src + v);
-        }
-    };
-    auto store = [&]() {
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            const int v = threadIdx.x + i * NT;
-            if (v < NV) *reinterpret_cast<uint4*>(&lds[T::lds_idx(2 * v)]) = r[i];
-        }
-    };
-    int it = 0;
-    int tile = tile_of(0);
-    if (tile < ntiles) { load(tile); store(); }
-    __syncthreads();
-    while (tile < ntiles) {
-        const int next = tile_of(++it);
-        if (next < ntiles) load(next);
-        compute_tile<D, P, R, T>(lds, taps, out, tile * T::OUTS);
-        __syncthreads();
-        if (next < ntiles) store();
-        __syncthreads();
-        tile = next;
-    }
-}
-
-// V2: persistent workgroups, LDS-DMA into a double-buffered tile.  The padded LDS layout (one 16-byte pad per eight
-// 16-byte vectors) is produced on the SOURCE side: LDS vector slot q holds source vector (q/9)*8 + q%9; the pad slots
-// (q%9 == 8) re-fetch their left neighbour's vector (same cache line, never read back).
-template <int D, int P, int R, int NT, int AUX>
-__global__ void __launch_bounds__(NT) k_dec_persist_dma(const float* __restrict__ in, int ntiles, const float* __restrict__ taps,
-                                                        float* __restrict__ out)
-{
-    using T = Tile<D, P, R, NT>;
-    static_assert(T::CHUNK == 16, "pad pattern below: one pad vector per 8 data vectors");
-    constexpr int NVL = (T::LDS_F2 + 1) / 2;                 // 16-byte slots of the padded tile
-    constexpr int NI = (NVL + NT - 1) / NT;                  // DMA instructions per thread
-    constexpr int BUF_F2 = NI * NT * 2;                      // float2 per buffer (whole instructions)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* lds = reinterpret_cast<float2*>(smem_raw);
-    const int nwg = gridDim.x;
-    auto tile_of = [&](int it) { const int g = it * nwg + blockIdx.x; return (g & ~63) + ((g & 7) << 3) + ((g >> 3) & 7); };
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int NV = (T::SPAN + 1) / 2;
-    int voff[NI];                                            // source vector of this lane's slot in instruction i
-#pragma unroll
-    for (int i = 0; i < NI; i++) {
-        const int q = i * NT + threadIdx.x;
-        const int rr = q % 9;
-        int v = (q / 9) * 8 + (rr == 8 ? 7 : rr);
-        if (v > NV - 1) v = NV - 1;
-        voff[i] = v;
-    }
-    auto issue = [&](int tile, int b) {
-        const uint4* src = reinterpret_cast<const uint4*>(in + 2 * (int64_t)tile * T::OUTS * D);
-#pragma unroll
-        for (int i = 0; i < NI; i++)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + voff[i]), (lptr_t)(lds + b * BUF_F2 + (i * NT + wave * 64) * 2), 16, 0, AUX);
-    };
-    int it = 0;
-    int tile = tile_of(0);
-    if (tile < ntiles) issue(tile, 0);
-    __syncthreads();
-    while (tile < ntiles) {
-        const int next = tile_of(++it);
-        if (next < ntiles) issue(next, it & 1);
-        compute_tile<D, P, R, T>(lds + ((it - 1) & 1) * BUF_F2, taps, out, tile * T::OUTS);
-        __syncthreads();      // drains this wave's DMA (vmcnt(0)) and orders every wave's reads before the next overwrite
-        tile = next;
-    }
-}
-
-// MAC phase alone: no global loads, LDS holds whatever the previous kernel left (the V0 run just before: real samples)
-template <int D, int P, int R, int NT>
-__global__ void __launch_bounds__(NT) k_dec_nold(int ntiles, const float* __restrict__ taps, float* __restrict__ out)
-{
-    using T = Tile<D, P, R, NT>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* lds = reinterpret_cast<float2*>(smem_raw);
-    const int b = blockIdx.x;
-    const int tile = (b & ~63) + ((b & 7) << 3) + ((b >> 3) & 7);
-    if (tile >= ntiles) return;
-    compute_tile<D, P, R, T>(lds, taps, out, tile * T::OUTS);
-}
-
-// V3: non-persistent, LDS-DMA single buffer (what the DMA alone buys over register staging)
-template <int D, int P, int R, int NT, int AUX>
-__global__ void __launch_bounds__(NT) k_dec_oneshot_dma(const float* __restrict__ in, int ntiles, const float* __restrict__ taps,
-                                                        float* __restrict__ out)
-{
-    using T = Tile<D, P, R, NT>;
-    constexpr int NVL = (T::LDS_F2 + 1) / 2;
-    constexpr int NI = (NVL + NT - 1) / NT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* lds = reinterpret_cast<float2*>(smem_raw);
-    const int b = blockIdx.x;
-    const int tile = (b & ~63) + ((b & 7) << 3) + ((b >> 3) & 7);
-    if (tile >= ntiles) return;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int NV = (T::SPAN + 1) / 2;
     const uint4* src = reinterpret_cast<const uint4*>(in + 2 * (int64_t)tile * T::OUTS * D);
+    uint4 r[PER];
 #pragma unroll
-    for (int i = 0; i < NI; i++) {
-        const int q = i * NT + threadIdx.x;
-        const int rr = q % 9;
-        int v = (q / 9) * 8 + (rr == 8 ? 7 : rr);
-        if (v > NV - 1) v = NV - 1;
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + v), (lptr_t)(lds + (i * NT + wave * 64) * 2), 16, 0, AUX);
+    for (int i = 0; i < PER; i++) {
+        const int v = threadIdx.x + i * NT;
+        if (i + 1 < PER || v < NV) r[i] = ld16<NTL>(src + v);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int v = threadIdx.x + i * NT;
+        if (v < NV) *reinterpret_cast<uint4*>(&lds[T::lds_idx(2 * v)]) = r[i];
     }
     __syncthreads();
-    compute_tile<D, P, R, T>(lds, taps, out, tile * T::OUTS);
+    compute_tile_v<D, P, R, T, VAR>(lds, taps, out, tile * T::OUTS);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -356,87 +416,68 @@ int main(int argc, char** argv)
         fflush(stdout);
     };
 
-    // LDS sizes of the DMA variants
-    constexpr int NVL = (T::LDS_F2 + 1) / 2, NI = (NVL + NT - 1) / NT;
-    constexpr size_t DMA_BUF = (size_t)NI * NT * 16;
     const int ncu = prop.multiProcessorCount;
-
+    (void)ncu;
     // streaming shapes: 8 uint4 in, 1 out per thread
     const int nchunks = (int)(n * 8 / 16 / (NT * 8));
     uint4* sin_ = reinterpret_cast<uint4*>(dx);
     uint4* sout = reinterpret_cast<uint4*>(dout);
-
 #define SETLDS(k, bytes) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
-    auto kreg3 = k_dec_persist_reg<D, P, R, NT, false, 3>;
-    auto kregnt3 = k_dec_persist_reg<D, P, R, NT, true, 3>;
-    auto kreg4 = k_dec_persist_reg<D, P, R, NT, false, 4>;
-    auto kregnt4 = k_dec_persist_reg<D, P, R, NT, true, 4>;
-    auto knold = k_dec_nold<D, P, R, NT>;
-    SETLDS(knold, T::LDS_BYTES);
-    auto kdma = k_dec_persist_dma<D, P, R, NT, 0>;
-    auto kdmant = k_dec_persist_dma<D, P, R, NT, 2>;
-    auto kone = k_dec_oneshot_dma<D, P, R, NT, 0>;
-    SETLDS(kreg3, T::LDS_BYTES); SETLDS(kregnt3, T::LDS_BYTES); SETLDS(kreg4, T::LDS_BYTES); SETLDS(kregnt4, T::LDS_BYTES); SETLDS(kdma, 2 * DMA_BUF); SETLDS(kdmant, 2 * DMA_BUF); SETLDS(kone, DMA_BUF);
 
+    ClkProbe* dpr;
+    CK(hipMalloc(&dpr, sizeof(ClkProbe)));
+    auto run_mac_lds = [&](auto kern, const char* nm, size_t lds_bytes) {
+        SETLDS(kern, lds_bytes);
+        CK(hipMemset(dpr, 0, sizeof(ClkProbe)));
+        const double us = tm.us([&] { hipLaunchKernelGGL(kern, dim3(grid0), dim3(NT), lds_bytes, 0, ntiles, dt, dout, dpr); }, reps);
+        ClkProbe h;
+        CK(hipMemcpy(&h, dpr, sizeof h, hipMemcpyDeviceToHost));
+        report(nm, us);
+        if (h.rt) printf("    clock probe: %.0f MHz shader clock (avg over %u workgroups), %.2f us per workgroup\n", (double)h.cyc / (double)h.rt * 100.0, h.n,
+                         (double)h.rt / h.n / 100.0);
+    };
+    auto run_mac = [&](auto kern, const char* nm) { run_mac_lds(kern, nm, T::LDS_BYTES); };
+    auto run_dec = [&](auto kern, const char* nm, bool chk) {
+        SETLDS(kern, T::LDS_BYTES);
+        CK(hipMemset(dout, 0xff, (size_t)nout * 8));
+        report(nm, tm.us([&] { hipLaunchKernelGGL(kern, dim3(grid0), dim3(NT), T::LDS_BYTES, 0, dx, ntiles, dt, dout); }, reps));
+        if (chk) check(nm);
+    };
     for (int round = 0; round < rounds; round++) {
         printf("---- round %d\n", round);
         report("stream oneshot 8:1", tm.us([&] { hipLaunchKernelGGL((k_stream_oneshot<NT, false>), dim3(nchunks), dim3(NT), 0, 0, sin_, sout); }, reps));
         report("stream oneshot 8:1 nt", tm.us([&] { hipLaunchKernelGGL((k_stream_oneshot<NT, true>), dim3(nchunks), dim3(NT), 0, 0, sin_, sout); }, reps));
-        for (int per : {4, 6, 8}) {
-            char nm[64];
-            snprintf(nm, sizeof nm, "stream persist 8:1 x%d/CU", per);
-            report(nm, tm.us([&] { hipLaunchKernelGGL((k_stream_persist<NT, false>), dim3(ncu * per), dim3(NT), 0, 0, sin_, sout, nchunks); }, reps));
-            snprintf(nm, sizeof nm, "stream persist 8:1 nt x%d/CU", per);
-            report(nm, tm.us([&] { hipLaunchKernelGGL((k_stream_persist<NT, true>), dim3(ncu * per), dim3(NT), 0, 0, sin_, sout, nchunks); }, reps));
-        }
-        for (int per : {2, 4}) {
-            char nm[64];
-            snprintf(nm, sizeof nm, "stream LDS-DMA 8:1 x%d/CU", per);
-            report(nm, tm.us([&] { hipLaunchKernelGGL((k_stream_dma<NT>), dim3(ncu * per), dim3(NT), 0, 0, sin_, sout, nchunks); }, reps));
-        }
-        {
-            // plain float4 copy moving the same total bytes (576 MiB -> 576 MiB at n = 2^27)
-            const size_t nv = (size_t)((rd_bytes + wr_bytes) / 2 / 16);
-            uint4* cdst = reinterpret_cast<uint4*>(dx) + nv;      // second half of the input buffer (restored below: not needed, lab data only read after)
-            (void)cdst;
-        }
         CK(hipMemset(dout, 0xff, (size_t)nout * 8));
-
         report("V0 production (4 WG/CU, reg stage)", tm.us([&] { run0(dout); }, reps));
         check("V0");
-        report("MAC phase only (no loads, stale LDS)", tm.us([&] { hipLaunchKernelGGL(knold, dim3(grid0), dim3(NT), T::LDS_BYTES, 0, ntiles, dt, dout); }, reps));
-        CK(hipMemset(dout, 0xff, (size_t)nout * 8));
-        for (int per : {3, 4}) {
-            char nm[64];
-            snprintf(nm, sizeof nm, "V1 persist reg-prefetch x%d/CU", per);
-            report(nm, tm.us([&] { hipLaunchKernelGGL(per == 3 ? kreg3 : kreg4, dim3(ncu * per), dim3(NT), T::LDS_BYTES, 0, dx, ntiles, dt, dout); }, reps));
-            check(nm);
-            snprintf(nm, sizeof nm, "V1 persist reg-prefetch nt x%d/CU", per);
-            report(nm, tm.us([&] { hipLaunchKernelGGL(per == 3 ? kregnt3 : kregnt4, dim3(ncu * per), dim3(NT), T::LDS_BYTES, 0, dx, ntiles, dt, dout); }, reps));
-            check(nm);
-        }
+        run0(dout);   // leave real samples in LDS for the MAC-only kernels
+        run_mac(k_mac_only<D, P, R, NT, 0>, "MAC only: mac_window (production)");
+        run_mac_lds(k_mac_only<D, P, R, NT, 0>, "MAC only: production, 3 WG/CU", 50 * 1024);
+        run_mac_lds(k_mac_only<D, P, R, NT, 0>, "MAC only: production, 2 WG/CU", 70 * 1024);
+        run_mac_lds(k_mac_only<D, P, R, NT, 0>, "MAC only: production, 1 WG/CU", 100 * 1024);
         {
-            using T1 = Tile<D, P, 2, 128>;
-            auto k = k_decimate_c4<D, P, 2, 128, false>;
-            SETLDS(k, T1::LDS_BYTES);
-            const int nt1 = (int)(nout / T1::OUTS), g1 = ((nt1 + 63) / 64) * 64;
-            report("V0 shape NT=128 R=2 (8 WG/CU)", tm.us([&] { hipLaunchKernelGGL(k, dim3(g1), dim3(128), T1::LDS_BYTES, 0, (const void*)dx, (int64_t)0, (int)nout, dt, dout, P); }, reps));
-            check("V0 NT=128 R=2");
+            auto kf = k_lds_fill<NT>;
+            SETLDS(kf, 160 * 1024);
+            hipLaunchKernelGGL(kf, dim3(ncu * 4), dim3(NT), 160 * 1024, 0, 160 * 256, 0u);
+            run_mac(k_mac_only<D, P, R, NT, 0>, "MAC only: production, LDS all zero");
+            hipLaunchKernelGGL(kf, dim3(ncu * 4), dim3(NT), 160 * 1024, 0, 160 * 256, 1u);
+            run_mac(k_mac_only<D, P, R, NT, 0>, "MAC only: production, LDS random");
         }
-        {
-            using T1 = Tile<D, P, 4, 128>;
-            auto k = k_decimate_c4<D, P, 4, 128, false>;
-            SETLDS(k, T1::LDS_BYTES);
-            const int nt1 = (int)(nout / T1::OUTS), g1 = ((nt1 + 63) / 64) * 64;
-            report("V0 shape NT=128 R=4 (4 WG/CU)", tm.us([&] { hipLaunchKernelGGL(k, dim3(g1), dim3(128), T1::LDS_BYTES, 0, (const void*)dx, (int64_t)0, (int)nout, dt, dout, P); }, reps));
-            check("V0 NT=128 R=4");
-        }
-        report("V2 persist LDS-DMA dbuf x2/CU", tm.us([&] { hipLaunchKernelGGL(kdma, dim3(ncu * 2), dim3(NT), 2 * DMA_BUF, 0, dx, ntiles, dt, dout); }, reps));
-        check("V2");
-        report("V2 persist LDS-DMA dbuf nt x2/CU", tm.us([&] { hipLaunchKernelGGL(kdmant, dim3(ncu * 2), dim3(NT), 2 * DMA_BUF, 0, dx, ntiles, dt, dout); }, reps));
-        check("V2 nt");
-        report("V3 oneshot LDS-DMA (4 WG/CU)", tm.us([&] { hipLaunchKernelGGL(kone, dim3(grid0), dim3(NT), DMA_BUF, 0, dx, ntiles, dt, dout); }, reps));
-        check("V3");
+        run_mac(k_mac_only<D, P, R, NT, 3>, "MAC only: mac_window2 unpinned d1");
+        run_mac(k_mac_only<D, P, R, NT, 1>, "MAC only: pinned wait, depth 1");
+        run_mac(k_mac_only<D, P, R, NT, 2>, "MAC only: pinned wait, depth 2");
+        run_mac(k_mac_only<D, P, R, NT, 7>, "MAC only: pinned wait, depth 3");
+        run_mac(k_mac_only<D, P, R, NT, 4>, "MAC only probe: no LDS stream");
+        run_mac(k_mac_only<D, P, R, NT, 5>, "MAC only probe: no scalar loads");
+        run_mac(k_mac_only<D, P, R, NT, 6>, "MAC only probe: neither");
+        run_dec(k_dec_v<D, P, R, NT, 0, false>, "dec: mac_window", true);
+        run_dec(k_dec_v<D, P, R, NT, 0, true>, "dec: mac_window, nt loads", true);
+        run_dec(k_dec_v<D, P, R, NT, 1, false>, "dec: pinned d1", true);
+        run_dec(k_dec_v<D, P, R, NT, 1, true>, "dec: pinned d1, nt loads", true);
+        run_dec(k_dec_v<D, P, R, NT, 2, false>, "dec: pinned d2", true);
+        run_dec(k_dec_v<D, P, R, NT, 2, true>, "dec: pinned d2, nt loads", true);
+        run_dec(k_dec_v<D, P, R, NT, 7, true>, "dec: pinned d3, nt loads", true);
+        run_dec(k_dec_v<D, P, R, NT, 3, true>, "dec: unpinned mac_window2, nt loads", true);
     }
     // plain copy, same total bytes, separate buffers
     {

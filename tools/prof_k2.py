@@ -6,18 +6,24 @@ import torch
 import sdr_amd.lib as L
 import signals as S
 
-n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 26)
-mode = sys.argv[2] if len(sys.argv) > 2 else "both"
-K = (n - 128) // 8 + 1
-dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
-out = torch.empty(2 * K, device="cuda")
-st = torch.cuda.current_stream().cuda_stream
-if mode in ("both", "f32"):
-    x = torch.rand(2 * n, device="cuda") * 2 - 1
-    for _ in range(5):
-        dec.run(x.data_ptr(), 0, out.data_ptr(), 0, K, 0, stream=st)
-if mode in ("both", "u8"):
-    u8 = torch.randint(0, 256, (2 * n,), device="cuda", dtype=torch.uint8)
-    for _ in range(5):
-        dec.run_u8(u8.data_ptr(), 0, out.data_ptr(), 0, K, 0, stream=st)
-torch.cuda.synchronize()
+
+def main():
+    n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 26)
+    mode = sys.argv[2] if len(sys.argv) > 2 else "both"
+    K = (n - 128) // 8 + 1
+    dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
+    out = torch.empty(2 * K, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    if mode in ("both", "f32"):
+        x = torch.rand(2 * n, device="cuda") * 2 - 1
+        for _ in range(5):
+            dec.run(x.data_ptr(), 0, out.data_ptr(), 0, K, 0, stream=st)
+    if mode in ("both", "u8"):
+        u8 = torch.randint(0, 256, (2 * n,), device="cuda", dtype=torch.uint8)
+        for _ in range(5):
+            dec.run_u8(u8.data_ptr(), 0, out.data_ptr(), 0, K, 0, stream=st)
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,12 +6,18 @@ import torch
 import sdr_amd.lib as L
 import signals as S
 
-n = 1 << 26
-K = (n - 128) // 8 + 1
-dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX)
-x = torch.rand(n, device="cuda") * 2 - 1
-out = torch.empty(K, device="cuda")
-st = torch.cuda.current_stream().cuda_stream
-for _ in range(5):
-    dec.run(x.data_ptr(), 0, out.data_ptr(), 0, K, 0, stream=st)
-torch.cuda.synchronize()
+
+def main():
+    n = 1 << 26
+    K = (n - 128) // 8 + 1
+    dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX)
+    x = torch.rand(n, device="cuda") * 2 - 1
+    out = torch.empty(K, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        dec.run(x.data_ptr(), 0, out.data_ptr(), 0, K, 0, stream=st)
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()
