@@ -292,6 +292,44 @@ int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain *c, int nsub);
 int sdrhip_fm_chain_enable_timing(sdrhip_fm_chain *c, int enable);
 int sdrhip_fm_chain_read_timing(sdrhip_fm_chain *c, double ms_sum[5], int *runs);
 
+/* ---- multi-GPU: the ntaps-1 halo exchange of the sharded chain ---- */
+/* The reference has no multi-device code; these entry points are what a sharded host (one thread or process per
+ * GPU -- e.g. eight Haskell pipelines of examples/fm/fm.hs:34-41, one per device) binds to.  Rank r owns the samples
+ * [r*S, (r+1)*S) of every super-block in a device buffer laid out [shard | halo region]; one exchange sends the FIRST
+ * `bytes` of the shard to the LEFT neighbour (rank r-1, wrapping) and receives the right neighbour's head into the halo
+ * region.  Transport: RCCL point-to-point (ncclGroupStart; ncclSend; ncclRecv; ncclGroupEnd) enqueued on the caller's HIP
+ * stream -- librccl.so.1 is loaded on first use, the library has no link-time dependency on it -- or, for the devices of
+ * ONE process, hipMemcpyPeerAsync.  The message is ~8 KB: latency-bound, so no collective is involved. */
+typedef struct sdrhip_comm sdrhip_comm;
+#define SDRHIP_COMM_ID_BYTES 128
+/* rank 0 creates the rendezvous id and hands it to the other ranks by any out-of-band means (file, socket, MPI ...) */
+int sdrhip_comm_get_unique_id(void *id /* SDRHIP_COMM_ID_BYTES */);
+/* one communicator per GPU process / thread; binds the CURRENT device (sdrhip_set_device first).  Collective: every
+ * rank must call it. */
+int sdrhip_comm_init_rank(sdrhip_comm **c, int nranks, int rank, const void *id);
+/* all `ndev` devices from ONE process: comms[i] is rank i on devices[i].  transport: SDRHIP_TRANSPORT_RCCL or
+ * SDRHIP_TRANSPORT_PEER_COPY (hipMemcpyPeerAsync; no RCCL needed). */
+#define SDRHIP_TRANSPORT_RCCL 1
+#define SDRHIP_TRANSPORT_PEER_COPY 2
+int sdrhip_comm_init_local(sdrhip_comm **comms, int ndev, const int *devices, int transport);
+void sdrhip_comm_destroy(sdrhip_comm *c);
+int sdrhip_comm_rank(const sdrhip_comm *c);
+int sdrhip_comm_size(const sdrhip_comm *c);
+const char *sdrhip_comm_transport(const sdrhip_comm *c);   /* "rccl" | "peer-copy" */
+/* One rank's exchange, asynchronous on `stream` (the compute stream: kernels queued after it see the halo).  d_send /
+ * d_recv are device pointers on this rank's GPU.  RCCL transport only (a per-rank call cannot see the peer's memory). */
+int sdrhip_halo_exchange(sdrhip_comm *c, void *stream, const void *d_send, void *d_recv, size_t bytes);
+/* All ranks of a single-process communicator at once: rank i sends d_send[i] and receives into d_recv[i] on streams[i].
+ * RCCL: one group over every rank; peer copy: stream i waits for the event of rank i+1's stream (the head must have been
+ * produced) and pulls it with hipMemcpyPeerAsync. */
+int sdrhip_halo_exchange_all(sdrhip_comm *const *comms, int ndev, void *const *streams, const void *const *d_send,
+                             void *const *d_recv, size_t bytes);
+/* The chain's own message: head = d_buf[0 .. 2*halo), halo region = d_buf + 2*shard_samples, halo =
+ * sdrhip_fm_chain_halo_samples(chain) (max_halo rounded up to 8 samples: the same on every rank). */
+int64_t sdrhip_fm_chain_halo_samples(const sdrhip_fm_chain *c);
+int sdrhip_fm_chain_halo_exchange(const sdrhip_fm_chain *chain, sdrhip_comm *comm, void *stream, uint8_t *d_buf,
+                                  int64_t shard_samples);
+
 /* Host-block streaming front end of the chain: u8 IQ source blocks in (host memory, `block` samples
  * each or a whole multiple), audio blocks of exactly block_size_out floats out -- the five middle
  * stages of examples/fm/fm.hs:34-41 as ONE operator with every intermediate resident in HBM.  Pinned
@@ -316,6 +354,13 @@ int sdrhip_fm_stream_flush(sdrhip_fm_stream *st);
  * latency; the audio blocks are the same.  Call with nothing staged. */
 int sdrhip_fm_stream_set_coalesce(sdrhip_fm_stream *st, int samples);
 int sdrhip_fm_stream_pop(sdrhip_fm_stream *st, float *out, int capacity);
+
+/* ---- measurement utilities (bench.py only; not part of the FM path) ---- */
+/* A streaming kernel with the traffic shape of the cfloat decimate-by-8 kernel (bytes_in read, bytes_in / 8 written;
+ * bytes_in a multiple of 32 KiB), with plain or non-temporal loads, and a float4 copy: the ceilings the memory system
+ * of this box delivers in this process, measured next to the kernel. */
+int sdrhip_bench_stream_8to1(void *stream, const void *d_in, void *d_out, size_t bytes_in, int non_temporal);
+int sdrhip_bench_copy(void *stream, const void *d_in, void *d_out, size_t bytes);
 
 /* ------------------------------------------------------------------------ */
 /* (3) Pipe operators on host blocks                                        */

@@ -198,6 +198,20 @@ int64_t sdrhip_fm_chain_max_halo(const sdrhip_fm_chain* c)
     return worst;
 }
 
+int64_t sdrhip_fm_chain_halo_samples(const sdrhip_fm_chain* c)
+{
+    const int64_t h = sdrhip_fm_chain_max_halo(c);
+    return h < 0 ? h : (h + 7) / 8 * 8;      // whole 16-byte vectors of u8 IQ, the same on every rank
+}
+
+int sdrhip_fm_chain_halo_exchange(const sdrhip_fm_chain* chain, sdrhip_comm* comm, void* stream, uint8_t* d_buf, int64_t shard_samples)
+{
+    SDRHIP_REQUIRE(chain != nullptr && comm != nullptr && d_buf != nullptr && shard_samples > 0, "sdrhip_fm_chain_halo_exchange");
+    const int64_t halo = sdrhip_fm_chain_halo_samples(chain);
+    SDRHIP_REQUIRE(halo <= shard_samples, "sdrhip_fm_chain_halo_exchange: shard shorter than the halo");
+    return sdrhip_halo_exchange(comm, stream, d_buf, d_buf + 2 * shard_samples, (size_t)(2 * halo));
+}
+
 size_t sdrhip_fm_chain_workspace_bytes(const sdrhip_fm_chain* c, int64_t n_in)
 {
     if (!c || n_in < 0) return 0;

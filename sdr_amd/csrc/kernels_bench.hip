@@ -1,0 +1,70 @@
+// kernels_bench.hip -- measurement utilities (NOT part of the FM path): streaming kernels with the traffic shape of the
+// cfloat decimate-by-8 kernel (8 bytes read : 1 byte written) and a plain float4 copy, so that bench.py can put the
+// kernel's achieved bandwidth next to what the memory system of THIS box delivers in the SAME process (the ceiling
+// moves by ~8 % from box to box and with the power state the previous kernels left behind).
+#include "common.hpp"
+
+namespace sdrhip {
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// each thread reads eight 16-byte vectors (wave-contiguous 1 KiB each), folds them and writes one
+template <int NT, bool NTL>
+__global__ void __launch_bounds__(NT) k_stream_8to1(const uint4* __restrict__ in, uint4* __restrict__ out)
+{
+    const size_t base = (size_t)blockIdx.x * NT * 8 + threadIdx.x;
+    uint4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if constexpr (NTL) {
+            const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in + base + (size_t)i * NT));
+            v[i] = make_uint4(t.x, t.y, t.z, t.w);
+        } else {
+            v[i] = in[base + (size_t)i * NT];
+        }
+    }
+    uint4 r = v[0];
+#pragma unroll
+    for (int i = 1; i < 8; i++) { r.x ^= v[i].x; r.y ^= v[i].y; r.z ^= v[i].z; r.w ^= v[i].w; }
+    out[(size_t)blockIdx.x * NT + threadIdx.x] = r;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT) k_copy16(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) out[i] = in[i];
+}
+
+}  // namespace
+}  // namespace sdrhip
+
+using namespace sdrhip;
+
+extern "C" {
+
+int sdrhip_bench_stream_8to1(void* stream, const void* d_in, void* d_out, size_t bytes_in, int non_temporal)
+{
+    SDRHIP_REQUIRE(d_in != nullptr && d_out != nullptr && bytes_in >= 32768 && bytes_in % 32768 == 0, "sdrhip_bench_stream_8to1");
+    const unsigned blocks = (unsigned)(bytes_in / 32768);      // 256 threads x 8 x 16 bytes per workgroup
+    if (non_temporal)
+        hipLaunchKernelGGL((k_stream_8to1<256, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_in, (uint4*)d_out);
+    else
+        hipLaunchKernelGGL((k_stream_8to1<256, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_in, (uint4*)d_out);
+    SDRHIP_CHECK_HIP(hipGetLastError());
+    return SDRHIP_OK;
+}
+
+int sdrhip_bench_copy(void* stream, const void* d_in, void* d_out, size_t bytes)
+{
+    SDRHIP_REQUIRE(d_in != nullptr && d_out != nullptr && bytes % 16 == 0, "sdrhip_bench_copy");
+    int dev = 0, cus = 256;
+    SDRHIP_CHECK_HIP(hipGetDevice(&dev));
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipLaunchKernelGGL((k_copy16<256>), dim3((unsigned)cus * 8), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_in, (uint4*)d_out, bytes / 16);
+    SDRHIP_CHECK_HIP(hipGetLastError());
+    return SDRHIP_OK;
+}
+
+}  // extern "C"

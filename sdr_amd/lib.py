@@ -123,6 +123,22 @@ lib.sdrhip_fm_chain_set_pipelining.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_enable_timing.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_read_timing.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
+lib.sdrhip_fm_chain_halo_samples.argtypes = [_vp]
+lib.sdrhip_fm_chain_halo_samples.restype = _i64
+lib.sdrhip_fm_chain_halo_exchange.argtypes = [_vp, _vp, _vp, _vp, _i64]
+lib.sdrhip_comm_get_unique_id.argtypes = [C.c_char_p]
+lib.sdrhip_comm_init_rank.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, C.c_char_p]
+lib.sdrhip_comm_init_local.argtypes = [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int), C.c_int]
+lib.sdrhip_comm_destroy.argtypes = [_vp]
+lib.sdrhip_comm_destroy.restype = None
+lib.sdrhip_comm_rank.argtypes = [_vp]
+lib.sdrhip_comm_size.argtypes = [_vp]
+lib.sdrhip_comm_transport.argtypes = [_vp]
+lib.sdrhip_comm_transport.restype = C.c_char_p
+lib.sdrhip_halo_exchange.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t]
+lib.sdrhip_halo_exchange_all.argtypes = [C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.c_size_t]
+lib.sdrhip_bench_stream_8to1.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]
+lib.sdrhip_bench_copy.argtypes = [_vp, _vp, _vp, C.c_size_t]
 lib.sdrhip_debug_tiled_launches.argtypes = []
 lib.sdrhip_debug_tiled_launches.restype = C.c_longlong
 lib.sdrhip_dc_blocker_workspace_bytes.argtypes = [C.c_int64]
@@ -383,6 +399,10 @@ class FmChain(_Handle):
     def max_halo(self):
         return lib.sdrhip_fm_chain_max_halo(self.h)
 
+    def halo_samples(self):
+        """max_halo rounded up to whole 16-byte vectors: the size of the halo message, the same on every rank."""
+        return int(lib.sdrhip_fm_chain_halo_samples(self.h))
+
     def workspace_bytes(self, n_in):
         return lib.sdrhip_fm_chain_workspace_bytes(self.h, n_in)
 
@@ -404,6 +424,65 @@ class FmChain(_Handle):
 
     def run(self, d_in_u8, s0, n_in, d_audio, q0, q1, d_ws, ws_bytes, stream=None):
         check(lib.sdrhip_fm_chain_run(self.h, stream, d_in_u8, s0, n_in, d_audio, q0, q1, d_ws, ws_bytes), "sdrhip_fm_chain_run")
+
+
+TRANSPORT_RCCL, TRANSPORT_PEER_COPY = 1, 2
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """The 128-byte rendezvous id rank 0 creates (ncclGetUniqueId) and hands to the other ranks out of band."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(lib.sdrhip_comm_get_unique_id(buf), "sdrhip_comm_get_unique_id")
+    return buf.raw
+
+
+class Comm(_Handle):
+    """One rank's communicator for the halo exchange (RCCL point-to-point inside libsdr_hip.so)."""
+    _destroy = lib.sdrhip_comm_destroy
+
+    def __init__(self, nranks=None, rank=None, uid=None, _adopt=None):
+        super().__init__()
+        if _adopt is not None:
+            self.h = _adopt
+            return
+        check(lib.sdrhip_comm_init_rank(C.byref(self.h), nranks, rank, uid), "sdrhip_comm_init_rank")
+
+    @staticmethod
+    def local(devices, transport=TRANSPORT_RCCL):
+        """All `devices` from this process: one Comm per device, rank i on devices[i]."""
+        n = len(devices)
+        hs = (_vp * n)()
+        devs = (C.c_int * n)(*devices)
+        check(lib.sdrhip_comm_init_local(hs, n, devs, transport), "sdrhip_comm_init_local")
+        return [Comm(_adopt=_vp(hs[i])) for i in range(n)]
+
+    @property
+    def rank(self):
+        return lib.sdrhip_comm_rank(self.h)
+
+    @property
+    def size(self):
+        return lib.sdrhip_comm_size(self.h)
+
+    @property
+    def transport(self):
+        return lib.sdrhip_comm_transport(self.h).decode()
+
+    def halo_exchange(self, d_send, d_recv, nbytes, stream=None):
+        check(lib.sdrhip_halo_exchange(self.h, stream, d_send, d_recv, nbytes), "sdrhip_halo_exchange")
+
+    def chain_halo_exchange(self, chain, d_buf, shard_samples, stream=None):
+        check(lib.sdrhip_fm_chain_halo_exchange(chain.h, self.h, stream, d_buf, shard_samples), "sdrhip_fm_chain_halo_exchange")
+
+
+def halo_exchange_all(comms, streams, d_send, d_recv, nbytes):
+    n = len(comms)
+    hs = (_vp * n)(*[c.h for c in comms])
+    ss = (_vp * n)(*[_vp(s) for s in streams])
+    sd = (_vp * n)(*[_vp(p) for p in d_send])
+    rv = (_vp * n)(*[_vp(p) for p in d_recv])
+    check(lib.sdrhip_halo_exchange_all(hs, n, ss, sd, rv, nbytes), "sdrhip_halo_exchange_all")
 
 
 class FmStream(_Handle):

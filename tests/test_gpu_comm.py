@@ -1,0 +1,110 @@
+"""The native halo exchange of the library (sdr_amd/csrc/comm.cpp): RCCL point-to-point and the
+single-process peer-copy transport, through the C ABI.  On a one-GPU box the ring closes on itself (a rank's right
+neighbour is the rank itself); with two or more devices the same tests run a real ring."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import signals as S
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "bin", "halo_ring")
+
+
+def _chain(L):
+    return L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), gain=0.2, block=8192)
+
+
+def _pattern(rank, n):
+    i = np.arange(n, dtype=np.int64)
+    return ((rank * 53 + i * 7 + (i >> 8)) & 0xFF).astype(np.uint8)
+
+
+def test_halo_size_is_the_composed_overlap(hip):
+    ch = _chain(hip)
+    h = ch.halo_samples()
+    assert h % 8 == 0 and ch.max_halo() <= h < ch.max_halo() + 8
+    assert 3000 < h < 6000          # ~ (127 + 8*(1 + 64 + 127*10/3)) input samples
+
+
+def test_rccl_ring_of_one_process_per_gpu(hip):
+    """sdrhip_comm_init_rank + sdrhip_fm_chain_halo_exchange, one communicator of size 1: send and receive to self."""
+    import torch
+    L = hip
+    ch = _chain(L)
+    shard, halo = 1 << 16, ch.halo_samples()
+    comm = L.Comm(1, 0, L.comm_unique_id())
+    assert comm.transport == "rccl" and comm.size == 1 and comm.rank == 0
+    buf = torch.zeros(2 * (shard + halo), dtype=torch.uint8, device="cuda")
+    buf[: 2 * shard] = torch.from_numpy(_pattern(0, 2 * shard)).cuda()
+    buf[2 * shard:] = 0xEE
+    st = torch.cuda.current_stream()
+    for _ in range(3):
+        comm.chain_halo_exchange(ch, buf.data_ptr(), shard, stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    got = buf[2 * shard:].cpu().numpy()
+    assert np.array_equal(got, _pattern(0, 2 * halo))
+    assert np.array_equal(buf[: 2 * shard].cpu().numpy(), _pattern(0, 2 * shard))      # the shard itself is untouched
+    comm.close()
+
+
+@pytest.mark.parametrize("transport", ["rccl", "peer-copy"])
+def test_single_process_ring_over_all_devices(hip, transport):
+    """sdrhip_comm_init_local + sdrhip_halo_exchange_all over every visible device (1 on the test box, 8 on a node)."""
+    import torch
+    L = hip
+    ndev = min(L.device_count(), 8)
+    t = L.TRANSPORT_RCCL if transport == "rccl" else L.TRANSPORT_PEER_COPY
+    comms = L.Comm.local(list(range(ndev)), t)
+    assert [c.rank for c in comms] == list(range(ndev)) and all(c.transport == transport for c in comms)
+    ch = _chain(L)
+    shard, halo = 1 << 16, ch.halo_samples()
+    bufs, streams = [], []
+    for r in range(ndev):
+        with torch.cuda.device(r):
+            b = torch.empty(2 * (shard + halo), dtype=torch.uint8, device=f"cuda:{r}")
+            b[: 2 * shard] = torch.from_numpy(_pattern(r, 2 * shard)).to(f"cuda:{r}")
+            b[2 * shard:] = 0xEE
+            bufs.append(b)
+            streams.append(torch.cuda.current_stream(r))
+    for r in range(ndev):
+        torch.cuda.synchronize(r)
+    for _ in range(2):
+        L.halo_exchange_all(comms, [s.cuda_stream for s in streams], [b.data_ptr() for b in bufs],
+                            [b.data_ptr() + 2 * shard for b in bufs], 2 * halo)
+    for r in range(ndev):
+        torch.cuda.synchronize(r)
+    for r in range(ndev):
+        got = bufs[r][2 * shard:].cpu().numpy()
+        assert np.array_equal(got, _pattern((r + 1) % ndev, 2 * halo)), f"rank {r}"
+    for c in comms:
+        c.close()
+
+
+def test_peer_copy_comm_refuses_the_per_rank_call(hip):
+    L = hip
+    comms = L.Comm.local([0], L.TRANSPORT_PEER_COPY)
+    with pytest.raises(L.SdrHipError):
+        comms[0].halo_exchange(1, 2, 16)
+    comms[0].close()
+
+
+def test_c_level_ring_one_process_per_rank(hip, tmp_path):
+    """examples/halo_ring.c: plain C over the C ABI, one PROCESS per GPU (two ranks when the box has two devices)."""
+    if not os.path.exists(EXE):
+        from sdr_amd import build as B
+        B.build()
+    assert os.path.exists(EXE)
+    nranks = min(hip.device_count(), 2)
+    idf = str(tmp_path / "rccl.id")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([EXE, str(nranks), str(r), idf, str(r), str(1 << 18), "3"], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(nranks)]
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, f"rank {r}: {err}"
+        assert f"halo_ring rank {r}/{nranks}: OK (rccl" in out
