@@ -5,15 +5,18 @@ Workload (BASELINE.json configs[2]; configs[4] for N > 1): the full FM chain of
 examples/fm/fm.hs:34-41 -- u8 IQ -> cfloat (fused) -> 127(->128)-tap complex FIR
 decimate-by-8 -> fmDemod -> polyphase resample 3/10 (191 taps) -> 128-tap (64
 half-tap) symmetric FIR -> *0.2 -- with the reference Pipes' 8192-sample block
-seams reproduced bit-exactly.  One "step" = one pass of that chain over one batch
-of `--blocks` 8192-sample blocks per GPU (default 65536 blocks = 2^29 samples = 1 GiB of u8 IQ),
-inputs already resident in HBM.
+seams reproduced bit-exactly.  One "pass" = that chain over one batch of `--blocks`
+8192-sample blocks per GPU (default 65536 blocks = 2^29 samples = 1 GiB of u8 IQ), inputs
+already resident in HBM; one "step" = `passes_per_step` passes (auto: ~50 ms of GPU time,
+so the default 20 steps keep the GPU busy for about a second).
 
-N > 1: one process per GPU (torch.distributed, backend "nccl" = RCCL).  The sample
-stream is sharded contiguously, rank r owning samples [r*S, (r+1)*S) of each
-super-block; every step each rank receives the head of its right neighbour's shard
-(the composed ntaps-1 overlap of all four stages, ~4.4k samples = 8.7 KB of u8)
-over RCCL send/recv and processes shard+halo.  Per-GPU work is fixed: weak scaling.
+N > 1: one process per GPU.  The sample stream is sharded contiguously, rank r owning
+samples [r*S, (r+1)*S) of each super-block; every pass each rank receives the head of its
+right neighbour's shard (the composed ntaps-1 overlap of all four stages, ~4.4k samples =
+8.7 KB of u8) through the LIBRARY's RCCL point-to-point (sdrhip_fm_chain_halo_exchange:
+ncclSend/ncclRecv on the compute stream) and processes shard+halo; torch.distributed (gloo)
+is only the control plane.  Per-GPU work is fixed: weak scaling.  The same run also reports
+BASELINE configs[4]'s shard size (2^20 samples per GPU per pass).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`
 (dominant kernel = the fused convert+decimate kernel, timed with HIP events on its
@@ -123,13 +126,22 @@ def cpu_baseline(seconds_single=6.0, seconds_all=8.0):
 
 
 # --------------------------------------------------------------------------------------
+def _sha256(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=65536, help="8192-sample blocks per GPU per step")
+    ap.add_argument("--blocks", type=int, default=65536, help="8192-sample blocks per GPU per pass")
+    ap.add_argument("--passes-per-step", type=int, default=0,
+                    help="passes of the chain over the batch that make one step (0 = auto: ~50 ms of GPU time per step, so that "
+                         "the default 20 steps keep the GPU busy for ~1 s and an outside utilisation sampler can see the run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the contract line (profiling runs)")
     ap.add_argument("--cpu-worker", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -160,168 +172,268 @@ def main():
     import signals as S
     from sdr_amd import sharding
 
-    # BENCH_BACKEND=gloo is a plumbing check only (several ranks may then share one GPU and the
-    # halo travels through host memory); the measured configuration is "nccl" = RCCL over xGMI.
-    backend = os.environ.get("BENCH_BACKEND", "nccl")
-    dev = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    # Control plane (rendezvous of the RCCL id, barriers, max-over-ranks of the timing): torch.distributed over gloo.
+    # Data plane (the halo exchange): the library's own RCCL point-to-point, sdrhip_fm_chain_halo_exchange (comm.cpp).
+    # BENCH_TRANSPORT=host is a plumbing check only (several ranks may then share one GPU; the halo travels through gloo).
+    transport = os.environ.get("BENCH_TRANSPORT", "rccl")
+    ndev = torch.cuda.device_count()
+    dev = local_rank % ndev
     torch.cuda.set_device(dev)
     L.check(L.lib.sdrhip_set_device(dev), "sdrhip_set_device")
+    comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if transport == "rccl":
+            ok = 1
             try:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
-                probe = torch.zeros(1, device="cuda")
-                dist.all_reduce(probe)               # creates the communicator now: an RCCL problem shows up here, not mid-run
-                torch.cuda.synchronize()
-            except Exception as e:                   # noqa: BLE001 -- SURVEY 8(e) fallback: same halos through host memory
-                sys.stderr.write(f"bench: RCCL initialisation failed ({e!r}); falling back to gloo (halo through host memory)\n")
+                box = [L.comm_unique_id() if rank == 0 else None]
+            except Exception as e:                   # noqa: BLE001
+                sys.stderr.write(f"bench: RCCL unavailable on rank 0 ({e!r})\n")
+                box, ok = [None], 0
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is not None:
                 try:
-                    dist.destroy_process_group()
-                except Exception:                    # noqa: BLE001
-                    pass
-                backend = "gloo"
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+                    comm = L.Comm(world, rank, box[0])
+                except Exception as e:               # noqa: BLE001 -- SURVEY 8(e) fallback: same halos through host memory
+                    sys.stderr.write(f"bench: sdrhip_comm_init_rank failed on rank {rank} ({e!r})\n")
+                    ok = 0
+            flag = torch.tensor([ok if box[0] is not None else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if not bool(flag.item()):
+                comm, transport = None, "host"
+                if rank == 0:
+                    sys.stderr.write("bench: falling back to the halo exchange through host memory (gloo)\n")
 
     chain = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), gain=0.2, block=BLOCK)
-    S_len = args.blocks * BLOCK
-    plan = sharding.ShardPlan(chain, rank, world, S_len)          # owned outputs + halo for this rank
-    gen = torch.Generator(device="cuda").manual_seed(S.SEED_IQ + rank)
-    buf = torch.randint(0, 256, (2 * (S_len + plan.halo_cap),), dtype=torch.uint8, device="cuda", generator=gen)
-    audio = torch.empty(plan.q1 - plan.q0, dtype=torch.float32, device="cuda")
-    ws_bytes = chain.workspace_bytes(S_len + plan.halo_cap)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
-    # N > 1: the halo (the right neighbour's first ~4k samples) is exchanged over RCCL while this rank already computes
-    # the outputs that need only its own samples, [q0, q_mid); the few that reach into the halo, [q_mid, q1), run on a
-    # second stream as soon as the halo has landed.  Two chain objects: each keeps its own timing events.
-    overlap = world > 1 and plan.q_mid > plan.q0 and os.environ.get("BENCH_NO_OVERLAP") != "1"
-    if overlap:
-        chain_b = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), gain=0.2, block=BLOCK)
-        aux = torch.cuda.Stream()
-        ws_b = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    def measure(blocks, steps, warmup, passes, ramp_s, timing):
+        """One configuration: `blocks` 8192-sample blocks per GPU per pass.  Returns the max-over-ranks wall time of
+        `steps` steps of `passes` passes each, the per-stage HIP-event times and the plan."""
+        S_len = blocks * BLOCK
+        plan = sharding.ShardPlan(chain, rank, world, S_len)          # owned outputs + halo for this rank
+        gen = torch.Generator(device="cuda").manual_seed(S.SEED_IQ + rank)
+        buf = torch.randint(0, 256, (2 * (S_len + plan.halo_cap),), dtype=torch.uint8, device="cuda", generator=gen)
+        audio = torch.empty(plan.q1 - plan.q0, dtype=torch.float32, device="cuda")
+        ws_bytes = chain.workspace_bytes(S_len + plan.halo_cap)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+        # N > 1: the halo (the right neighbour's first ~4k samples) travels while this rank already computes the outputs
+        # that need only its own samples, [q0, q_mid); the few that reach into the halo, [q_mid, q1), run on a second stream
+        # as soon as it has landed.  Two chain objects: each keeps its own timing events.
+        overlap = world > 1 and plan.q_mid > plan.q0 and os.environ.get("BENCH_NO_OVERLAP") != "1"
+        if overlap:
+            chain_b = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), gain=0.2, block=BLOCK)
+            aux = torch.cuda.Stream()
+            ws_b = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
 
-    def step():
-        if not overlap:
-            if world > 1:
-                sharding.halo_exchange(buf, plan, dist, via_host=(backend != "nccl"))   # send/recv of the ntaps-1 overlap
-            chain.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q1, ws.data_ptr(), ws_bytes,
-                      stream=sptr)
-            return
-        aux.wait_stream(stream)                      # the previous step's readers of the halo region are done
-        with torch.cuda.stream(aux):
-            if backend == "nccl":
-                for req in sharding.halo_exchange_start(buf, plan, dist):
-                    req.wait()                       # aux waits for RCCL's stream; the host does not block
+        def exchange(on_stream):
+            if comm is not None:
+                comm.chain_halo_exchange(chain, buf.data_ptr(), S_len, stream=on_stream.cuda_stream)   # ncclSend/ncclRecv on that stream
             else:
-                sharding.halo_exchange(buf, plan, dist, via_host=True)   # plumbing check (gloo): through host memory
-            if plan.q1 > plan.q_mid:
-                chain_b.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr() + 4 * (plan.q_mid - plan.q0), plan.q_mid, plan.q1,
-                            ws_b.data_ptr(), ws_bytes, stream=aux.cuda_stream)
-        chain.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q_mid, ws.data_ptr(), ws_bytes, stream=sptr)
-        stream.wait_stream(aux)
+                sharding.halo_exchange(buf, plan, dist, via_host=True)
 
-    if overlap:
-        try:                                         # never lose an N > 1 measurement to the scheduling refinement
-            step()
+        def one_pass():
+            if not overlap:
+                if world > 1:
+                    exchange(stream)
+                chain.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q1, ws.data_ptr(), ws_bytes, stream=sptr)
+                return
+            aux.wait_stream(stream)                      # the previous pass's readers of the halo region are done
+            with torch.cuda.stream(aux):
+                exchange(aux)
+                if plan.q1 > plan.q_mid:
+                    chain_b.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr() + 4 * (plan.q_mid - plan.q0), plan.q_mid, plan.q1,
+                                ws_b.data_ptr(), ws_bytes, stream=aux.cuda_stream)
+            chain.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q_mid, ws.data_ptr(), ws_bytes, stream=sptr)
+            stream.wait_stream(aux)
+
+        # Clock / power-state ramp: the first ~15 ms of sustained work of a fresh process run 10 % slow; spin for ramp_s first.
+        # With several ranks every pass is a send/recv with the neighbours, so all ranks must run the SAME number of passes: the
+        # decision to go on is taken collectively.
+        t_ramp = time.perf_counter()
+        while True:
+            go = time.perf_counter() - t_ramp < ramp_s
+            if world > 1:
+                flag = torch.tensor([1 if go else 0], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                go = bool(flag.item())
+            if not go:
+                break
+            one_pass()
             torch.cuda.synchronize()
-        except Exception as e:                       # noqa: BLE001
-            sys.stderr.write(f"bench: overlapped halo exchange failed ({e!r}); falling back to exchange-then-compute\n")
-            overlap = False
-
-    # Clock / power-state ramp: the first ~15 ms of sustained work on a fresh process run 10 % slow
-    # (interleaved A/B in tools/pipeline_ab.py); spin the same step for ~0.3 s before the W warmup steps.
-    # With several ranks every step is a send/recv with the neighbours, so all ranks must run the SAME number of steps: the
-    # decision to go on is taken collectively (a time-based loop per rank can differ by one step and then deadlocks).
-    t_ramp = time.perf_counter()
-    while True:
-        go = time.perf_counter() - t_ramp < 0.3
-        if world > 1:
-            flag = torch.tensor([1 if go else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            go = bool(flag.item())
-        if not go:
-            break
-        step()
+        if passes <= 0:
+            # auto: ~50 ms of GPU time per step, measured on this configuration (the same on every rank)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                one_pass()
+            torch.cuda.synchronize()
+            per = (time.perf_counter() - t0) / 4
+            pt = torch.tensor([max(1, min(2000, int(round(0.05 / max(per, 1e-6)))))], dtype=torch.int32)
+            if world > 1:
+                dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+            passes = int(pt.item())
+        for _ in range(warmup):
+            for _ in range(passes):
+                one_pass()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    chain.enable_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    stage_ms, runs = chain.read_timing()
-    chain.enable_timing(False)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if timing:
+            chain.enable_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for _ in range(passes):
+                one_pass()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        stage_ms, runs = ({}, 0)
+        if timing:
+            stage_ms, runs = chain.read_timing()
+            chain.enable_timing(False)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        crc = None
+        if os.environ.get("BENCH_CHECKSUM") == "1":      # plumbing checks: the same audio whichever way the pass is scheduled
+            import zlib
+            crc = [zlib.crc32(audio.cpu().numpy().tobytes())]
+            if world > 1:
+                gathered = [None] * world
+                dist.all_gather_object(gathered, crc[0])
+                crc = gathered
+        del buf, audio, ws
+        return {"elapsed": elapsed, "passes": passes, "stage_ms": stage_ms, "plan": plan, "S_len": S_len, "overlap": overlap, "crc": crc}
 
-    # BASELINE configs[1] (the north_star's roofline kernel): the same decimate-by-8 kernel fed
-    # cfloat IQ (8 B read + 1 B written per input sample), device-resident, 8192-sample seams.
+    dbg = (lambda m: sys.stderr.write(f"bench[{rank}]: {m}\n")) if os.environ.get("BENCH_DEBUG") else (lambda m: None)
+    main_run = measure(args.blocks, args.steps, args.warmup, args.passes_per_step, 0.3, True)
+    dbg("main measurement done")
+    extras = not args.no_extras
+
+    # BASELINE configs[4]'s shard size: 2^20 samples (128 blocks) per GPU per pass -- launch/latency-bound, the case where the
+    # halo exchange matters; reported next to the main line, same run
+    shard_1m = None
+    if extras and args.blocks != 128:
+        r1 = measure(128, max(2, args.steps // 4), 1, 0, 0.05, False)
+        shard_1m = {"samples_per_gpu_per_pass": r1["S_len"], "passes_per_step": r1["passes"],
+                    "value": round(world * r1["S_len"] * r1["passes"] * max(2, args.steps // 4) / r1["elapsed"] / 1e6, 1), "unit": "Msamples/s",
+                    "us_per_pass": round(r1["elapsed"] / (r1["passes"] * max(2, args.steps // 4)) * 1e6, 2),
+                    "note": "BASELINE configs[4] shard size (1M-sample block per GPU per pass): launch/latency-bound"}
+
+    dbg("shard_1m done")
+    # BASELINE configs[1] (the north_star's roofline kernel): the same decimate-by-8 kernel fed cfloat IQ (8 B read + 1 B
+    # written per input sample), device-resident, 8192-sample seams -- next to what the memory system of THIS box delivers
+    # in THIS process for the same traffic shape
     cfg1 = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and extras:
         n1 = 1 << 27
         k1 = (n1 - 128) // 8 + 1
         dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
-        x1 = torch.rand(2 * n1, device="cuda") * 2 - 1
-        o1 = torch.empty(2 * k1, device="cuda")
-        for _ in range(3):
-            dec.run(x1.data_ptr(), 0, o1.data_ptr(), 0, k1, BLOCK, stream=sptr)
+        o1 = torch.empty(2 * k1 + 64, device="cuda")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 10
-        e0.record(stream)
-        for _ in range(reps):
-            dec.run(x1.data_ptr(), 0, o1.data_ptr(), 0, k1, BLOCK, stream=sptr)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        t1 = e0.elapsed_time(e1) * 1e-3 / reps
-        cfg1 = {"kernel": "k_decimate_c4 (cfloat in) + seam fix-up", "samples_per_launch": n1,
-                "avg_launch_ms": round(t1 * 1e3, 5), "Msamples_per_s": round(n1 / t1 / 1e6, 1),
-                "bound": "hbm", "achieved": round(9.0 * n1 / t1 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(9.0 * n1 / t1 / 1e9 / HBM_PEAK_GBS, 4),
-                "read_only_frac": round(8.0 * n1 / t1 / 1e9 / HBM_PEAK_GBS, 4)}
-        del x1, o1
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        def timed(fn, reps=10, warm=3):
+            for _ in range(warm):
+                fn()
+            e0.record(stream)
+            for _ in range(reps):
+                fn()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
 
-    audio_crc = None
-    if os.environ.get("BENCH_CHECKSUM") == "1":      # plumbing checks: the same audio whichever way the step is scheduled
-        import zlib
-        audio_crc = [zlib.crc32(audio.cpu().numpy().tobytes())]
-        if world > 1:
-            gathered = [None] * world
-            dist.all_gather_object(gathered, audio_crc[0])
-            audio_crc = gathered
+        def k2c_line(x):
+            t = timed(lambda: dec.run(x.data_ptr(), 0, o1.data_ptr(), 0, k1, BLOCK, stream=sptr))
+            return {"avg_launch_ms": round(t * 1e3, 5), "Msamples_per_s": round(n1 / t / 1e6, 1),
+                    "achieved": round(9.0 * n1 / t / 1e9, 1), "frac": round(9.0 * n1 / t / 1e9 / HBM_PEAK_GBS, 4),
+                    "read_only_frac": round(8.0 * n1 / t / 1e9 / HBM_PEAK_GBS, 4)}, t
+
+        x_uni = torch.rand(2 * n1, device="cuda") * 2 - 1
+        uni, t_uni = k2c_line(x_uni)
+        dbg("cfg1 kernel done")
+        sout = torch.empty(n1 // 4 + 64, device="cuda")
+        t_plain = timed(lambda: L.check(L.lib.sdrhip_bench_stream_8to1(sptr, x_uni.data_ptr(), sout.data_ptr(), 8 * n1, 0)))
+        t_nt = timed(lambda: L.check(L.lib.sdrhip_bench_stream_8to1(sptr, x_uni.data_ptr(), sout.data_ptr(), 8 * n1, 1)))
+        half = (9 * n1 // 2) // 16 * 16
+        src_c = x_uni.view(torch.uint8)[:half]
+        dst_c = torch.empty(half, dtype=torch.uint8, device="cuda")
+        t_copy = timed(lambda: L.check(L.lib.sdrhip_bench_copy(sptr, src_c.data_ptr(), dst_c.data_ptr(), half)))
+        del dst_c
+        dbg("cfg1 ceilings done")
+        # the data the FM pipeline actually feeds this stage: convert(u8 IQ), i.e. cfloat values k/128 (SURVEY 8(d))
+        x_u8 = (torch.randint(0, 256, (2 * n1,), device="cuda", dtype=torch.uint8).to(torch.float32) - 128.0) * (1.0 / 128.0)
+        del x_uni
+        u8d, t_u8d = k2c_line(x_u8)
+        del x_u8, o1, sout
+        cfg1 = {"kernel": "k_decimate_c4 (cfloat in) + seam fix-up", "samples_per_launch": n1, "bound": "hbm", "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", **uni, "input": "uniform [-1,1) f32",
+                "input_convert_u8": {**u8d, "input": "convert(u8 IQ): the values the FM pipeline feeds this stage"},
+                "ceilings_same_process": {
+                    "stream_8to1_plain_loads": {"ms": round(t_plain * 1e3, 5), "read_only_frac": round(8.0 * n1 / t_plain / 1e9 / HBM_PEAK_GBS, 4)},
+                    "stream_8to1_nontemporal_loads": {"ms": round(t_nt * 1e3, 5), "read_only_frac": round(8.0 * n1 / t_nt / 1e9 / HBM_PEAK_GBS, 4)},
+                    "float4_copy_same_total_bytes": {"ms": round(t_copy * 1e3, 5), "total_GBps": round(2.0 * half / t_copy / 1e9, 1)},
+                    "kernel_over_plain_stream": round(t_plain / t_uni, 4), "kernel_over_float4_copy": round(t_copy / t_uni, 4),
+                    "what": "a kernel that reads the same 1 GiB with 16-byte loads and writes 128 MiB (no arithmetic), and a float4 "
+                            "copy moving the same 1.125 GiB in total; the decimator is power-limited (DESIGN.md 7): with the same loads "
+                            "and no traffic its MAC phase alone takes ~0.17-0.18 ms at a shader clock of ~1.65-1.75 GHz"}}
+
+    # Host-streamed operation (PCIe inclusive, never `value`): the C-ABI host-block operators at the reference's own block
+    # sizes, timed by the library's C loops (a compiled caller's cost per push; tools/host_stream_native.py)
+    dbg("cfg1 done")
+    host = None
+    if rank == 0 and world == 1 and extras:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import host_stream_native as H
+        host = {"unit": "Msamples/s of input (PCIe inclusive)", "cpu_single_thread_chain": cpu["single_thread_value"] if cpu else None}
+        for name, bpp, pushes, zc in (("fm_stream_1_block_per_push", 1, 4000, True), ("fm_stream_1_block_per_push_memcpy", 1, 4000, False),
+                                      ("fm_stream_16_blocks_per_push", 16, 1000, True), ("fm_stream_4096_blocks_per_push_zero_copy", 4096, 12, True)):
+            try:
+                sps, _ = H.fm_stream_rate(L, chain, bpp * BLOCK, pushes, zc)
+                host[name] = round(sps / 1e6, 1)
+                dbg(f"host {name} done")
+            except Exception as e:                      # noqa: BLE001
+                host[name] = f"failed: {e!r}"
+        try:
+            res = L.Resampler(3, 10, S.taps_resamp191(), L.ORDER_AVX)
+            pp = L.Pipe("resampler", res, BLOCK)
+            host["config3_firResampler_pipe_65536_float_blocks_Melements_per_s"] = round(H.pipe_rate(L, pp.h, 65536, 1, BLOCK, 2000, True) / 1e6, 1)
+            dec8 = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
+            pd = L.Pipe("decimator", dec8, BLOCK)
+            host["config1_firDecimator_pipe_8192_cfloat_blocks_Melements_per_s"] = round(H.pipe_rate(L, pd.h, BLOCK, 2, BLOCK, 2000, True) / 1e6, 1)
+        except Exception as e:                          # noqa: BLE001
+            host["pipes"] = f"failed: {e!r}"
 
     if rank == 0:
-        total_samples = world * S_len * args.steps
+        plan, S_len, passes, stage_ms = main_run["plan"], main_run["S_len"], main_run["passes"], main_run["stage_ms"]
+        elapsed = main_run["elapsed"]
+        total_samples = world * S_len * passes * args.steps
         k2_s = stage_ms["decimate"] * 1e-3
         k2_alg_bytes = 3.0 * plan.k2_samples                      # SURVEY 8(d): u8-fused K2 = 2 B read + 1 B written per input sample
         k2_flops = 64.0 * plan.k2_samples                         # 2*2*P/D unfused flop per input sample
-        achieved = k2_alg_bytes / k2_s / 1e9 if k2_s > 0 else 0.0
-        traffic = None
+        hbm_achieved = k2_alg_bytes / k2_s / 1e9 if k2_s > 0 else 0.0
+        valu_achieved = k2_flops / k2_s / 1e12 if k2_s > 0 else 0.0
+        traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "k2_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("samples_per_launch") == plan.k2_samples:
+                now = _sha256(os.path.join(ROOT, "sdr_amd", "csrc", "kernels_fast.hip"))
+                if tj.get("kernels_fast_sha256") != now:
+                    traffic_note = "profiles/k2_traffic.json was measured on another version of kernels_fast.hip: re-run tools/profile_bench.sh"
+                elif tj.get("samples_per_launch") != plan.k2_samples:
+                    traffic_note = "profiles/k2_traffic.json was measured at another launch size"
+                else:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        tail_ms = sum(stage_ms.get(k, 0.0) for k in ("fm_demod", "resample", "filter", "fused_tail"))
         result = {
             "metric": "Msamples/s through FM pipeline (decim8->demod->resamp3/10->filt)",
             "value": round(total_samples / elapsed / 1e6, 1),
@@ -335,36 +447,47 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            **({"audio_crc32_per_rank": audio_crc} if audio_crc is not None else {}),
+            **({"audio_crc32_per_rank": main_run["crc"]} if main_run["crc"] is not None else {}),
             "config": {
                 "workload": "full FM chain (u8 IQ -> decim8 127 taps -> fmDemod -> resamp 3/10 191 taps -> 128-tap sym filter -> *0.2), 8192-sample block seams",
-                "blocks_per_gpu_per_step": args.blocks,
-                "samples_per_gpu_per_step": S_len,
-                "sharding": "none" if world == 1 else f"contiguous shards x{world}, {backend} halo exchange of {plan.halo_cap} samples/step"
-                            + (", overlapped with the outputs that need no halo" if overlap else ""),
+                "blocks_per_gpu_per_pass": args.blocks,
+                "samples_per_gpu_per_pass": S_len,
+                "passes_per_step": passes,
+                "samples_per_gpu_per_step": S_len * passes,
+                "ms_per_pass": round(elapsed / (args.steps * passes) * 1e3, 4),
+                "sharding": "none" if world == 1 else f"contiguous shards x{world}, halo exchange of {plan.halo_cap} samples per pass"
+                            + (", overlapped with the outputs that need no halo" if main_run["overlap"] else ""),
+                "halo_transport": None if world == 1 else ("rccl: ncclSend/ncclRecv inside libsdr_hip.so (sdrhip_fm_chain_halo_exchange) on the compute stream"
+                                                           if comm is not None else "host memory through gloo (fallback / plumbing check)"),
                 "order": "AVX (bit-exact vs reference AVX path)",
             },
             "roofline": {
                 "kernel": "k_decimate_c4 (u8->cfloat convert fused + 128-tap complex decimate-by-8) + seam fix-up",
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "bound": "valu",
+                "achieved": round(valu_achieved, 2),
+                "peak": VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(valu_achieved / VALU_PEAK_TFLOPS, 4),
+                "peak_note": "f32 VALU with UNFUSED multiply and add (parity forbids FMA; MFMA is an fma chain): 256 CU x 4 SIMD x 32 lanes x 2.4 GHz",
                 "traffic": traffic,
+                **({"traffic_note": traffic_note} if traffic_note else {}),
                 "avg_launch_ms": round(stage_ms["decimate"], 5),
+                "algorithmic_flops_per_launch": k2_flops,
                 "algorithmic_bytes_per_launch": k2_alg_bytes,
-                "note": "this kernel is VALU-bound, not HBM-bound: see valu",
-                "valu": {"achieved": round(k2_flops / k2_s / 1e12, 2) if k2_s > 0 else 0.0, "peak": VALU_PEAK_TFLOPS,
-                         "unit": "TFLOP/s (unfused f32 mul+add)",
-                         "frac": round(k2_flops / k2_s / 1e12 / VALU_PEAK_TFLOPS, 4) if k2_s > 0 else 0.0},
+                "hbm": {"achieved": round(hbm_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 4),
+                        "note": "secondary roof: fusing the convert removed 85 % of this kernel's bytes"},
             },
             "roofline_config1_cfloat_decimate": cfg1,
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+            "tail_ms": round(tail_ms, 5),
+            "shard_1M_samples_per_gpu": shard_1m,
+            "host_streamed": host,
             "cpu_baseline": cpu,
         }
         print(json.dumps(result))
 
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -284,8 +284,14 @@ int sdrhip_fm_chain_run(sdrhip_fm_chain *c, void *stream, const uint8_t *d_in_iq
  * wait for the internal one before the call returns control of the stream.  Results do not
  * depend on nsub (every kernel works in global stream indices). */
 int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain *c, int nsub);
+/* fmDemod -> resampler -> audio filter (* gain) as ONE kernel (the demodulated and resampled streams never leave LDS)
+ * when the chain has the FM receiver's shape (3/10 resampler with 64-float groups, 64 half-tap symmetric filter, AVX
+ * order, buffers longer than one tile).  mode 0 = never (the three stage kernels), 1 = always, 2 = auto (default): only
+ * for runs of at most one tile (2046 audio outputs, i.e. pushes of one to six 8192-sample source blocks), where one
+ * launch replaces eight; on large batches the stage kernels are ~15 % faster (every stage is VALU-bound).  Same bits. */
+int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain *c, int mode);
 /* Per-stage timing with HIP events recorded around each stage's kernels on the stream they are
- * launched on; stages {decimate(+seam fix-up), fmDemod, resample, filter(+gain), unused}.
+ * launched on; stages {decimate(+seam fix-up), fmDemod, resample, filter(+gain), fused tail (the three in one kernel)}.
  * read_timing waits for the recorded runs, returns the SUM of elapsed ms per stage over
  * `*runs` runs and resets the recorder.  With pipelining on, stages of neighbouring sub-batches
  * overlap in time, so the per-stage sums add up to more than the run's wall time. */
@@ -361,6 +367,14 @@ int sdrhip_fm_stream_pop(sdrhip_fm_stream *st, float *out, int capacity);
  * of this box delivers in this process, measured next to the kernel. */
 int sdrhip_bench_stream_8to1(void *stream, const void *d_in, void *d_out, size_t bytes_in, int non_temporal);
 int sdrhip_bench_copy(void *stream, const void *d_in, void *d_out, size_t bytes);
+/* Timing loops over the host-block operators, written against this header only: what a compiled caller pays per push
+ * (a Python loop adds 10-20 us per call).  fm_stream: `pushes` pushes of n_samples u8 IQ samples (zero_copy: through
+ * sdrhip_fm_stream_input_buffer), every audio block popped; pipe: pushes of n elements into an existing pipe. */
+struct sdrhip_pipe;
+int sdrhip_bench_fm_stream(sdrhip_fm_chain *chain, int n_samples, int pushes, int zero_copy, int coalesce_samples,
+                           double *samples_per_s, long long *audio_blocks);
+int sdrhip_bench_pipe(struct sdrhip_pipe *p, int n, int floats_per_element, int block_size_out, int pushes, int zero_copy,
+                      double *elements_per_s);
 
 /* ------------------------------------------------------------------------ */
 /* (3) Pipe operators on host blocks                                        */

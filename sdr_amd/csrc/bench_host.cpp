@@ -1,0 +1,101 @@
+// bench_host.cpp -- measurement utilities (NOT part of the FM path): timing loops over the host-block operators written
+// against the PUBLIC C ABI only, so that bench.py reports what a compiled caller (the Haskell pipeline, examples/fm_replay.c)
+// pays per push -- a Python loop adds 10-20 us of interpreter and ctypes overhead to every call, which at the reference's
+// block size (8192 samples) is as much as the work itself.
+#include <string.h>
+
+#include <chrono>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace sdrhip;
+
+extern "C" {
+
+// Push `pushes` batches of `n_samples` u8 IQ samples through a fresh sdrhip_fm_stream on `chain` and pop every audio
+// block; zero_copy: the source writes into the operator's pinned staging buffer (as the RTL-SDR read would), else
+// sdrhip_fm_stream_push copies from the caller's buffer.  *samples_per_s = n_samples * pushes / wall time (flush included).
+int sdrhip_bench_fm_stream(sdrhip_fm_chain* chain, int n_samples, int pushes, int zero_copy, int coalesce_samples, double* samples_per_s,
+                           long long* audio_blocks)
+{
+    SDRHIP_REQUIRE(chain != nullptr && n_samples > 0 && pushes > 0 && samples_per_s != nullptr, "sdrhip_bench_fm_stream");
+    sdrhip_fm_stream* st = nullptr;
+    int rc = sdrhip_fm_stream_create(&st, chain, n_samples, 8192);
+    if (rc != SDRHIP_OK) return rc;
+    if (coalesce_samples > 0 && (rc = sdrhip_fm_stream_set_coalesce(st, coalesce_samples)) != SDRHIP_OK) { sdrhip_fm_stream_destroy(st); return rc; }
+    std::vector<uint8_t> src((size_t)2 * n_samples);
+    uint32_t s = 12345u;
+    for (auto& b : src) { s = s * 1664525u + 1013904223u; b = (uint8_t)(s >> 24); }
+    std::vector<float> out(8192);
+    long long blocks = 0;
+    auto one = [&](int i) -> int {
+        int ready;
+        if (zero_copy) {
+            uint8_t* dst = sdrhip_fm_stream_input_buffer(st);
+            if (!dst) return SDRHIP_ERR_STATE;
+            if ((i & 63) == 0) memcpy(dst, src.data(), src.size());       // the "radio": fresh data now and then, stale bytes otherwise
+            ready = sdrhip_fm_stream_push(st, dst, n_samples);
+        } else {
+            ready = sdrhip_fm_stream_push(st, src.data(), n_samples);
+        }
+        if (ready < 0) return ready;
+        while (ready-- > 0) {
+            if (sdrhip_fm_stream_pop(st, out.data(), 8192) > 0) blocks++;
+        }
+        return SDRHIP_OK;
+    };
+    const int warm = pushes / 10 + 4;
+    for (int i = 0; i < warm; i++)
+        if ((rc = one(i)) != SDRHIP_OK) { sdrhip_fm_stream_destroy(st); return rc; }
+    blocks = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < pushes; i++)
+        if ((rc = one(i)) != SDRHIP_OK) { sdrhip_fm_stream_destroy(st); return rc; }
+    int ready = sdrhip_fm_stream_flush(st);
+    while (ready-- > 0)
+        if (sdrhip_fm_stream_pop(st, out.data(), 8192) > 0) blocks++;
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *samples_per_s = (double)n_samples * pushes / dt;
+    if (audio_blocks) *audio_blocks = blocks;
+    sdrhip_fm_stream_destroy(st);
+    return SDRHIP_OK;
+}
+
+// The same for one Pipe (firDecimator / firFilter / firResampler): `n` elements per push (floats, or complex pairs for a
+// complex stage), zero-copy staging or not; *elements_per_s = n * pushes / wall time.
+int sdrhip_bench_pipe(sdrhip_pipe* p, int n, int floats_per_element, int block_size_out, int pushes, int zero_copy, double* elements_per_s)
+{
+    SDRHIP_REQUIRE(p != nullptr && n > 0 && pushes > 0 && elements_per_s != nullptr && floats_per_element >= 1, "sdrhip_bench_pipe");
+    std::vector<float> src((size_t)n * floats_per_element);
+    uint32_t s = 777u;
+    for (auto& v : src) { s = s * 1664525u + 1013904223u; v = (float)(int32_t)s * (1.0f / 2147483648.0f); }
+    std::vector<float> out((size_t)block_size_out * 2);
+    auto one = [&](int i) -> int {
+        int ready;
+        if (zero_copy) {
+            float* dst = sdrhip_pipe_input_buffer(p, n);
+            if (!dst) return SDRHIP_ERR_STATE;
+            if ((i & 63) == 0) memcpy(dst, src.data(), src.size() * sizeof(float));
+            ready = sdrhip_pipe_push(p, dst, n);
+        } else {
+            ready = sdrhip_pipe_push(p, src.data(), n);
+        }
+        if (ready < 0) return ready;
+        while (ready-- > 0) (void)sdrhip_pipe_pop(p, out.data(), (int)out.size());
+        return SDRHIP_OK;
+    };
+    int rc;
+    for (int i = 0; i < pushes / 10 + 4; i++)
+        if ((rc = one(i)) != SDRHIP_OK) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < pushes; i++)
+        if ((rc = one(i)) != SDRHIP_OK) return rc;
+    int ready = sdrhip_pipe_flush(p);
+    while (ready-- > 0) (void)sdrhip_pipe_pop(p, out.data(), (int)out.size());
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *elements_per_s = (double)n * pushes / dt;
+    return SDRHIP_OK;
+}
+
+}  // extern "C"

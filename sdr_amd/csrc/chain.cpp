@@ -9,6 +9,7 @@
 //   inOff(m) = ceil(m*D2/I2)) -> q audio outputs (window [q, q+L3)).
 // Seams: all four Pipes of fm.hs run with blockSizeOut = `block` and the source
 // delivers `block`-sample buffers, so each stage's input blocks are `block` long.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -17,7 +18,7 @@
 
 using namespace sdrhip;
 
-static const int kStages = 5;  // decimate(+seam fix-up), fmDemod, resample, filter, gain
+static const int kStages = 5;  // decimate(+seam fix-up), fmDemod, resample, filter, fused tail (fmDemod+resample+filter+gain in one kernel)
 
 struct sdrhip_fm_chain {
     FirDesc decim;     // complex, factor D1
@@ -41,6 +42,18 @@ struct sdrhip_fm_chain {
     // (nsub 4) and 1.219 (nsub 8) with it -- every kernel of the chain is VALU-issue-bound, so co-resident
     // kernels only take issue slots from each other, and the extra launches cost more than they hide.
     int nsub = 1;
+    // fmDemod -> resampler -> audio filter (* gain) as ONE kernel (kernels_tail.hip), y and z never leaving LDS.  Measured on
+    // MI355X (2^29 samples per run): 0.43-0.49 ms against 0.38 + 0.02 ms for the three stage kernels and their seam fix-ups --
+    // every stage is VALU-bound, fusion saves HBM traffic that was not the limit and pays 7 % recomputed overlap; but a run
+    // that fills at most one tile (a push of one to six 8192-sample source blocks) costs ONE launch of a few microseconds
+    // instead of eight.  mode 0 = never, 1 = always, 2 = auto (runs of at most one tile): sdrhip_fm_chain_set_fused_tail,
+    // SDRHIP_FUSED_TAIL=0/1/2.
+    int fused_tail = getenv("SDRHIP_FUSED_TAIL") ? atoi(getenv("SDRHIP_FUSED_TAIL")) : 2;
+    bool tail_shape_ok(int64_t n_out) const
+    {
+        if (fused_tail == 0 || (fused_tail == 2 && n_out > kTailTileOutputs)) return false;
+        return !resamp.cplx && resamp.lanes == 8 && !audio.cplx && audio.sym && audio.lanes == 8 && audio.factor == 1;
+    }
     hipStream_t aux = nullptr;
     std::vector<hipEvent_t> ev_k2;       // per sub-batch: decimator output ready
     hipEvent_t ev_done = nullptr;        // aux finished this run
@@ -335,6 +348,19 @@ int sdrhip_fm_chain_run(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
             SDRHIP_CHECK_HIP(hipEventRecord(c->ev_k2[i], s));
             SDRHIP_CHECK_HIP(hipStreamWaitEvent(st, c->ev_k2[i], 0));
         }
+        if (c->tail_shape_ok(r.q1 - r.q0)) {
+            if ((rc = c->resamp.ensure_device()) != SDRHIP_OK || (rc = c->audio.ensure_device()) != SDRHIP_OK) return rc;
+            if ((rc = begin_span(4, st, &b)) != SDRHIP_OK) return rc;
+            const bool took = launch_fm_tail_fused(st, d_d, r.kd0, r.kd1, r.ky0, r.ky1, d_audio + (r.q0 - q0), r.q0, r.q1, c->resamp.d_groups,
+                                                   c->resamp.row_stride, c->resamp.nloop, c->resamp.increments.data(), c->resamp.num_groups,
+                                                   c->resamp.I, c->resamp.D, c->resamp.Lp, c->resamp.d_plain, c->resamp.ntaps, c->audio.d_taps,
+                                                   c->audio.ntaps_kernel, c->audio.d_cross, c->gain, c->block);
+            if (took) {
+                if ((rc = end_span(4, st, b)) != SDRHIP_OK) return rc;
+                continue;
+            }
+            if (c->timing && c->ev_used > 0) c->ev_used--;      // the span's begin event goes back to the pool
+        }
         // K3: fmDemod; at stream start the carried sample is 0 (Demod.hs:41)
         if ((rc = begin_span(1, st, &b)) != SDRHIP_OK) return rc;
         launch_fm_demod_fast(st, d_d + 2 * (r.ky0 - r.kd0), d_y, r.ky1 - r.ky0, r.ky0 > r.kd0, 0.0f, 0.0f);
@@ -362,6 +388,13 @@ int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain* c, int nsub)
 {
     SDRHIP_REQUIRE(c != nullptr && nsub >= 1 && nsub <= 16, "sdrhip_fm_chain_set_pipelining");
     c->nsub = nsub;
+    return SDRHIP_OK;
+}
+
+int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain* c, int enable)
+{
+    SDRHIP_REQUIRE(c != nullptr && enable >= 0 && enable <= 2, "sdrhip_fm_chain_set_fused_tail");
+    c->fused_tail = enable;
     return SDRHIP_OK;
 }
 
@@ -400,32 +433,40 @@ int sdrhip_fm_chain_read_timing(sdrhip_fm_chain* c, double* ms_sum, int* runs)
 // memory, `block` samples each -- or a multiple) go in, audio blocks of exactly `block_size_out`
 // floats come out, bit-identical to what the reference's four Pipes + convert + gain yield.
 //
-// Per push: the block is copied into a pinned staging buffer, uploaded with hipMemcpyAsync on an
-// upload stream behind the carried tail (the samples earlier pushes received but later outputs still
-// need), the chain runs on the compute stream for every audio output whose receptive field is now
-// complete, and the result is downloaded on a third stream.  Two slots alternate, so the upload of
-// block i overlaps the compute of block i-1 and the download of block i-2; results lag one push
-// (sdrhip_fm_stream_flush drains).
+// Per submission the pinned staging buffer of the current slot holds [carried tail | new samples]
+// contiguously: the tail (the ~4.4k samples earlier pushes delivered and later outputs still need) is
+// kept in a small host-side history and copied in front of the new samples by the host (8 KB), so the
+// device never shuffles it.  Then
+//   * large submissions: ONE hipMemcpyAsync H2D on the upload stream, the chain on the compute stream,
+//     one D2H on the download stream -- three HIP streams, two slots, upload of block i over compute
+//     of i-1 over download of i-2;
+//   * small submissions (<= kDirectSamples): NO copies at all -- the decimator kernel reads the pinned
+//     host buffer directly over PCIe and the last kernel writes the audio straight into pinned host
+//     memory: three kernel launches and one event per push instead of ~15 API calls, which is what
+//     the reference's own block size (8192 samples) needs to beat one CPU thread.
+// Results lag one push (sdrhip_fm_stream_flush drains).
 // ---------------------------------------------------------------------------
 struct sdrhip_fm_stream {
     sdrhip_fm_chain* c = nullptr;
     int max_block = 0;
     int block_out = 0;
     hipStream_t compute = nullptr, up = nullptr, down = nullptr;
-    hipEvent_t ev_tail = nullptr;
-    bool tail_pending = false;
-    DevBuf din[2];
+    DevBuf din[2];         // device input of the two slots (copy mode)
     DevBuf ws;
-    int cur = 0;
-    int64_t base = 0;      // global sample index of din[cur][0]
     int64_t N = 0;         // samples received so far
     int64_t q_done = 0;    // audio outputs computed so far
+    int64_t head_cap = 0;  // samples of room in front of the staged samples (for the carried tail), multiple of 8
+    std::vector<uint8_t> hist;   // the last `head_cap` samples of the stream (host copy)
+    int64_t hist_n = 0;          // valid samples in hist (they are the stream's samples [N - hist_n, N))
+    bool direct_ok = getenv("SDRHIP_NO_DIRECT_STREAM") == nullptr;
+    static constexpr int64_t kDirectSamples = 65536;      // [tail | new] up to this many samples is read in place over PCIe
     struct Slot {
         PinBuf hin, hout;
         DevBuf dout;
         hipEvent_t ev = nullptr, ev_up = nullptr, ev_k = nullptr;
         int64_t n_out = 0;
         bool busy = false;
+        bool direct = false;       // the last submission ran in place: `ev` also releases the staging buffer
     } slot[2];
     int64_t pushes = 0;        // submissions so far (slot = pushes & 1)
     int staged = 0;            // samples copied into the current slot's staging buffer, not yet submitted
@@ -441,11 +482,11 @@ struct sdrhip_fm_stream {
         for (auto& sl : slot)
             for (hipEvent_t e : {sl.ev, sl.ev_up, sl.ev_k})
                 if (e) (void)hipEventDestroy(e);
-        if (ev_tail) (void)hipEventDestroy(ev_tail);
         for (hipStream_t st : {up, compute, down})
             if (st) (void)hipStreamDestroy(st);
     }
     int ready() const { return (int)((fifo.size() - head) / (size_t)block_out); }
+    uint8_t* staged_base(Slot& sl) const { return (uint8_t*)sl.hin.p + 2 * head_cap; }    // where staged sample 0 lives
     int harvest(int si)
     {
         Slot& sl = slot[si];
@@ -473,13 +514,15 @@ int sdrhip_fm_stream_create(sdrhip_fm_stream** out, sdrhip_fm_chain* chain, int 
     st->c = chain;
     st->max_block = max_block_samples;
     st->block_out = block_size_out;
+    // the carried tail never exceeds the receptive field of one audio output (+ the 8-sample alignment of its start)
+    st->head_cap = (sdrhip_fm_chain_max_halo(chain) + 8 + 15) / 8 * 8;
+    st->hist.resize((size_t)(2 * st->head_cap));
     hipError_t e = hipStreamCreateWithFlags(&st->compute, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->up, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->down, hipStreamNonBlocking);
     for (auto& sl : st->slot)
         for (hipEvent_t* ev : {&sl.ev, &sl.ev_up, &sl.ev_k})
             if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_tail, hipEventDisableTiming);
     if (e != hipSuccess) {
         set_error("sdrhip_fm_stream_create: %s", hipGetErrorString(e));
         delete st;
@@ -494,7 +537,7 @@ void sdrhip_fm_stream_destroy(sdrhip_fm_stream* st) { delete st; }
 }  // extern "C"
 
 
-// Submit everything staged in the current slot: carried tail + staged samples -> device, chain, audio -> host.
+// Submit everything staged in the current slot: [carried tail | staged samples] -> chain -> audio -> host.
 static int stream_submit(sdrhip_fm_stream* st)
 {
     sdrhip_fm_chain* c = st->c;
@@ -507,44 +550,64 @@ static int stream_submit(sdrhip_fm_stream* st)
     const int64_t N1 = st->N + n;
     int64_t q_new = sdrhip_fm_chain_ready(c, N1);
     if (q_new < st->q_done) q_new = st->q_done;
-    // device input = [carried tail | new samples]; the tail starts at the first sample the next pending output
-    // needs, rounded down to a multiple of 8 samples (16-byte aligned tiles for the LDS-tiled decimator)
+    // the tail starts at the first sample the next pending output needs, rounded down to a multiple of 8 samples
+    // (16-byte aligned tiles for the LDS-tiled decimator)
     int64_t keep_from = c->start(st->q_done) & ~(int64_t)7;
     if (keep_from > st->N) keep_from = st->N & ~(int64_t)7;
     const int64_t tail = st->N - keep_from;
-    DevBuf& prev = st->din[st->cur];
-    DevBuf& next = st->din[st->cur ^ 1];
-    if ((rc = next.ensure((size_t)(tail + n) * 2 + 64)) != SDRHIP_OK) return rc;
-    if (st->tail_pending) SDRHIP_CHECK_HIP(hipStreamWaitEvent(st->up, st->ev_tail, 0));
-    st->tail_pending = false;
-    if (tail > 0)
-        SDRHIP_CHECK_HIP(hipMemcpyAsync(next.p, (const char*)prev.p + (size_t)(keep_from - st->base) * 2, (size_t)tail * 2,
-                                        hipMemcpyDeviceToDevice, st->compute));
-    // everything queued so far that reads `prev` (earlier chain runs, this tail copy) precedes this event;
-    // the NEXT submission uploads into `prev` and waits for it
-    SDRHIP_CHECK_HIP(hipEventRecord(st->ev_tail, st->compute));
-    st->tail_pending = true;
-    SDRHIP_CHECK_HIP(hipMemcpyAsync((char*)next.p + (size_t)tail * 2, sl.hin.p, (size_t)n * 2, hipMemcpyHostToDevice, st->up));
-    SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, st->up));
-    SDRHIP_CHECK_HIP(hipStreamWaitEvent(st->compute, sl.ev_up, 0));
-    st->cur ^= 1;
-    st->base = keep_from;
+    if (tail > st->hist_n || tail > st->head_cap) {
+        set_error("sdrhip_fm_stream: carried tail of %lld samples exceeds the history (%lld)", (long long)tail, (long long)st->hist_n);
+        return SDRHIP_ERR_STATE;
+    }
+    uint8_t* first = st->staged_base(sl) - 2 * tail;               // 16-byte aligned: tail and head_cap are multiples of 8 samples
+    if (tail > 0) memcpy(first, st->hist.data() + 2 * (st->hist_n - tail), (size_t)(2 * tail));
+    // history for the next submission: the last head_cap samples of [tail | staged] (the tail alone may not reach back far
+    // enough, the staged samples alone may be fewer than head_cap)
+    {
+        const int64_t have = tail + n;
+        const int64_t keep = have < st->head_cap ? have : st->head_cap;
+        memmove(st->hist.data(), first + 2 * (have - keep), (size_t)(2 * keep));
+        st->hist_n = keep;
+    }
 
     const int64_t n_out = q_new - st->q_done;
+    const bool direct = st->direct_ok && tail + n <= sdrhip_fm_stream::kDirectSamples;
     sl.n_out = 0;
     if (n_out > 0) {
         const size_t wsb = sdrhip_fm_chain_workspace_bytes(c, tail + n);
         if ((rc = st->ws.ensure(wsb)) != SDRHIP_OK) return rc;
-        if ((rc = sl.dout.ensure((size_t)n_out * 4)) != SDRHIP_OK) return rc;
         if ((rc = sl.hout.ensure((size_t)n_out * 4)) != SDRHIP_OK) return rc;
-        if ((rc = sdrhip_fm_chain_run(c, (void*)st->compute, (const uint8_t*)next.p, keep_from, tail + n, (float*)sl.dout.p,
-                                      st->q_done, q_new, st->ws.p, st->ws.cap)) != SDRHIP_OK) return rc;
-        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, st->compute));
-        SDRHIP_CHECK_HIP(hipStreamWaitEvent(st->down, sl.ev_k, 0));
-        SDRHIP_CHECK_HIP(hipMemcpyAsync(sl.hout.p, sl.dout.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st->down));
-        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, st->down));
-        sl.n_out = n_out;
-        sl.busy = true;
+    }
+    if (direct) {
+        // zero-copy: the kernels read the pinned staging buffer and write the pinned result buffer themselves
+        if (n_out > 0) {
+            if ((rc = sdrhip_fm_chain_run(c, (void*)st->compute, (const uint8_t*)sl.hin.dev_ptr(first), keep_from, tail + n,
+                                          (float*)sl.hout.dev, st->q_done, q_new, st->ws.p, st->ws.cap)) != SDRHIP_OK) return rc;
+            sl.n_out = n_out;
+            sl.busy = true;
+        }
+        // ONE event per push: the results are in pinned memory and the staging buffer is free again when the kernels are done
+        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, st->compute));
+        sl.direct = true;
+    } else {
+        DevBuf& dbuf = st->din[si];
+        if ((rc = dbuf.ensure((size_t)(tail + n) * 2 + 64)) != SDRHIP_OK) return rc;
+        // slot si's device buffer was last read by the chain run of submission i-2, harvested before this slot was reopened
+        SDRHIP_CHECK_HIP(hipMemcpyAsync(dbuf.p, first, (size_t)(tail + n) * 2, hipMemcpyHostToDevice, st->up));
+        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, st->up));
+        sl.direct = false;
+        if (n_out > 0) {
+            SDRHIP_CHECK_HIP(hipStreamWaitEvent(st->compute, sl.ev_up, 0));
+            if ((rc = sl.dout.ensure((size_t)n_out * 4)) != SDRHIP_OK) return rc;
+            if ((rc = sdrhip_fm_chain_run(c, (void*)st->compute, (const uint8_t*)dbuf.p, keep_from, tail + n, (float*)sl.dout.p,
+                                          st->q_done, q_new, st->ws.p, st->ws.cap)) != SDRHIP_OK) return rc;
+            SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, st->compute));
+            SDRHIP_CHECK_HIP(hipStreamWaitEvent(st->down, sl.ev_k, 0));
+            SDRHIP_CHECK_HIP(hipMemcpyAsync(sl.hout.p, sl.dout.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st->down));
+            SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, st->down));
+            sl.n_out = n_out;
+            sl.busy = true;
+        }
     }
     st->q_done = q_new;
     st->N = N1;
@@ -553,16 +616,16 @@ static int stream_submit(sdrhip_fm_stream* st)
     return st->harvest(si ^ 1);
 }
 
-// make the current slot's staging buffer writable (its previous upload and download are over)
+// make the current slot's staging buffer writable (its previous upload / in-place read and its download are over)
 static int stream_open_slot(sdrhip_fm_stream* st)
 {
     sdrhip_fm_stream::Slot& sl = st->slot[st->pushes & 1];
     int rc;
     if (st->staged == 0) {
         if ((rc = st->harvest((int)(st->pushes & 1))) != SDRHIP_OK) return rc;
-        SDRHIP_CHECK_HIP(hipEventSynchronize(sl.ev_up));
+        SDRHIP_CHECK_HIP(hipEventSynchronize(sl.direct ? sl.ev : sl.ev_up));
     }
-    return sl.hin.ensure((size_t)st->capacity() * 2);
+    return sl.hin.ensure((size_t)(st->head_cap + st->capacity()) * 2);
 }
 
 extern "C" {
@@ -583,7 +646,7 @@ uint8_t* sdrhip_fm_stream_input_buffer(sdrhip_fm_stream* st)
     // the caller may write up to max_block samples: make room for all of them behind what is already staged
     if (st->staged + st->max_block > st->capacity() && stream_submit(st) != SDRHIP_OK) return nullptr;
     if (stream_open_slot(st) != SDRHIP_OK) return nullptr;
-    return (uint8_t*)st->slot[st->pushes & 1].hin.p + (size_t)st->staged * 2;
+    return st->staged_base(st->slot[st->pushes & 1]) + (size_t)st->staged * 2;
 }
 
 int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
@@ -594,7 +657,7 @@ int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
     int rc;
     if (st->staged + n > st->capacity() && (rc = stream_submit(st)) != SDRHIP_OK) return rc;
     if ((rc = stream_open_slot(st)) != SDRHIP_OK) return rc;
-    uint8_t* dst = (uint8_t*)st->slot[st->pushes & 1].hin.p + (size_t)st->staged * 2;
+    uint8_t* dst = st->staged_base(st->slot[st->pushes & 1]) + (size_t)st->staged * 2;
     if (iq != dst) memcpy(dst, iq, (size_t)n * 2);   // else: the caller filled our staging buffer in place
     st->staged += n;
     if (st->staged >= st->coalesce && (rc = stream_submit(st)) != SDRHIP_OK) return rc;

@@ -72,15 +72,17 @@ struct DevBuf {
     ~DevBuf() { release(); }
 };
 
-// Grow-only pinned host buffer.
+// Grow-only pinned host buffer.  dev = the address kernels use to read / write it in place (zero-copy over PCIe).
 struct PinBuf {
     void* p = nullptr;
+    void* dev = nullptr;
     size_t cap = 0;
     int ensure(size_t bytes)
     {
         if (bytes <= cap) return SDRHIP_OK;
         if (p) (void)hipHostFree(p);
         p = nullptr;
+        dev = nullptr;
         cap = 0;
         size_t want = bytes + bytes / 4 + 256;
         hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
@@ -88,13 +90,19 @@ struct PinBuf {
             set_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
             return SDRHIP_ERR_NOMEM;
         }
+        if (hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            dev = p;                       // unified addressing: the host pointer is the device pointer
+        }
         cap = want;
         return SDRHIP_OK;
     }
+    void* dev_ptr(const void* host) const { return (char*)dev + ((const char*)host - (const char*)p); }
     void release()
     {
         if (p) (void)hipHostFree(p);
         p = nullptr;
+        dev = nullptr;
         cap = 0;
     }
     ~PinBuf() { release(); }

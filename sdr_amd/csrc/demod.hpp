@@ -1,0 +1,91 @@
+// demod.hpp -- fmDemod's per-sample arithmetic (Demod.hs:21-46 + GHC base atan2 + fdlibm atanf), shared by the
+// stand-alone kernel (kernels_chain.hip) and the fused tail kernel (kernels_tail.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sdrhip {
+
+// ---------------------------------------------------------------------------
+// K3  fmDemod, Demod.hs:21-46 (+ GHC base atan2, glibc/fdlibm atanf).  Same
+// operations in the same order as device_atanf/ghc_atan2 of kernels_generic.hip, but
+// every data-dependent branch is a select: on noise-like IQ all of fdlibm's five
+// argument ranges occur in every wave, so branches would serialise all of them.
+// ---------------------------------------------------------------------------
+// Every alternative is first computed into a local and then chosen with a ternary whose arms are locals or constants:
+// clang lowers exactly that shape to `select` (v_cndmask); an arithmetic expression inside an arm, or a nested ternary,
+// becomes control flow instead -- one basic block per range per sample, which serialises the samples a thread works on
+// (no instruction-level parallelism across them) and costs exec-mask bookkeeping.  Speculating the arms is free of side
+// effects: they are single additions / multiplications.
+__device__ __forceinline__ float sel(bool c, float a, float b) { return c ? a : b; }
+
+__device__ __forceinline__ float atanf_sel(float x)
+{
+    const uint32_t hx = __float_as_uint(x);
+    const uint32_t ix = hx & 0x7fffffffu;
+    const bool neg = (hx >> 31) != 0;
+    const float ax = __uint_as_float(ix);
+    const bool tiny_range = ix < 0x3ee00000u;                 // |x| < 0.4375: no reduction, keeps sign
+    const bool r0 = !tiny_range & (ix < 0x3f300000u);
+    const bool r1 = !tiny_range & !r0 & (ix < 0x3f980000u);
+    const bool r2 = !tiny_range & !r0 & !r1 & (ix < 0x401c0000u);
+    // numerator / denominator of the reduction; x/1 is exact so the unreduced range shares the divide
+    const float n0 = 2.0f * ax - 1.0f, n1 = ax - 1.0f, n2 = ax - 1.5f;
+    const float d0 = 2.0f + ax, d1 = ax + 1.0f, d2 = 1.0f + 1.5f * ax;
+    const float num = sel(tiny_range, x, sel(r0, n0, sel(r1, n1, sel(r2, n2, -1.0f))));
+    const float den = sel(tiny_range, 1.0f, sel(r0, d0, sel(r1, d1, sel(r2, d2, ax))));
+    const float xr = num / den;
+    const float hv = sel(r0, 4.6364760399e-01f, sel(r1, 7.8539812565e-01f, sel(r2, 9.8279368877e-01f, 1.5707962513e+00f)));
+    const float lv = sel(r0, 5.0121582440e-09f, sel(r1, 3.7748947079e-08f, sel(r2, 3.4473217170e-08f, 7.5497894159e-08f)));
+    const float z = xr * xr;
+    const float w = z * z;
+    const float s1 = z * (3.3333334327e-01f + w * (1.4285714924e-01f + w * (9.0908870101e-02f + w * (6.6610731184e-02f + w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
+    const float s2 = w * (-2.0000000298e-01f + w * (-1.1111110449e-01f + w * (-7.6918758452e-02f + w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
+    const float small = xr - xr * (s1 + s2);
+    const float zz = hv - ((xr * (s1 + s2) - lv) - xr);
+    const float nzz = -zz;
+    float res = sel(tiny_range, small, sel(neg, nzz, zz));
+    res = sel(ix < 0x31000000u, x, res);                       // |x| < 2^-29
+    const float big = 1.5707962513e+00f + 7.5497894159e-08f;
+    const float xx = x + x;
+    const float huge_res = sel(ix > 0x7f800000u, xx, sel(neg, -big, big));
+    res = sel(ix >= 0x4c000000u, huge_res, res);               // |x| >= 2^25, inf, nan
+    return res;
+}
+
+__device__ __forceinline__ bool negzero(float v) { return __float_as_uint(v) == 0x80000000u; }
+
+// GHC RealFloat default atan2, evaluated once on (|case|-folded) operands
+__device__ __forceinline__ float ghc_atan2_sel(float y, float x)
+{
+    const float pi = 3.14159274101257324f;
+    // clause 4 (negate (atan2 (negate y) x)) folds the lower half-plane onto the upper one
+    const bool nzx = negzero(x), nzy = negzero(y);
+    const bool fold = ((x <= 0.0f) & (y < 0.0f)) | ((x < 0.0f) & nzy) | (nzx & nzy);
+    const bool c1 = x > 0.0f;
+    const bool flip = !c1 & fold;
+    const float ny = -y;
+    const float yy = sel(flip, ny, y);
+    const float a = atanf_sel(yy / x);
+    const bool xz = x == 0.0f, xn = x < 0.0f, yp = yy > 0.0f, yz = yy == 0.0f;
+    const float pa = pi + a, xy = x + yy;
+    float r = xy;                                             // applied last to first: the first matching clause wins
+    r = sel(xz & yz, yy, r);
+    r = sel(yz & (xn | nzx), pi, r);
+    r = sel(xn & yp, pa, r);
+    r = sel(xz & yp, pi / 2.0f, r);
+    r = sel(c1, a, r);                                        // clause 1 (never folded: x > 0)
+    const float nr = -r;
+    return sel(flip, nr, r);
+}
+
+__device__ __forceinline__ float fm_phase_sel(float2 cur, float2 prev)
+{
+    const float nd = -prev.y;
+    const float re = cur.x * prev.x - cur.y * nd;
+    const float im = cur.x * nd + cur.y * prev.x;
+    const float p = ghc_atan2_sel(im, re);
+    return sel((re == 0.0f) & (im == 0.0f), 0.0f, p);
+}
+
+}  // namespace sdrhip

@@ -133,6 +133,13 @@ bool launch_filter_cplx4_fast(hipStream_t s, const Geom& g, const float* d_dup_t
                               const float* d_in, float* d_out);
 bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& t, const int* increments,
                                const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out);
+// kernels_tail.hip: fmDemod -> 3/10 resampler -> symmetric filter (* gain) as one kernel (y and z never leave LDS); false = the
+// configuration is not the FM chain's tail (3 groups of 64, increments {4,3,3}, 64 half-taps, buffers longer than a tile)
+constexpr int kTailTileOutputs = 2046;   // audio outputs one workgroup of the fused tail kernel produces
+bool launch_fm_tail_fused(hipStream_t s, const float* d_d, int64_t kd0, int64_t kd1, int64_t ky0, int64_t ky1, float* d_audio,
+                          int64_t q0, int64_t q1, const float* d_groups, int row_stride, int nloop, const int* increments,
+                          int ngroups, int I, int D, int rLp, const float* d_rplain, int ntaps, const float* d_fhalf, int nhalf,
+                          const float* d_fplain, float gain, int64_t seam);
 bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps,
                              const void* d_in, bool in_is_u8, float* d_out);
 

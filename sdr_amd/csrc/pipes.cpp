@@ -12,12 +12,16 @@
 // block, then the One outputs inside the new block -- over a device buffer that
 // holds [carried tail | new block].  Block sizes may vary from push to push.
 //
-// Transfers are pinned and double-buffered over three HIP streams: push(i) enqueues
-// H2D(i) on the upload stream, kernels(i) on the compute stream (after H2D(i)'s
-// event) and D2H(i) on the download stream (after the kernels' event), and only
-// then harvests slot i-1 -- so the upload of block i and the download of block i-1
-// overlap the compute between them.  Results therefore lag by one push;
-// sdrhip_pipe_flush() drains the in-flight slot.
+// The pinned staging buffer of a slot holds [carried tail | staged blocks] contiguously; the tail (the last < Lp/I + D/I
+// elements earlier pushes delivered and pending outputs still need) comes from a small host-side history, so the device
+// never shuffles it.  Large submissions are double-buffered over three HIP streams: push(i) enqueues H2D(i) on the upload
+// stream, kernels(i) on the compute stream (after H2D(i)'s event) and D2H(i) on the download stream (after the kernels'
+// event), and only then harvests slot i-1 -- so the upload of block i and the download of block i-1 overlap the compute
+// between them.  Small submissions (<= kDirectBytes of input) skip both copies: the kernels read the pinned staging buffer
+// and write the pinned result buffer directly over PCIe, which leaves two or three kernel launches and one event per push
+// -- the reference's own block sizes (8192 .. 65536 elements) are launch-bound, not bandwidth-bound.  Results lag by one
+// push; sdrhip_pipe_flush() drains the in-flight slot.
+#include <stdlib.h>
 #include <string.h>
 
 #include <deque>
@@ -39,13 +43,16 @@ struct sdrhip_pipe {
     hipStream_t stream = nullptr;   // compute
     hipStream_t up = nullptr;       // H2D
     hipStream_t down = nullptr;     // D2H
-    hipEvent_t ev_tail = nullptr;   // last tail copy (reads the buffer the NEXT upload overwrites)
-    bool tail_pending = false;
-    // device input: two buffers, alternating, each holding [tail | block]
+    // device input of the two slots (copy mode), each holding [tail | blocks]; map pipes alternate them by `cur`
     DevBuf din[2];
     int cur = 0;
-    int64_t base = 0;       // global index of din[cur][0]
-    int64_t have = 0;       // elements valid in din[cur]
+    // FIR-like pipes: room (elements) in front of the staged elements for the carried tail, and the host-side history
+    // it is copied from: the stream's last hist_n elements
+    int64_t head_cap = 0;
+    std::vector<float> hist;
+    int64_t hist_n = 0;
+    bool direct_ok = getenv("SDRHIP_NO_DIRECT_STREAM") == nullptr;
+    static constexpr size_t kDirectBytes = 512 << 10;     // [tail | staged] up to this size is read in place over PCIe
     int64_t E_prev = 0;     // global end of the previous block
     int64_t m_done = 0;     // outputs computed so far
     float last_re = 0.0f, last_im = 0.0f;  // fmDemod carry (Demod.hs:41,46)
@@ -64,6 +71,7 @@ struct sdrhip_pipe {
         hipEvent_t ev_k = nullptr;    // kernels complete
         int64_t n_out = 0;   // elements produced by the in-flight work
         bool busy = false;
+        bool direct = false; // the last submission ran in place: `ev` also releases the staging buffer
     } slot[2];
     int64_t pushes = 0;
 
@@ -75,6 +83,7 @@ struct sdrhip_pipe {
     DevBuf dc_state, dc_ws;            // dcBlockingFilter: {lastSample, lastOutput} carried on the device
     bool is_map() const { return kind == PK_DEMOD || kind == PK_DCBLOCK; }
 
+    float* staged_base(Slot& sl) const { return (float*)sl.hin.p + (size_t)head_cap * (cplx_in ? 2 : 1); }   // staged element 0
     int esz_in() const { return cplx_in ? 2 : 1; }
     int esz_out() const { return cplx_out ? 2 : 1; }
     int64_t in_offset(int64_t m) const { return ceil_div64(m * (int64_t)D, I); }
@@ -86,7 +95,6 @@ struct sdrhip_pipe {
         for (auto& s : slot)
             for (hipEvent_t e : {s.ev, s.ev_up, s.ev_k})
                 if (e) (void)hipEventDestroy(e);
-        if (ev_tail) (void)hipEventDestroy(ev_tail);
         for (hipStream_t st : {up, stream, down})
             if (st) (void)hipStreamDestroy(st);
     }
@@ -102,7 +110,6 @@ static int pipe_new(sdrhip_pipe** out, PipeKind kind)
     for (auto& sl : p->slot)
         for (hipEvent_t* ev : {&sl.ev, &sl.ev_up, &sl.ev_k})
             if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_tail, hipEventDisableTiming);
     if (e != hipSuccess) {
         set_error("pipe: stream/event creation failed: %s", hipGetErrorString(e));
         delete p;
@@ -170,62 +177,80 @@ static int fir_submit(sdrhip_pipe* p, int n, int64_t uniform_seam)
     // ... and the last of them, when its first input is already in the new block, only if the output block had room for
     // it (kernels.hpp: late_output_is_one)
     if (m_split > p->m_done && late_output_is_one(m_split - 1, E_prev * p->I, p->I, p->D, p->block_out)) m_split--;
-    // device input = [tail of previous | new samples]
-    const int64_t keep_from = p->in_offset(p->m_done);  // first input any pending output needs
-    const int64_t tail = E_prev - keep_from > 0 ? E_prev - keep_from : 0;
-    DevBuf& prev = p->din[p->cur];
-    DevBuf& next = p->din[p->cur ^ 1];
-    if ((rc = next.ensure((size_t)(tail + n) * ein)) != SDRHIP_OK) return rc;
-    // the previous submission's tail copy READ `next` (it was that submission's `prev`): the upload
-    // below must not overwrite it first
-    if (p->tail_pending) SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->up, p->ev_tail, 0));
-    p->tail_pending = false;
-    if (tail > 0) {
-        SDRHIP_CHECK_HIP(hipMemcpyAsync(next.p, (const char*)prev.p + (size_t)(keep_from - p->base) * ein,
-                                        (size_t)tail * ein, hipMemcpyDeviceToDevice, p->stream));
-        SDRHIP_CHECK_HIP(hipEventRecord(p->ev_tail, p->stream));
-        p->tail_pending = true;
+    // staging buffer = [carried tail | staged elements]: the tail starts at the first input any pending output needs,
+    // rounded down to a multiple of 4 elements (16-byte aligned device reads wherever the block sizes allow)
+    int64_t keep_from = p->in_offset(p->m_done);
+    if (keep_from > E_prev) keep_from = E_prev;
+    keep_from -= keep_from & 3;
+    if (E_prev - keep_from > p->hist_n) keep_from = E_prev - p->hist_n;      // stream start: nothing before element 0
+    const int64_t tail = E_prev - keep_from;
+    if (tail > p->head_cap) {
+        set_error("pipe: carried tail of %lld elements exceeds the head room (%lld)", (long long)tail, (long long)p->head_cap);
+        return SDRHIP_ERR_STATE;
     }
-    // `next` was last read by the kernels of submission i-2, which has been harvested, so the
-    // upload may start while submission i-1's kernels are still running on the compute stream
-    SDRHIP_CHECK_HIP(hipMemcpyAsync((char*)next.p + (size_t)tail * ein, sl.hin.p, (size_t)n * ein,
-                                    hipMemcpyHostToDevice, p->up));
-    SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, p->up));
-    SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->stream, sl.ev_up, 0));
-    p->cur ^= 1;
-    p->base = tail > 0 ? keep_from : E_prev;
-    p->have = tail + n;
+    float* first = p->staged_base(sl) - tail * p->esz_in();
+    if (tail > 0) memcpy(first, p->hist.data() + (size_t)(p->hist_n - tail) * p->esz_in(), (size_t)tail * ein);
+    {
+        const int64_t have = tail + n;
+        const int64_t keep = have < p->head_cap ? have : p->head_cap;
+        memmove(p->hist.data(), first + (size_t)(have - keep) * p->esz_in(), (size_t)keep * ein);
+        p->hist_n = keep;
+    }
+    const bool direct = p->direct_ok && (size_t)(tail + n) * ein <= sdrhip_pipe::kDirectBytes;
+    const float* din = nullptr;
+    if (direct) {
+        din = (const float*)sl.hin.dev_ptr(first);
+    } else {
+        DevBuf& dbuf = p->din[si];
+        if ((rc = dbuf.ensure((size_t)(tail + n) * ein + 64)) != SDRHIP_OK) return rc;
+        // slot si's device buffer was last read by the kernels of submission i-2, harvested before the slot was reopened
+        SDRHIP_CHECK_HIP(hipMemcpyAsync(dbuf.p, first, (size_t)(tail + n) * ein, hipMemcpyHostToDevice, p->up));
+        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, p->up));
+        SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->stream, sl.ev_up, 0));
+        din = (const float*)dbuf.p;
+    }
+    const int64_t in_base = keep_from;
 
     const int64_t n_out = m_end - p->m_done;
     sl.n_out = 0;
     if (n_out > 0) {
-        if ((rc = sl.dout.ensure((size_t)n_out * eout)) != SDRHIP_OK) return rc;
         if ((rc = sl.hout.ensure((size_t)n_out * eout)) != SDRHIP_OK) return rc;
-        float* dout = (float*)sl.dout.p;
-        const float* din = (const float*)next.p;
+        float* dout = nullptr;
+        if (direct) {
+            dout = (float*)sl.hout.dev;
+        } else {
+            if ((rc = sl.dout.ensure((size_t)n_out * eout)) != SDRHIP_OK) return rc;
+            dout = (float*)sl.dout.p;
+        }
         if (uniform_seam > 0) {
             if (p->kind == PK_RESAMPLER)
-                rc = resamp_run(p->rs, p->stream, din, p->base, dout, p->m_done, m_end, uniform_seam, p->block_out);
+                rc = resamp_run(p->rs, p->stream, din, in_base, dout, p->m_done, m_end, uniform_seam, p->block_out);
             else
-                rc = fir_run(p->fir, p->stream, din, false, p->base, dout, p->m_done, m_end, uniform_seam);
+                rc = fir_run(p->fir, p->stream, din, false, in_base, dout, p->m_done, m_end, uniform_seam);
             if (rc != SDRHIP_OK) return rc;
         } else {
             const int64_t ncross = m_split - p->m_done;
             if (p->kind == PK_RESAMPLER) {
-                if (ncross > 0 && (rc = resamp_run(p->rs, p->stream, din, p->base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
-                if ((rc = resamp_run(p->rs, p->stream, din, p->base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
+                if (ncross > 0 && (rc = resamp_run(p->rs, p->stream, din, in_base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
+                if ((rc = resamp_run(p->rs, p->stream, din, in_base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
             } else {
-                if (ncross > 0 && (rc = fir_run(p->fir, p->stream, din, false, p->base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
-                if ((rc = fir_run(p->fir, p->stream, din, false, p->base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
+                if (ncross > 0 && (rc = fir_run(p->fir, p->stream, din, false, in_base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
+                if ((rc = fir_run(p->fir, p->stream, din, false, in_base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
             }
         }
-        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, p->stream));
-        SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->down, sl.ev_k, 0));
-        SDRHIP_CHECK_HIP(hipMemcpyAsync(sl.hout.p, sl.dout.p, (size_t)n_out * eout, hipMemcpyDeviceToHost, p->down));
-        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, p->down));
+        if (!direct) {
+            SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, p->stream));
+            SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->down, sl.ev_k, 0));
+            SDRHIP_CHECK_HIP(hipMemcpyAsync(sl.hout.p, sl.dout.p, (size_t)n_out * eout, hipMemcpyDeviceToHost, p->down));
+            SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, p->down));
+        }
         sl.n_out = n_out * p->esz_out();
         sl.busy = true;
     }
+    // direct mode, ONE event per push: the results are in pinned memory and the staging buffer is free again when the
+    // kernels are done
+    if (direct) SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, p->stream));
+    sl.direct = direct;
     p->m_done = m_end;
     p->E_prev = E;
     p->pushes++;
@@ -240,18 +265,21 @@ static int fir_open_slot(sdrhip_pipe* p, size_t elems)
     int rc;
     if (p->staged == 0) {
         if ((rc = harvest(p, (int)(p->pushes & 1))) != SDRHIP_OK) return rc;
-        SDRHIP_CHECK_HIP(hipEventSynchronize(sl.ev_up));   // the slot's previous upload has left the buffer
+        SDRHIP_CHECK_HIP(hipEventSynchronize(sl.direct ? sl.ev : sl.ev_up));   // the slot's previous upload / in-place read has left the buffer
     }
-    if (sl.hin.cap < elems * p->esz_in() * 4) {
+    const size_t head_bytes = (size_t)p->head_cap * p->esz_in() * 4;
+    if (sl.hin.cap < head_bytes + elems * p->esz_in() * 4) {
         // growing must keep what is already staged -- and what the caller wrote in place behind it (a block handed out by
-        // sdrhip_pipe_input_buffer and not pushed yet)
+        // sdrhip_pipe_input_buffer and not pushed yet); the staged elements live behind the head room
         PinBuf bigger;
-        if ((rc = bigger.ensure(elems * p->esz_in() * 4)) != SDRHIP_OK) return rc;
+        if ((rc = bigger.ensure(head_bytes + elems * p->esz_in() * 4)) != SDRHIP_OK) return rc;
         size_t keep = (size_t)(p->staged + p->lent) * p->esz_in() * 4;
-        if (keep > sl.hin.cap) keep = sl.hin.cap;
-        if (keep > 0) memcpy(bigger.p, sl.hin.p, keep);
+        if (sl.hin.cap < head_bytes) keep = 0;
+        else if (keep > sl.hin.cap - head_bytes) keep = sl.hin.cap - head_bytes;
+        if (keep > 0) memcpy((char*)bigger.p + head_bytes, (char*)sl.hin.p + head_bytes, keep);
         std::swap(sl.hin.p, bigger.p);
         std::swap(sl.hin.cap, bigger.cap);
+        std::swap(sl.hin.dev, bigger.dev);
     }
     return SDRHIP_OK;
 }
@@ -272,6 +300,16 @@ static int fir_check_block(const sdrhip_pipe* p, int64_t E_at, int64_t m_pending
     return SDRHIP_OK;
 }
 
+// head room and history of a FIR-like pipe: the carried tail is E_prev - in_offset(m_done) < (Lp + D) / I + 1 elements,
+// plus up to 3 of alignment slack
+static void pipe_init_history(sdrhip_pipe* p)
+{
+    const int64_t max_tail = ((int64_t)p->Lp + p->D) / p->I + 2;
+    p->head_cap = (max_tail + 3 + 3) / 4 * 4 + 4;
+    p->hist.assign((size_t)p->head_cap * p->esz_in(), 0.0f);
+    p->hist_n = 0;
+}
+
 static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
 {
     int rc;
@@ -287,7 +325,7 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
     // zero-copy push: `block` is the staging buffer's own write position (sdrhip_pipe_input_buffer); noted before the
     // buffer can be re-allocated below (growth keeps the lent region, so the data is then already in place)
     const bool in_place = p->slot[p->pushes & 1].hin.p != nullptr &&
-                          block == (const float*)p->slot[p->pushes & 1].hin.p + (size_t)p->staged * p->esz_in();
+                          block == p->staged_base(p->slot[p->pushes & 1]) + (size_t)p->staged * p->esz_in();
     if (!coalescing && p->staged > 0) {
         // a block of another size ends the uniform run: what is staged goes out as one uniform batch first
         if ((rc = fir_submit(p, p->staged, p->uniform_n)) != SDRHIP_OK) return rc;
@@ -300,7 +338,7 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
     p->all_uniform = all_uniform;
     const int64_t cap = coalescing ? (int64_t)p->coalesce * p->uniform_n : n;
     if ((rc = fir_open_slot(p, (size_t)(cap > p->staged + n ? cap : p->staged + n))) != SDRHIP_OK) return rc;
-    float* dst = (float*)p->slot[p->pushes & 1].hin.p + (size_t)p->staged * p->esz_in();
+    float* dst = p->staged_base(p->slot[p->pushes & 1]) + (size_t)p->staged * p->esz_in();
     if (!in_place) memcpy(dst, block, (size_t)n * ein);   // else: the caller filled the staging buffer in place
     p->lent = 0;
     p->staged += n;
@@ -328,6 +366,7 @@ int sdrhip_pipe_fir_filter(sdrhip_pipe** pp, const sdrhip_filter* f, int block_s
     p->I = 1;
     p->D = 1;
     p->Lp = f->Lp;
+    pipe_init_history(p);
     return SDRHIP_OK;
 }
 
@@ -343,6 +382,7 @@ int sdrhip_pipe_fir_decimator(sdrhip_pipe** pp, const sdrhip_decimator* d, int b
     p->I = 1;
     p->D = d->factor;
     p->Lp = d->Lp;
+    pipe_init_history(p);
     return SDRHIP_OK;
 }
 
@@ -360,6 +400,7 @@ int sdrhip_pipe_fir_resampler(sdrhip_pipe** pp, const sdrhip_resampler* r, int b
     p->I = r->I;
     p->D = r->D;
     p->Lp = r->Lp;
+    pipe_init_history(p);
     return SDRHIP_OK;
 }
 
@@ -461,7 +502,7 @@ float* sdrhip_pipe_input_buffer(sdrhip_pipe* p, int n)
     if (cap > (int64_t)1 << 30) { set_error("sdrhip_pipe_input_buffer: coalesced batch too large"); return nullptr; }
     if (fir_open_slot(p, (size_t)(cap > p->staged + n ? cap : p->staged + n)) != SDRHIP_OK) return nullptr;
     p->lent = n;
-    return (float*)p->slot[p->pushes & 1].hin.p + (size_t)p->staged * p->esz_in();
+    return p->staged_base(p->slot[p->pushes & 1]) + (size_t)p->staged * p->esz_in();
 }
 
 int sdrhip_pipe_flush(sdrhip_pipe* p)

@@ -120,6 +120,7 @@ lib.sdrhip_fm_chain_workspace_bytes.restype = C.c_size_t
 lib.sdrhip_fm_chain_run.argtypes = [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, C.c_size_t]
 
 lib.sdrhip_fm_chain_set_pipelining.argtypes = [_vp, C.c_int]
+lib.sdrhip_fm_chain_set_fused_tail.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_enable_timing.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_read_timing.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
@@ -139,6 +140,8 @@ lib.sdrhip_halo_exchange.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t]
 lib.sdrhip_halo_exchange_all.argtypes = [C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.c_size_t]
 lib.sdrhip_bench_stream_8to1.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]
 lib.sdrhip_bench_copy.argtypes = [_vp, _vp, _vp, C.c_size_t]
+lib.sdrhip_bench_fm_stream.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+lib.sdrhip_bench_pipe.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
 lib.sdrhip_debug_tiled_launches.argtypes = []
 lib.sdrhip_debug_tiled_launches.restype = C.c_longlong
 lib.sdrhip_dc_blocker_workspace_bytes.argtypes = [C.c_int64]
@@ -406,10 +409,14 @@ class FmChain(_Handle):
     def workspace_bytes(self, n_in):
         return lib.sdrhip_fm_chain_workspace_bytes(self.h, n_in)
 
-    STAGES = ("decimate", "fm_demod", "resample", "filter", "gain")
+    STAGES = ("decimate", "fm_demod", "resample", "filter", "fused_tail")
 
     def set_pipelining(self, nsub):
         check(lib.sdrhip_fm_chain_set_pipelining(self.h, nsub), "sdrhip_fm_chain_set_pipelining")
+
+    def set_fused_tail(self, mode=2):
+        """0 = stage kernels, 1 = the fused tail kernel wherever the chain's shape allows, 2 = auto (short runs only)."""
+        check(lib.sdrhip_fm_chain_set_fused_tail(self.h, int(mode)), "sdrhip_fm_chain_set_fused_tail")
 
     def enable_timing(self, on=True):
         check(lib.sdrhip_fm_chain_enable_timing(self.h, int(on)), "sdrhip_fm_chain_enable_timing")

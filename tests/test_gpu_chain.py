@@ -319,3 +319,32 @@ def test_fm_stream_coalesce_ragged_inplace(hip, oracle):
     got = np.concatenate(got)
     assert got.size >= exp.size
     assert_bit_equal(got[: exp.size], exp, "ragged coalesced zero-copy stream")
+
+
+@pytest.mark.parametrize("block", [B, 0, 3 * B])
+def test_fused_tail_equals_stage_kernels(hip, oracle, block):
+    """kernels_tail.hip (fmDemod -> resampler -> filter in one kernel, Cross outputs decided in-kernel) against the three
+    stage kernels + their seam fix-ups: whole runs, runs that start and end mid-tile, short runs inside one tile."""
+    nblk = 70
+    total = nblk * B
+    u8 = S.iq_u8_fm(total)
+    d = to_dev(u8)
+    ch = _chain(hip, block=block)
+    q0, q1, _ = ch.plan(0, total, total)
+    rng = np.random.default_rng(77 + SWEEP_SEED)
+    ranges = [(0, q1), (0, 2046), (0, 2047), (1, 700), (2047, 2047 + 4093), (q1 - 5000, q1)]
+    for _ in range(6 * SWEEP_SCALE):
+        a = int(rng.integers(0, q1 - 10))
+        ranges.append((a, int(min(q1, a + rng.integers(1, 9000)))))
+    for a, b in ranges:
+        ch.set_fused_tail(0)
+        ref = _run(hip, ch, d, 0, total, a, b)
+        ch.set_fused_tail(1)
+        got = _run(hip, ch, d, 0, total, a, b)
+        assert_bit_equal(got, ref, f"fused tail, block {block}, outputs [{a},{b})")
+    if block == B:
+        exp = _model(oracle, u8, nblk)
+        ch.set_fused_tail(1)
+        got = _run(hip, ch, d, 0, total, 0, q1)
+        assert exp.size >= B
+        assert_bit_equal(got[: exp.size], exp, "fused tail vs restated pipes")

@@ -1,0 +1,45 @@
+"""Host-streamed throughput measured by the library's own C timing loops (sdrhip_bench_fm_stream / sdrhip_bench_pipe):
+what a compiled caller pays per push, without the Python interpreter in the loop."""
+import ctypes as C
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def fm_stream_rate(L, chain, n_samples, pushes, zero_copy=True, coalesce=0):
+    sps, blocks = C.c_double(), C.c_longlong()
+    L.check(L.lib.sdrhip_bench_fm_stream(chain.h, n_samples, pushes, int(zero_copy), coalesce, C.byref(sps), C.byref(blocks)),
+            "sdrhip_bench_fm_stream")
+    return sps.value, blocks.value
+
+
+def pipe_rate(L, pipe_handle, n, floats_per_element, block_out, pushes, zero_copy=True):
+    eps = C.c_double()
+    L.check(L.lib.sdrhip_bench_pipe(pipe_handle, n, floats_per_element, block_out, pushes, int(zero_copy), C.byref(eps)), "sdrhip_bench_pipe")
+    return eps.value
+
+
+def main():
+    import sdr_amd.lib as L
+    import signals as S
+    B = 8192
+    chain = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, B)
+    for bpp, pushes in ((1, 4000), (2, 3000), (4, 2000), (16, 1000), (256, 100), (4096, 12)):
+        for zc in (False, True):
+            sps, blocks = fm_stream_rate(L, chain, bpp * B, pushes, zc)
+            print(f"sdrhip_fm_stream {bpp:5d} block(s)/push, {'zero-copy' if zc else 'memcpy   '}: {sps / 1e6:9.1f} Msamples/s "
+                  f"({bpp * B / sps * 1e6:7.1f} us/push, {blocks} audio blocks)")
+    dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
+    res = L.Resampler(3, 10, S.taps_resamp191(), L.ORDER_AVX)
+    fil = L.Filter(S.taps_audio_half64(), L.ORDER_AVX, sym=True)
+    for name, mk, n, fpe in (("firDecimator /8 127 taps, 8192-sample cfloat blocks", lambda: L.Pipe("decimator", dec, B), B, 2),
+                             ("firResampler 3/10 191 taps, 65536-float blocks (configs[3])", lambda: L.Pipe("resampler", res, B), 65536, 1),
+                             ("firFilter 64 half-taps sym, 8192-float blocks", lambda: L.Pipe("filter", fil, B), B, 1)):
+        for zc in (False, True):
+            p = mk()
+            r = pipe_rate(L, p.h, n, fpe, B, 2000, zc)
+            print(f"{name}, {'zero-copy' if zc else 'memcpy   '}: {r / 1e6:8.1f} M elements/s ({n / r * 1e6:6.1f} us/push)")
+
+
+if __name__ == "__main__":
+    main()
