@@ -1,4 +1,4 @@
-{-# LANGUAGE ForeignFunctionInterface #-}
+{-# LANGUAGE ForeignFunctionInterface, RecordWildCards #-}
 
 {-| GPU back-end for the FM hot path of the @sdr@ library, over the C ABI of @libsdr_hip.so@
     (@include/sdr_hip.h@, layer 3: Pipe operators).
@@ -7,7 +7,14 @@
     maintainer of adamwalker/sdr would add next to SDR.Filter / SDR.Demod / SDR.Util.  The tested
     boundary is the C ABI itself (tests/test_abi.py, tests/test_gpu_pipes.py).
 
-    The operators mirror the reference's:
+    Two levels.  (a) The reference's own records ('Filter' / 'Decimator' / 'Resampler', Filter.hs:116-144) with BOTH
+    closures bound to device calls -- 'fastDecimatorCGpu', 'fastResamplerRGpu', 'fastFilterSymRGpu' -- so that the
+    reference's unchanged 'firDecimator' / 'firResampler' / 'firFilter' drive the GPU:
+
+    > decimator <- fastDecimatorCGpu 8 coeffsRFDecim          -- instead of fastDecimatorC info 8 coeffsRFDecim
+    > ... firDecimator decimator samples ...                   -- fm.hs:36, unchanged
+
+    (b) whole-Pipe operators that keep the stream state on the device.  They mirror the reference's:
 
     > firDecimatorGpu :: GpuDecimator -> Int -> Pipe (Vector (Complex Float)) (Vector (Complex Float)) IO ()   -- firDecimator, Filter.hs:574
     > firResamplerGpu :: GpuResampler -> Int -> Pipe (Vector Float) (Vector Float) IO ()                       -- firResampler, Filter.hs:679
@@ -21,6 +28,9 @@
     host (the One/Cross split at buffer seams included).
 -}
 module SDR.GPU (
+    -- * The reference's own records, closures bound to the device (the reference's Pipes run unchanged)
+    fastDecimatorCGpu, fastResamplerRGpu, fastFilterSymRGpu, fastFilterRGpu,
+    -- * Device descriptors and whole-Pipe operators
     GpuDecimator, GpuResampler, GpuFilter,
     gpuDecimatorC, gpuResamplerR, gpuFilterSymR, gpuFilterR,
     firDecimatorGpu, firResamplerGpu, firFilterGpu, fmDemodGpu, dcBlockingFilterGpu,
@@ -29,7 +39,10 @@ module SDR.GPU (
     ) where
 
 import           Control.Monad
+import           Control.Monad.Primitive       (RealWorld)
 import           Data.Complex
+import qualified Data.Vector.Storable.Mutable  as VSM
+import           SDR.Filter                    (Filter (..), Decimator (..), Resampler (..))
 import           Foreign
 import           Foreign.C.String
 import           Foreign.C.Types
@@ -70,6 +83,17 @@ foreign import ccall safe "sdrhip_fm_stream_create"    c_stream_create     :: Pt
 foreign import ccall safe "sdrhip_fm_stream_push"      c_stream_push       :: Ptr SdrStream -> Ptr CUChar -> CInt -> IO CInt
 foreign import ccall safe "sdrhip_fm_stream_pop"       c_stream_pop        :: Ptr SdrStream -> Ptr CFloat -> CInt -> IO CInt
 foreign import ccall safe "convertCAVX"                c_convertCAVX       :: CInt -> Ptr CUChar -> Ptr CFloat -> IO ()
+-- the record seam (include/sdr_hip.h, "the record seam on HOST vectors"): One = the C SIMD kernel on one buffer,
+-- Cross = the sequential kernel on `drop i last ++ next` (FilterInternal.hs:397-423)
+foreign import ccall safe "sdrhip_filter_num_coeffs"    c_filter_num_coeffs    :: Ptr SdrFilter -> IO CInt
+foreign import ccall safe "sdrhip_decimator_num_coeffs" c_decimator_num_coeffs :: Ptr SdrDecimator -> IO CInt
+foreign import ccall safe "sdrhip_resampler_num_coeffs" c_resampler_num_coeffs :: Ptr SdrResampler -> IO CInt
+foreign import ccall safe "sdrhip_filter_one"       c_filter_one       :: Ptr SdrFilter -> CInt -> Ptr CFloat -> Ptr CFloat -> IO CInt
+foreign import ccall safe "sdrhip_filter_cross"     c_filter_cross     :: Ptr SdrFilter -> CInt -> Ptr CFloat -> CInt -> Ptr CFloat -> CInt -> Ptr CFloat -> IO CInt
+foreign import ccall safe "sdrhip_decimator_one"    c_decimator_one    :: Ptr SdrDecimator -> CInt -> Ptr CFloat -> Ptr CFloat -> IO CInt
+foreign import ccall safe "sdrhip_decimator_cross"  c_decimator_cross  :: Ptr SdrDecimator -> CInt -> Ptr CFloat -> CInt -> Ptr CFloat -> CInt -> Ptr CFloat -> IO CInt
+foreign import ccall safe "sdrhip_resampler_one"    c_resampler_one    :: Ptr SdrResampler -> CInt -> CInt -> Ptr CFloat -> CInt -> Ptr CFloat -> IO CInt
+foreign import ccall safe "sdrhip_resampler_cross"  c_resampler_cross  :: Ptr SdrResampler -> CInt -> CInt -> Ptr CFloat -> CInt -> Ptr CFloat -> CInt -> Ptr CFloat -> IO CInt
 
 -- | SDRHIP_ORDER_AVX: reproduce the variant 'SDR.CPUID.featureSelect' picks on any AVX host.
 orderAVX :: CInt
@@ -107,6 +131,70 @@ gpuFilterR :: [Float] -> IO GpuFilter
 gpuFilterR coeffs = alloca $ \pp -> do
     _ <- withCoeffs coeffs $ \p n -> c_filter_create pp orderAVX 0 p n >>= check
     GpuFilter <$> peek pp
+
+-- ---------------------------------------------------------------------------------------------
+-- The reference's records (Filter.hs:116-144) with both closures bound to the device.  These are
+-- drop-in replacements for 'fastDecimatorC' / 'fastResamplerR' / 'fastFilterSymR' / 'fastFilterR':
+-- hand the result to the reference's OWN 'firDecimator' / 'firResampler' / 'firFilter' (Filter.hs:532-727)
+-- and the pipeline of examples/fm/fm.hs runs unchanged, every vector identical bit for bit.
+-- (One FFI round trip per closure call; the whole-Pipe operators below amortise it better.)
+-- ---------------------------------------------------------------------------------------------
+withIn :: Storable a => VS.Vector a -> (Ptr CFloat -> CInt -> IO b) -> IO b
+withIn v act = VS.unsafeWith (VS.unsafeCast v) $ \p -> act p (fromIntegral (VS.length v))
+
+withOut :: Storable a => VSM.MVector RealWorld a -> (Ptr CFloat -> IO b) -> IO b
+withOut v act = VSM.unsafeWith (VSM.unsafeCast v) act
+
+-- | 'fastDecimatorC' (Filter.hs:352-356): @Decimator IO Vector MVector (Complex Float)@.
+fastDecimatorCGpu :: Int -> [Float] -> IO (Decimator IO VS.Vector VSM.MVector (Complex Float))
+fastDecimatorCGpu decimationD coeffs = do
+    GpuDecimator d <- gpuDecimatorC decimationD coeffs
+    numCoeffsD <- fromIntegral <$> c_decimator_num_coeffs d
+    let decimateOne num inBuf outBuf =
+            void $ withIn inBuf $ \i _ -> withOut outBuf $ \o -> c_decimator_one d (fromIntegral num) i o >>= check
+        decimateCross num lastBuf nextBuf outBuf =
+            void $ withIn lastBuf $ \l nl -> withIn nextBuf $ \n nn -> withOut outBuf $ \o ->
+                c_decimator_cross d (fromIntegral num) l nl n nn o >>= check
+    return Decimator {..}
+
+-- | 'fastFilterSymR' (Filter.hs:258-261): pass the first half of an even-length linear-phase filter.
+fastFilterSymRGpu :: [Float] -> IO (Filter IO VS.Vector VSM.MVector Float)
+fastFilterSymRGpu half = gpuFilterSymR half >>= filterRecord
+
+-- | 'fastFilterR' (Filter.hs:191-194).
+fastFilterRGpu :: [Float] -> IO (Filter IO VS.Vector VSM.MVector Float)
+fastFilterRGpu coeffs = gpuFilterR coeffs >>= filterRecord
+
+filterRecord :: GpuFilter -> IO (Filter IO VS.Vector VSM.MVector Float)
+filterRecord (GpuFilter f) = do
+    numCoeffsF <- fromIntegral <$> c_filter_num_coeffs f
+    let filterOne num inBuf outBuf =
+            void $ withIn inBuf $ \i _ -> withOut outBuf $ \o -> c_filter_one f (fromIntegral num) i o >>= check
+        filterCross num lastBuf nextBuf outBuf =
+            void $ withIn lastBuf $ \l nl -> withIn nextBuf $ \n nn -> withOut outBuf $ \o ->
+                c_filter_cross f (fromIntegral num) l nl n nn o >>= check
+    return Filter {..}
+
+-- | 'fastResamplerR' (Filter.hs:468-473).  The state carried between calls is the reference's own
+--   @(group, offset)@ (mkResampler, Filter.hs:408-425): 'resampleOne' starts in polyphase group @group@
+--   and learns the next group from the C call; 'resampleCross' starts at filter offset @offset@ and
+--   learns the next offset from it.
+fastResamplerRGpu :: Int -> Int -> [Float] -> IO (Resampler IO VS.Vector VSM.MVector Float)
+fastResamplerRGpu interpolationR decimationR coeffs = do
+    GpuResampler r <- gpuResamplerR interpolationR decimationR coeffs
+    numCoeffsR <- fromIntegral <$> c_resampler_num_coeffs r
+    let offsetOf group = interpolationR - 1 - ((interpolationR + group * decimationR - 1) `mod` interpolationR)
+        resampleOne (group, _) num inBuf outBuf = do
+            group' <- fmap fromIntegral $ withIn inBuf $ \i ni -> withOut outBuf $ \o ->
+                          c_resampler_one r (fromIntegral group) (fromIntegral num) i ni o >>= check
+            let offset' = offsetOf group'
+            return ((group', offset'), offset')
+        resampleCross (group, offset) num lastBuf nextBuf outBuf = do
+            offset' <- fmap fromIntegral $ withIn lastBuf $ \l nl -> withIn nextBuf $ \n nn -> withOut outBuf $ \o ->
+                           c_resampler_cross r (fromIntegral offset) (fromIntegral num) l nl n nn o >>= check
+            return (((group + num) `mod` interpolationR, offset'), offset')
+        startDat = (0, 0) :: (Int, Int)
+    return Resampler {..}
 
 -- | Forward blocks through one C pipe.  @wIn@ / @wOut@: floats per element (2 for complex).
 --   Output blocks have exactly @blockSizeOut@ elements (advanceOutBuf, Filter.hs:516-523).

@@ -247,6 +247,25 @@ int sdrhip_dc_blocker_run(void *stream, const float *d_in, float *d_out, int64_t
                           float last_output, float *d_final, void *d_workspace, size_t workspace_bytes,
                           int run_in);
 
+/* ---- the record seam on HOST vectors (hs_sources/SDR/Filter.hs:116-144) ---- */
+/* The closures a Haskell constructor puts into the reference's own Filter / Decimator / Resampler records, so that
+ * the reference's UNCHANGED Pipes (firFilter / firDecimator / firResampler, Filter.hs:532-727) drive the device:
+ *   *_one   = the C SIMD kernel on one buffer: num outputs from in[0 ..] (FilterInternal.hs:66-71,172-177,335-342);
+ *   *_cross = the sequential Haskell kernel on `drop i last ++ next` (decimate/filter/resampleCrossHighLevel,
+ *             FilterInternal.hs:397-423).
+ * HOST pointers, synchronous; n_* in elements (complex pairs for complex descriptors).  The resampler calls carry the
+ * reference's state: _one takes the polyphase group and returns the group of the next output (what resampleAVXRR
+ * returns), _cross takes the filter offset and returns the offset after the last output; negative = error. */
+int sdrhip_filter_one(const sdrhip_filter *f, int num, const float *in, float *out);
+int sdrhip_filter_cross(const sdrhip_filter *f, int num, const float *last, int n_last, const float *next, int n_next,
+                        float *out);
+int sdrhip_decimator_one(const sdrhip_decimator *d, int num, const float *in, float *out);
+int sdrhip_decimator_cross(const sdrhip_decimator *d, int num, const float *last, int n_last, const float *next,
+                           int n_next, float *out);
+int sdrhip_resampler_one(const sdrhip_resampler *r, int group, int num, const float *in, int n_in, float *out);
+int sdrhip_resampler_cross(const sdrhip_resampler *r, int filter_offset, int num, const float *last, int n_last,
+                           const float *next, int n_next, float *out);
+
 /* ---- the FM receiver chain (examples/fm/fm.hs:34-41) ----------------------- */
 /* u8 IQ -> [convert] -> decimator -> fmDemod -> resampler -> symmetric filter
  * [-> * gain].  All four Pipes of fm.hs run with blockSizeOut = block, and the

@@ -138,6 +138,12 @@ lib.sdrhip_comm_transport.argtypes = [_vp]
 lib.sdrhip_comm_transport.restype = C.c_char_p
 lib.sdrhip_halo_exchange.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t]
 lib.sdrhip_halo_exchange_all.argtypes = [C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.c_size_t]
+lib.sdrhip_filter_one.argtypes = [_vp, C.c_int, _f32p, _f32p]
+lib.sdrhip_filter_cross.argtypes = [_vp, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f32p]
+lib.sdrhip_decimator_one.argtypes = [_vp, C.c_int, _f32p, _f32p]
+lib.sdrhip_decimator_cross.argtypes = [_vp, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f32p]
+lib.sdrhip_resampler_one.argtypes = [_vp, C.c_int, C.c_int, _f32p, C.c_int, _f32p]
+lib.sdrhip_resampler_cross.argtypes = [_vp, C.c_int, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f32p]
 lib.sdrhip_bench_stream_8to1.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]
 lib.sdrhip_bench_copy.argtypes = [_vp, _vp, _vp, C.c_size_t]
 lib.sdrhip_bench_fm_stream.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]

@@ -14,6 +14,10 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $CM
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $CMD > $OUT/bench_write_run.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d $OUT/pmc_sq -o bench -- $CMD > $OUT/bench_sq_run.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_lds -o bench -- $CMD > $OUT/bench_lds_run.log 2>&1
+# the cfloat-in instantiation of the decimator (BASELINE configs[1]) on its own
+K2C="python $R/tools/prof_k2.py 27 f32"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_k2c -o bench -- $K2C > $OUT/k2c_fetch_run.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_k2c -o bench -- $K2C > $OUT/k2c_write_run.log 2>&1
 # un-profiled reference run of the same command
 $CMD > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 find $OUT -name "*.csv" | head -50

@@ -66,8 +66,10 @@ k2 = next(k for k in ours if k.startswith("k_decimate_c4<"))
 fetch_kib = ours[k2].get("FETCH_SIZE", float("nan"))
 write_kib = ours[k2].get("WRITE_SIZE", float("nan"))
 samples = bench["roofline"]["algorithmic_bytes_per_launch"] / 3.0
+import hashlib
 traffic = {
     "kernel": k2,
+    "kernels_fast_sha256": hashlib.sha256(open(os.path.join(ROOT, "sdr_amd", "csrc", "kernels_fast.hip"), "rb").read()).hexdigest(),
     "samples_per_launch": int(round(samples)),
     "FETCH_SIZE_KiB_raw": fetch_kib,
     "WRITE_SIZE_KiB_raw": write_kib,
@@ -81,6 +83,23 @@ traffic = {
 }
 json.dump(traffic, open(os.path.join(dst, "k2_traffic.json"), "w"), indent=1)
 json.dump(bench, open(os.path.join(dst, f"{tag}_bench_unprofiled.json"), "w"), indent=1)
+
+# 3b. the cfloat-in instantiation (BASELINE configs[1]), from the separate passes over tools/prof_k2.py
+try:
+    c_f = pmc("pmc_fetch_k2c")
+    c_w = pmc("pmc_write_k2c")
+    kc = next(k for k in c_f if k.startswith("k_decimate_c4<") and k.rstrip(">").endswith("false"))
+    n_c = 1 << 27
+    fk, wk = c_f[kc].get("FETCH_SIZE", float("nan")), c_w[kc].get("WRITE_SIZE", float("nan"))
+    json.dump({"kernel": kc, "samples_per_launch": n_c, "FETCH_SIZE_KiB_raw": fk, "WRITE_SIZE_KiB_raw": wk,
+               "fetch_bytes_corrected": 2.0 * fk * 1024.0, "write_bytes": wk * 1024.0,
+               "hbm_bytes_per_launch": 2.0 * fk * 1024.0 + wk * 1024.0, "algorithmic_bytes_per_launch": 9.0 * n_c,
+               "ratio": (2.0 * fk * 1024.0 + wk * 1024.0) / (9.0 * n_c),
+               "kernels_fast_sha256": traffic["kernels_fast_sha256"],
+               "how": "as k2_traffic.json, over `python tools/prof_k2.py 27 f32` (cfloat IQ in, 2^27 samples per launch, no seams)"},
+              open(os.path.join(dst, "k2c_traffic.json"), "w"), indent=1)
+except Exception as e:          # noqa: BLE001
+    print("no k2c passes:", e)
 
 # 4. derived table for the README
 print("kernel                                   avg_us(stats)  clock_GHz  valu_quad_busy  lds_conflict/idx")
