@@ -380,6 +380,21 @@ int sdrhip_fm_stream_flush(sdrhip_fm_stream *st);
 int sdrhip_fm_stream_set_coalesce(sdrhip_fm_stream *st, int samples);
 int sdrhip_fm_stream_pop(sdrhip_fm_stream *st, float *out, int capacity);
 
+/* ---- spectrum path (hs_sources/SDR/FFT.hs:44-168) on hipFFT ---- */
+/* fftw' / fftw (complex-to-complex forward DFT of n Complex Double), fftwReal' / fftwReal (n Double -> n/2+1 bins) and
+ * fftwParallel (several buffers in flight: here a batched plan).  Double precision, unnormalised, forward sign
+ * exp(-2 pi i jk/n): FFTW's conventions and bin order.  Tolerance contract (a different summation tree from FFTW's), not
+ * bit parity.  libhipfft.so.0 is loaded on first use. */
+typedef struct sdrhip_fft sdrhip_fft;
+int sdrhip_fft_create(sdrhip_fft **f, int n, int real_input, int batch);
+void sdrhip_fft_destroy(sdrhip_fft *f);
+int sdrhip_fft_size(const sdrhip_fft *f);
+int sdrhip_fft_bins(const sdrhip_fft *f);                                  /* n, or n/2 + 1 for real input */
+/* HOST vectors, synchronous: in = batch x n complex doubles (interleaved) or batch x n doubles; out = batch x bins complex */
+int sdrhip_fft_run(sdrhip_fft *f, const double *in, double *out);
+/* DEVICE vectors, asynchronous on `stream` */
+int sdrhip_fft_run_device(sdrhip_fft *f, void *stream, const double *d_in, double *d_out);
+
 /* ---- measurement utilities (bench.py only; not part of the FM path) ---- */
 /* A streaming kernel with the traffic shape of the cfloat decimate-by-8 kernel (bytes_in read, bytes_in / 8 written;
  * bytes_in a multiple of 32 KiB), with plain or non-temporal loads, and a float4 copy: the ceilings the memory system

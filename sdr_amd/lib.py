@@ -138,6 +138,14 @@ lib.sdrhip_comm_transport.argtypes = [_vp]
 lib.sdrhip_comm_transport.restype = C.c_char_p
 lib.sdrhip_halo_exchange.argtypes = [_vp, _vp, _vp, _vp, C.c_size_t]
 lib.sdrhip_halo_exchange_all.argtypes = [C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.c_size_t]
+_f64p = C.POINTER(C.c_double)
+lib.sdrhip_fft_create.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, C.c_int]
+lib.sdrhip_fft_destroy.argtypes = [_vp]
+lib.sdrhip_fft_destroy.restype = None
+lib.sdrhip_fft_size.argtypes = [_vp]
+lib.sdrhip_fft_bins.argtypes = [_vp]
+lib.sdrhip_fft_run.argtypes = [_vp, _f64p, _f64p]
+lib.sdrhip_fft_run_device.argtypes = [_vp, _vp, _vp, _vp]
 lib.sdrhip_filter_one.argtypes = [_vp, C.c_int, _f32p, _f32p]
 lib.sdrhip_filter_cross.argtypes = [_vp, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f32p]
 lib.sdrhip_decimator_one.argtypes = [_vp, C.c_int, _f32p, _f32p]
@@ -437,6 +445,27 @@ class FmChain(_Handle):
 
     def run(self, d_in_u8, s0, n_in, d_audio, q0, q1, d_ws, ws_bytes, stream=None):
         check(lib.sdrhip_fm_chain_run(self.h, stream, d_in_u8, s0, n_in, d_audio, q0, q1, d_ws, ws_bytes), "sdrhip_fm_chain_run")
+
+
+class Fft(_Handle):
+    """fftw' / fftwReal' of SDR.FFT (FFT.hs:44-108) on hipFFT: Complex Double in FFTW's order, `batch` transforms per call."""
+    _destroy = lib.sdrhip_fft_destroy
+
+    def __init__(self, n, real_input=False, batch=1):
+        super().__init__()
+        check(lib.sdrhip_fft_create(C.byref(self.h), n, int(real_input), batch), "sdrhip_fft_create")
+        self.n, self.real_input, self.batch = n, bool(real_input), batch
+        self.bins = lib.sdrhip_fft_bins(self.h)
+
+    def run(self, x):
+        import numpy as np
+        if self.real_input:
+            a = np.ascontiguousarray(x, dtype=np.float64).reshape(self.batch, self.n)
+        else:
+            a = np.ascontiguousarray(x, dtype=np.complex128).reshape(self.batch, self.n)
+        out = np.empty((self.batch, self.bins), np.complex128)
+        check(lib.sdrhip_fft_run(self.h, a.ctypes.data_as(_f64p), out.ctypes.data_as(_f64p)), "sdrhip_fft_run")
+        return out if self.batch > 1 else out[0]
 
 
 TRANSPORT_RCCL, TRANSPORT_PEER_COPY = 1, 2
