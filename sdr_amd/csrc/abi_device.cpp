@@ -148,6 +148,9 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
         if (d->corder == CO_L4 &&
             launch_decimate_c4_fast(s, g, d->d_plain, d->Lp, d->d_cross, d_in, in_u8, d_out)) {
             // specialised kernel took it
+        } else if (d->corder != CO_L4 && !d->sym &&
+                   launch_decimate_c_orders_fast(s, g, d->corder, d->d_plain, d->Lp, d->d_cross, d_in, in_u8, d_out)) {
+            // the same tiled kernel with the SSE / RC2 partial-sum layout took it
         } else if (d->corder == CO_L4 && !in_u8 &&
                    launch_filter_cplx4_fast(s, g, d->d_taps, d->Lp, d->d_cross, (const float*)d_in, d_out)) {
             // LDS-tiled complex filter took it
@@ -270,7 +273,9 @@ int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in
     t.force_seq = 0;
     for (int q = 0; q < r->num_groups; q++) t.fo[q] = r->offsets[q];
     if (r->cplx) {
-        if (!launch_resample_split(s, g, true, r->lanes, r->corder, t, r->d_groups, r->d_plain, d_in, d_out))
+        if (launch_resample3c_fast(s, g, r->corder, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
+            // specialised complex 3-group kernel took it
+        } else if (!launch_resample_split(s, g, true, r->lanes, r->corder, t, r->d_groups, r->d_plain, d_in, d_out))
             launch_resample_cplx(s, g, r->corder, t, r->d_groups, r->d_plain, d_in, d_out);
     } else if (r->lanes == 8 && launch_resample_3_10_fast(s, g, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
         // specialised 3-group kernel took it

@@ -32,7 +32,9 @@ struct sdrhip_fm_chain {
     bool fused_first_stage() const
     {
         const int D = decim.factor;
-        return decim.corder == CO_L4 && (D == 4 || D == 8 || D == 16) && decim.Lp > D && decim.Lp <= (D == 4 ? 128 : 256) && decim.Lp % 4 == 0;
+        if (!((D == 4 || D == 8 || D == 16) && decim.Lp > D && decim.Lp % 4 == 0)) return false;
+        if (decim.corder == CO_L4) return decim.Lp <= (D == 4 ? 128 : 256);
+        return decim.corder == CO_L2 && decim.Lp <= 128;      // the SSE order's fused instantiations (kernels_fast_orders.hip)
     }
 
     // Optional software pipelining inside one run (sdrhip_fm_chain_set_pipelining): the outputs are cut

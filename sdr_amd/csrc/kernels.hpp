@@ -131,6 +131,9 @@ bool launch_fir_real8_fast(hipStream_t s, const Geom& g, bool sym, const float* 
 // complex filter (D == 1), AVX "RC" order, duplicated taps (2P floats), P % 4 == 0
 bool launch_filter_cplx4_fast(hipStream_t s, const Geom& g, const float* d_dup_taps, int P, const float* d_cross_taps,
                               const float* d_in, float* d_out);
+// kernels_cplx.hip: the same shape on complex data ("RC2" orders of resampleAVXRC / resampleSSERC)
+bool launch_resample3c_fast(hipStream_t s, const Geom& g, ComplexOrder order, const ResampTable& t, const int* increments, const float* d_groups,
+                            const float* d_plain_taps, const float* d_in, float* d_out);
 bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& t, const int* increments,
                                const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out);
 // kernels_tail.hip: fmDemod -> 3/10 resampler -> symmetric filter (* gain) as one kernel (y and z never leave LDS); false = the
@@ -142,5 +145,8 @@ bool launch_fm_tail_fused(hipStream_t s, const float* d_d, int64_t kd0, int64_t 
                           const float* d_fplain, float gain, int64_t seam);
 bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps,
                              const void* d_in, bool in_is_u8, float* d_out);
+// kernels_fast_orders.hip: the same tiled decimator for the SSE "RC" and the "RC2" summation orders (CO_L2, CO_X4, CO_X2)
+bool launch_decimate_c_orders_fast(hipStream_t s, const Geom& g, ComplexOrder order, const float* d_plain_taps, int P,
+                                   const float* d_cross_taps, const void* d_in, bool in_is_u8, float* d_out);
 
 }  // namespace sdrhip

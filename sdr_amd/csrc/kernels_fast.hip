@@ -22,388 +22,11 @@
 //   * taps are wave-uniform -> scalar loads / SGPR operands.
 //   "Cross" outputs (seam straddlers, sequential order) are rewritten afterwards by
 //   a tiny fix-up kernel on the same stream: ~1.5 % of outputs.
-#include <atomic>
-
-#include "crossfix.hpp"
-#include "kernels.hpp"
+#include "decimate_tile.hpp"
 
 namespace sdrhip {
 
 namespace {
-
-
-template <int D, int P, int R, int NT>
-struct Tile {
-    static constexpr int OUTS = NT * R;                   // outputs per workgroup
-    static constexpr int SPAN = (OUTS - 1) * D + P;       // input samples per workgroup
-    static constexpr int CHUNK = D * R;                   // samples between adjacent threads' windows
-    static constexpr int WIN = (R - 1) * D + P;           // samples one thread reads
-    static_assert(CHUNK % 2 == 0, "chunk must hold whole float4s");
-    // padded LDS layout: 2 float2 of padding after every CHUNK samples
-    __host__ __device__ static constexpr int lds_idx(int s) { return s + 2 * (s / CHUNK); }
-    static constexpr int LDS_F2 = SPAN + 2 * (SPAN / CHUNK) + 2;
-    static constexpr size_t LDS_BYTES = (size_t)LDS_F2 * 8;
-};
-
-// One scalar load of TC taps, pinned in program order: the empty volatile asm makes
-// the address opaque (the load cannot be hoisted above it, nor out of a loop) and
-// fences memory operations, so neither the tap loads nor the LDS reads of later
-// sample blocks can pile up at the top of the unrolled code.  Constant address
-// space + an SGPR-resident address => s_load_dwordx8.
-template <int TC> struct TapVec;
-template <> struct TapVec<8> { typedef float type __attribute__((ext_vector_type(8))); };
-template <> struct TapVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
-template <int TC>
-__device__ __forceinline__ typename TapVec<TC>::type load_tap_chunk(const float* taps, int c)
-{
-    typedef const __attribute__((address_space(4))) typename TapVec<TC>::type* ctapp;
-    uint64_t a = reinterpret_cast<uint64_t>(taps) + (4u * TC) * (uint32_t)c;
-    asm volatile("" : "+s"(a));
-    return *reinterpret_cast<ctapp>(a);
-}
-
-// The MAC loop of one thread: WIN samples from LDS (two per ds_read_b128), each
-// feeding up to R outputs; fully unrolled.  Taps are wave-uniform and live in SGPRs.
-// They arrive 8 at a time, one chunk ahead of first use: a scalar-load wait is a
-// full lgkmcnt(0) drain (SMEM returns out of order) that also stalls the LDS
-// pipeline, so there must be few of them -- P/8 per tile instead of one per tap pair.
-// GUARD: the filter actually has nch_eff * TC <= P taps (run-time, wave-uniform); blocks and (block, output) pairs that
-// only meet taps beyond them are skipped, so one instantiation serves every shorter filter with exactly the arithmetic of
-// an exact-length kernel (nothing is multiplied by padding).
-template <int D, int P, int R, class T, int TC, bool GUARD>
-__device__ __forceinline__ void mac_window(const float2* __restrict__ win, const float* __restrict__ taps, float2 (&acc)[R][4],
-                                           int nch_eff)
-{
-    static_assert(P % TC == 0 && T::WIN % TC == 0 && D % TC == 0, "window and taps are walked in blocks of TC");
-    constexpr int NCH = P / TC;
-    const int nb_eff = GUARD ? nch_eff + (R - 1) * (D / TC) : 0;   // sample blocks that still meet a live tap
-    constexpr int NB = T::WIN / TC;             // sample blocks per thread
-    typename TapVec<TC>::type tc[NCH];
-    float4 buf[2][TC / 2];                      // LDS reads are double-buffered one block ahead
-    tc[0] = load_tap_chunk<TC>(taps, 0);
-#pragma unroll
-    for (int i = 0; i < TC / 2; i++) buf[0][i] = *reinterpret_cast<const float4*>(&win[2 * i + 2 * ((2 * i) / T::CHUNK)]);
-#pragma unroll
-    for (int b = 0; b < NB; b++) {
-        if (GUARD && b >= nb_eff) continue;         // wave-uniform: nothing left for this block
-        // the fence inside load_tap_chunk keeps these reads (block b+1) here, ahead of block b's MACs
-        if (b + 1 < NCH && (!GUARD || b + 1 < nch_eff)) tc[b + 1] = load_tap_chunk<TC>(taps, b + 1);   // never past the filter's own taps
-        else asm volatile("" ::: "memory");
-        if (b + 1 < NB) {
-#pragma unroll
-            for (int i = 0; i < TC / 2; i++) {
-                const int s = TC * (b + 1) + 2 * i;
-                buf[(b + 1) & 1][i] = *reinterpret_cast<const float4*>(&win[s + 2 * (s / T::CHUNK)]);
-            }
-        }
-        if constexpr (!GUARD) {
-#pragma unroll
-            for (int i = 0; i < TC / 2; i++) {
-                const float4 v2 = buf[b & 1][i];
-                const float2 v[2] = {make_float2(v2.x, v2.y), make_float2(v2.z, v2.w)};
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const int ss = TC * b + 2 * i + e;
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const int j = ss - r * D;
-                        if (j >= 0 && j < P) {
-                            const float h = tc[j / TC][j % TC];
-                            acc[r][j & 3].x = acc[r][j & 3].x + h * v[e].x;
-                            acc[r][j & 3].y = acc[r][j & 3].y + h * v[e].y;
-                        }
-                    }
-                }
-            }
-        } else {
-            // output r meets tap chunk cb = b - r*D/TC in this block: live iff 0 <= cb < nch_eff (per output the taps are
-            // still walked in increasing order, which is all the summation order asks for)
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int cb = b - r * (D / TC);
-                if (cb < 0 || cb >= NCH) continue;
-                if (cb >= nch_eff) continue;        // wave-uniform
-#pragma unroll
-                for (int i = 0; i < TC / 2; i++) {
-                    const float4 v2 = buf[b & 1][i];
-                    const float2 v[2] = {make_float2(v2.x, v2.y), make_float2(v2.z, v2.w)};
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const int jj = 2 * i + e;   // tap cb*TC + jj
-                        const float h = tc[cb][jj];
-                        acc[r][jj & 3].x = acc[r][jj & 3].x + h * v[e].x;
-                        acc[r][jj & 3].y = acc[r][jj & 3].y + h * v[e].y;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// Staging of one tile: all of a thread's 16-byte global loads are issued before the first wait, then
-// converted (u8) and written to the padded LDS layout.
-template <class T, bool U8, int NT>
-struct Stage {
-    static constexpr int SPV = U8 ? 8 : 2;                       // samples per 16-byte vector
-    static constexpr int NV = (T::SPAN + SPV - 1) / SPV;         // vectors per tile
-    static constexpr int PER = (NV + NT - 1) / NT;               // vectors per thread
-    uint4 r[PER];
-
-    __device__ __forceinline__ void load(const void* __restrict__ src_v, int64_t sample0, int avail)
-    {
-        const char* src = reinterpret_cast<const char*>(src_v) + (U8 ? 2 : 8) * sample0;
-        if (avail >= T::SPAN) {
-            // every tile but the last: unconditional 16-byte loads, all in flight together
-#pragma unroll
-            for (int i = 0; i < PER; i++) {
-                const int v = threadIdx.x + i * NT;
-                if (i + 1 < PER || v < NV) r[i] = *reinterpret_cast<const uint4*>(src + 16 * (int64_t)v);
-            }
-            return;
-        }
-        // ragged end of the stream (one workgroup per launch): element-wise, zero-filled (u8 128 == 0.0f)
-#pragma unroll 1
-        for (int i = 0; i < PER; i++) {
-            const int v = threadIdx.x + i * NT;
-            const int s = v * SPV;
-            uint32_t w[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) w[k] = U8 ? 0x80808080u : 0u;
-            if (v < NV) {
-                if constexpr (U8) {
-                    const uint8_t* b = reinterpret_cast<const uint8_t*>(src) + 16 * (int64_t)v;
-                    for (int e = 0; e < 16; e++)
-                        if (s + e / 2 < avail) w[e >> 2] = (w[e >> 2] & ~(0xffu << (8 * (e & 3)))) | ((uint32_t)b[e] << (8 * (e & 3)));
-                } else {
-                    const uint32_t* f = reinterpret_cast<const uint32_t*>(src) + 4 * (int64_t)v;
-                    for (int e = 0; e < 4; e++)
-                        if (s + e / 2 < avail) w[e] = f[e];
-                }
-            }
-            // PER is small and compile-time: a select chain keeps r[] in registers
-#pragma unroll
-            for (int q = 0; q < PER; q++)
-                if (q == i) r[q] = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-    }
-
-    __device__ __forceinline__ void store(float2* __restrict__ lds) const
-    {
-#pragma unroll
-        for (int i = 0; i < PER; i++) {
-            const int v = threadIdx.x + i * NT;
-            const int s = v * SPV;
-            if (v < NV) {
-                if constexpr (!U8) {
-                    *reinterpret_cast<uint4*>(&lds[T::lds_idx(s)]) = r[i];
-                } else {
-                    const uint32_t w[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        float4 f;
-                        // (u - 128) * (1/128) == fma(u, 1/128, -1) exactly: every result is
-                        // representable, so the single rounding of the fma returns the same bits
-                        f.x = __builtin_fmaf((float)(w[k] & 0xff), 1.0f / 128.0f, -1.0f);
-                        f.y = __builtin_fmaf((float)((w[k] >> 8) & 0xff), 1.0f / 128.0f, -1.0f);
-                        f.z = __builtin_fmaf((float)((w[k] >> 16) & 0xff), 1.0f / 128.0f, -1.0f);
-                        f.w = __builtin_fmaf((float)(w[k] >> 24), 1.0f / 128.0f, -1.0f);
-                        const int ss = s + 2 * k;
-                        if (ss < T::SPAN + 1) *reinterpret_cast<float4*>(&lds[T::lds_idx(ss)]) = f;
-                    }
-                }
-            }
-        }
-    }
-};
-
-template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false>
-__global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in, int64_t x0 /* sample index of output 0's window in `in` */,
-                                                    int count, const float* __restrict__ taps, float* __restrict__ out,
-                                                    int p_eff /* GUARD: taps of the filter (multiple of TC, <= P); else unused */)
-{
-    using T = Tile<D, P, R, NT>;
-    static_assert(D % 4 == 0, "lane of a tap must not depend on the output within a thread");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* lds = reinterpret_cast<float2*>(smem_raw);
-
-    // XCD-aware tile order: workgroup b runs on XCD b % 8 (each XCD has its own L2).  Within every group
-    // of 64 consecutive tiles XCD x takes the 8 consecutive tiles [8x, 8x+8), so 7 of 8 tile-to-tile
-    // overlaps (120 samples each) hit in the SAME L2, while all XCDs still stream through the same
-    // ~2 MB neighbourhood of HBM (giving every XCD its own far-apart eighth of the buffer measured
-    // 20 % slower: DRAM locality matters more than the 3 % of re-reads).
-    const int ntiles = (count + T::OUTS - 1) / T::OUTS;
-    const int b = blockIdx.x;
-    const int tile = (b & ~63) + ((b & 7) << 3) + ((b >> 3) & 7);
-    if (tile >= ntiles) return;
-    const int out0 = tile * T::OUTS;
-    const int64_t s0 = (int64_t)out0 * D;                     // first sample of the tile, relative to x0
-    const int64_t total_avail = (int64_t)(count - 1) * D + (GUARD ? p_eff : P); // samples that exist from x0 on
-    int64_t av = total_avail - s0;
-    int avail = av > T::SPAN ? T::SPAN : (int)av;
-
-    {
-        // all of the tile's global loads in flight at once, then one wait
-        Stage<T, U8, NT> st;
-        st.load(in, x0 + s0, avail);
-        st.store(lds);
-    }
-    __syncthreads();
-
-    // per-thread window starts at sample tid*CHUNK of the tile
-    const float2* win = lds + T::lds_idx(threadIdx.x * T::CHUNK);
-    float2 acc[R][4];
-#pragma unroll
-    for (int r = 0; r < R; r++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) acc[r][k] = make_float2(0.0f, 0.0f);
-
-    mac_window<D, P, R, T, TC, GUARD>(win, taps, acc, GUARD ? p_eff / TC : 0);
-
-    const int o = out0 + threadIdx.x * R;
-    float2 res[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        res[r].x = (acc[r][0].x + acc[r][1].x) + (acc[r][2].x + acc[r][3].x);
-        res[r].y = (acc[r][0].y + acc[r][1].y) + (acc[r][2].y + acc[r][3].y);
-    }
-    if (R % 2 == 0 && o + R <= count) {
-        float4* dst = reinterpret_cast<float4*>(out + 2 * (int64_t)o);
-#pragma unroll
-        for (int r = 0; r + 1 < R; r += 2) dst[r / 2] = make_float4(res[r].x, res[r].y, res[r + 1].x, res[r + 1].y);
-    } else {
-#pragma unroll
-        for (int r = 0; r < R; r++)
-            if (o + r < count) *reinterpret_cast<float2*>(out + 2 * (int64_t)(o + r)) = res[r];
-    }
-}
-
-// Cross outputs: sequential order over the Lp plain taps (decimateCrossHighLevel,
-// FilterInternal.hs:397-402).  The <= ceil((Lp-1)/D) straddlers of one seam have
-// windows that overlap almost entirely, so a group of PER threads stages their union
-// (Lp + (PER-1)*D samples, converted once) in LDS with coalesced loads and each
-// thread then walks its own window.  SPW seams per workgroup.
-template <bool U8, int D, int LP, int PER, int SPW, bool RT = false>
-__global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const float* __restrict__ xtaps,
-                                                                   const void* __restrict__ in, float* __restrict__ out,
-                                                                   int64_t first_seam, int nseams)
-{
-    // RT: the filter has g.Lp <= LP taps (run-time); the staging layout is still the one of LP taps
-    const int lp = RT ? g.Lp : LP;
-    static_assert(D == 8 && PER == 16 && LP <= 128, "LDS layout below is worked out for 16 candidate slots 8 samples apart");
-    constexpr int UNI = LP + (PER - 1) * D;          // samples in the union of one seam's windows
-    // layout: one float2 of padding after every 8 samples (candidate c then starts at 9c float2 = 18c
-    // dwords: 16 distinct bank pairs), rows 16 (mod 32) float2 apart (the two seams of a 32-lane group
-    // land on complementary banks): ds_read_b64 conflict-free.
-    constexpr int ROW = ((UNI + UNI / 8 + 31) / 32) * 32 + 16;
-    static_assert(UNI <= PER * SPW, "one staging pass per seam");
-    __shared__ float2 lds[SPW * ROW];
-    const int tid = threadIdx.x;
-    const int seam0 = blockIdx.x * SPW;
-    const int64_t lo = g.k_begin * D - g.in_base, hi = (g.k_begin + g.count - 1) * (int64_t)D + lp - g.in_base;
-    {
-        // staging: the PER lanes of a seam load its union with 16-byte vectors, all seams of the
-        // workgroup at once (one HBM round trip).  The union starts at a multiple of 8 samples, i.e.
-        // 16-byte aligned like the tiles of the main kernel.
-        const int sl = tid / PER, lane = tid - sl * PER;
-        const int si = seam0 + sl;
-        if (si < nseams) {
-            const int64_t edge = (first_seam + si) * g.seamBI;
-            const int64_t m_hi = (edge + D - 1) / D - 1;                 // last output starting before the edge
-            const int64_t u0 = (m_hi - (PER - 1)) * D - g.in_base;       // first sample of the union, relative to `in`
-            constexpr int SPV = U8 ? 8 : 2;                              // samples per 16-byte vector
-            constexpr int NV = (UNI + SPV - 1) / SPV;
-            float2* row = lds + sl * ROW;
-            for (int v = lane; v < NV; v += PER) {
-                const int64_t idx = u0 + (int64_t)v * SPV;
-                float2 smp[SPV];
-                // vectors that poke outside the launch's own windows only feed discarded candidates
-                if (idx >= lo && idx + SPV <= hi) {
-                    if constexpr (U8) {
-                        const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(in) + 2 * idx);
-                        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            smp[2 * k] = make_float2(((float)(w[k] & 0xff) - 128.0f) * (1.0f / 128.0f),
-                                                     ((float)((w[k] >> 8) & 0xff) - 128.0f) * (1.0f / 128.0f));
-                            smp[2 * k + 1] = make_float2(((float)((w[k] >> 16) & 0xff) - 128.0f) * (1.0f / 128.0f),
-                                                         ((float)(w[k] >> 24) - 128.0f) * (1.0f / 128.0f));
-                        }
-                    } else {
-                        const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(in) + 2 * idx);
-                        smp[0] = make_float2(q.x, q.y);
-                        smp[1] = make_float2(q.z, q.w);
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < SPV; k++) {
-                        const int64_t ik = idx + k;
-                        float2 t = make_float2(0.0f, 0.0f);
-                        if (ik >= lo && ik < hi) {
-                            if constexpr (U8) {
-                                const uchar2 u = *reinterpret_cast<const uchar2*>(reinterpret_cast<const uint8_t*>(in) + 2 * ik);
-                                t = make_float2(((float)u.x - 128.0f) * (1.0f / 128.0f), ((float)u.y - 128.0f) * (1.0f / 128.0f));
-                            } else {
-                                t = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(in) + 2 * ik);
-                            }
-                        }
-                        smp[k] = t;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < SPV; k++) {
-                    const int so = v * SPV + k;
-                    if (so < UNI) row[so + so / 8] = smp[k];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int sl = tid / PER, ci = tid - sl * PER;
-    const int si = seam0 + sl;
-    if (si >= nseams) return;
-    const int64_t edge = (first_seam + si) * g.seamBI;
-    const int64_t m_hi = (edge + D - 1) / D - 1;
-    const int64_t m = m_hi - (PER - 1) + ci;
-    if (m < g.k_begin || m >= g.k_begin + g.count) return;
-    const int64_t vm = m * D;
-    if (!(vm < edge && vm + lp > edge)) return;
-    const float2* w = lds + sl * ROW + ci * (D + 1);
-    float re = 0.0f, im = 0.0f;
-    if constexpr (RT) {
-        for (int j = 0; j < lp; j++) {
-            const float2 x = w[j + j / 8];
-            const float h = xtaps[j];
-            re = re + x.x * h;
-            im = im + x.y * h;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < LP; j++) {
-            const float2 x = w[j + j / 8];
-            const float h = xtaps[j];
-            re = re + x.x * h;
-            im = im + x.y * h;
-        }
-    }
-    *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
-}
-
-template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false>
-void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, float* out)
-{
-    using T = Tile<D, P, R, NT>;
-    static std::atomic<bool> attr_set{false};   // idempotent: a race only repeats the call
-    auto kern = k_decimate_c4<D, P, R, NT, U8, TC, GUARD>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)T::LDS_BYTES);
-        attr_set = true;
-    }
-    int tiles = (g.count + T::OUTS - 1) / T::OUTS;
-    int grid = ((tiles + 63) / 64) * 64;       // whole groups of 64: the kernel permutes blockIdx -> tile within a group
-    int64_t x0 = g.k_begin * D - g.in_base;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, taps, out, g.Lp);
-}
 
 }  // namespace
 

@@ -64,8 +64,10 @@ def test_decimator_families(hip, oracle, order, complex_, factor, ntaps):
     K = exp.size // w
     assert K >= 4096
     d = hip.Decimator(factor, taps, order, complex_=complex_)
-    # complex AVX decimators by 4 / 8 / 16 with up to 128 taps have their own kernel (k_decimate_c4, exact or guarded)
-    special = factor in (4, 8, 16) and order == PM.ORDER_AVX and complex_ and factor < d.num_coeffs <= (128 if factor == 4 else 256)
+    # complex decimators by 4 / 8 / 16 with up to 128 (256) taps have their own kernel (k_decimate_c4, exact or guarded;
+    # the SSE order through kernels_fast_orders.hip)
+    special = (factor in (4, 8, 16) and order in (PM.ORDER_AVX, PM.ORDER_SSE) and complex_ and d.num_coeffs % 4 == 0
+               and factor < d.num_coeffs <= (128 if factor == 4 else 256))
     before = _tiled(hip)
     got = _run(d, to_dev(x), w, K, B)
     if _fits(d.num_coeffs, order, complex_) and not special:
@@ -127,7 +129,8 @@ def test_resampler_families(hip, oracle, order, complex_, I, D, ntaps):
     K = exp.size // w
     assert K >= 4096
     r = hip.Resampler(I, D, taps, order, complex_)
-    is_special = (I, D, order, complex_) == (3, 10, PM.ORDER_AVX, False)
+    # 3/10 with 64-tap groups has specialised kernels: real AVX (k_resample3_fast), complex AVX / SSE (k_resample3c_fast)
+    is_special = (I, D) == (3, 10) and 185 <= ntaps <= 192 and (order == PM.ORDER_AVX or (complex_ and order == PM.ORDER_SSE))
     before = _tiled(hip)
     got = _run(r, to_dev(x), w, K, B, out_block=512)
     if not is_special:
