@@ -442,8 +442,11 @@ def main():
         elapsed = main_run["elapsed"]
         total_samples = world * S_len * passes * args.steps
         k2_s = stage_ms["decimate"] * 1e-3
-        k2_alg_bytes = 3.0 * plan.k2_samples                      # u8-fused K2 = 2 B read + 1 B written per input sample
-        k2_flops = 64.0 * plan.k2_samples                         # 2*2*P/D unfused flop per input sample
+        # samples the TIMED decimate launch consumed: with the overlapped halo exchange only the chain object that computes
+        # [q0, q_mid) carries timing events, and it reads the rank's own shard only
+        k2_n = plan.shard_len if main_run["overlap"] else plan.k2_samples
+        k2_alg_bytes = 3.0 * k2_n                                 # u8-fused K2 = 2 B read + 1 B written per input sample
+        k2_flops = 64.0 * k2_n                                    # 2*2*P/D unfused flop per input sample
         hbm_achieved = k2_alg_bytes / k2_s / 1e9 if k2_s > 0 else 0.0
         valu_achieved = k2_flops / k2_s / 1e12 if k2_s > 0 else 0.0
         traffic, traffic_note = None, None

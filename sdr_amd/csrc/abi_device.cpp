@@ -33,11 +33,27 @@ int upload_floats(float** d, const std::vector<float>& h)
 // mutation there is goes under a lock (d_taps / d_groups are published last).
 static std::mutex g_upload_mu;
 
+// A descriptor's taps live on the device that was current at its first use; using it from another device afterwards would
+// hand kernels pointers into the wrong HBM: refused loudly (one descriptor per device, like one chain per device).
+static int check_device(int* dev_of, const char* what)
+{
+    int dev = 0;
+    SDRHIP_CHECK_HIP(hipGetDevice(&dev));
+    if (*dev_of < 0) *dev_of = dev;
+    if (*dev_of != dev) {
+        set_error("%s: the descriptor's taps were uploaded to device %d, the current device is %d (create one descriptor per device)", what,
+                  *dev_of, dev);
+        return SDRHIP_ERR_STATE;
+    }
+    return SDRHIP_OK;
+}
+
 int FirDesc::ensure_device() const
 {
     std::lock_guard<std::mutex> lk(g_upload_mu);
+    int rc = check_device(&device, "filter / decimator");
+    if (rc != SDRHIP_OK) return rc;
     if (d_taps) return SDRHIP_OK;
-    int rc;
     if ((rc = upload_floats(&d_cross, h_plain)) != SDRHIP_OK) return rc;
     d_plain = d_cross;
     return upload_floats(&d_taps, h_kernel);
@@ -45,8 +61,9 @@ int FirDesc::ensure_device() const
 int ResampDesc::ensure_device() const
 {
     std::lock_guard<std::mutex> lk(g_upload_mu);
+    int rc = check_device(&device, "resampler");
+    if (rc != SDRHIP_OK) return rc;
     if (d_groups) return SDRHIP_OK;
-    int rc;
     if ((rc = upload_floats(&d_plain, h_plain)) != SDRHIP_OK) return rc;
     return upload_floats(&d_groups, h_groups);
 }

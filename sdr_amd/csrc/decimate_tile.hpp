@@ -389,12 +389,15 @@ template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4),
 void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, float* out)
 {
     using T = Tile<D, P, R, NT>;
-    static std::atomic<bool> attr_set{false};   // idempotent: a race only repeats the call
+    // the dynamic-LDS attribute is per device: one flag per (instantiation, device); idempotent, a race only repeats the call
+    static std::atomic<bool> attr_set[64];
     auto kern = k_decimate_c4<D, P, R, NT, U8, TC, GUARD, NP, ORD>;
-    if (!attr_set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)T::LDS_BYTES);
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     int tiles = (g.count + T::OUTS - 1) / T::OUTS;
     int grid = ((tiles + 63) / 64) * 64;       // whole groups of 64: the kernel permutes blockIdx -> tile within a group

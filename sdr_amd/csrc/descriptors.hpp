@@ -21,6 +21,7 @@ struct FirDesc {
     int ntaps_kernel = 0; // length of d_taps as the kernel consumes it
     // Device copies are made on first use (ensure_device), so descriptors -- and the
     // planning arithmetic built on them -- can be created on a host without a GPU.
+    mutable int device = -1;           // the device the taps were uploaded to (-1: not yet)
     mutable float* d_taps = nullptr;   // real: padded plain (or half for sym); complex RC: duplicated
     mutable float* d_cross = nullptr;  // Lp plain taps for the sequential Cross outputs
     mutable float* d_plain = nullptr;  // padded plain taps (aliases d_cross)
@@ -44,6 +45,7 @@ struct ResampDesc {
     int nloop = 0;        // floats the SIMD loop actually walks
     std::vector<int> increments, offsets, lut;  // lut: filter offset -> group
     std::vector<float> h_groups, h_plain;
+    mutable int device = -1;           // the device the taps were uploaded to (-1: not yet)
     mutable float* d_groups = nullptr;
     mutable float* d_plain = nullptr;
     int ensure_device() const;

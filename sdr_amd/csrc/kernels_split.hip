@@ -280,10 +280,13 @@ template <bool CPLX, int M, int ORD, bool SYM, int NCHMAX, int U, bool EXACT>
 void launch_kernel(hipStream_t s, const SplitArgs& a, unsigned grid, size_t lds_bytes)
 {
     auto kern = k_split<CPLX, M, ORD, SYM, NCHMAX, U, EXACT>;
-    static std::atomic<bool> attr_set{false};   // per instantiation: tiles of large decimation factors exceed the 64 KiB default cap
-    if (!attr_set) {
+    // per instantiation and device: tiles of large decimation factors exceed the 64 KiB default cap
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, s, a);
 }

@@ -132,3 +132,26 @@ def test_device_calls_fail_loudly_without_a_gpu(L):
     p = C.c_void_p()
     assert L.lib.sdrhip_malloc(C.byref(p), 1024) < 0
     assert b"hipMalloc" in L.lib.sdrhip_last_error()
+
+
+def test_round2_entry_points_fail_loudly_without_a_gpu(L):
+    """The multi-GPU, record-seam and spectrum entry points have no CPU fallback either: without a device they return an
+    error and say why (run-time bound RCCL / hipFFT included)."""
+    if L.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(L.SdrHipError):
+        L.comm_unique_id()
+    with pytest.raises(L.SdrHipError):
+        L.Comm.local([0], L.TRANSPORT_PEER_COPY)
+    with pytest.raises(L.SdrHipError):
+        L.Fft(1024)
+    dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
+    x = np.zeros(2 * 8192, np.float32)
+    out = np.zeros(2 * 1009, np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    assert L.lib.sdrhip_decimator_one(dec.h, 1009, fp(x), fp(out)) < 0
+    assert L.lib.sdrhip_decimator_cross(dec.h, 15, fp(x), 120, fp(x), 8192, fp(out)) < 0
+    # planning arithmetic needs no device: the halo of the FM chain is the composed ntaps-1 overlap, whole 16-byte vectors
+    ch = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, 8192)
+    h = ch.halo_samples()
+    assert h % 8 == 0 and ch.max_halo() <= h < ch.max_halo() + 8
