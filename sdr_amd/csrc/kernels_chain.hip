@@ -33,10 +33,10 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
         if (q > 0 || has_prev) prev = in2[4 * q - 1];
         else prev = make_float2(last_re, last_im);
         float4 r;
-        r.x = fm_phase_sel(s0, prev);
-        r.y = fm_phase_sel(s1, s0);
-        r.z = fm_phase_sel(s2, s1);
-        r.w = fm_phase_sel(s3, s2);
+        r.x = fm_phase_tern(s0, prev);
+        r.y = fm_phase_tern(s1, s0);
+        r.z = fm_phase_tern(s2, s1);
+        r.w = fm_phase_tern(s3, s2);
         if (out_vec) {
             reinterpret_cast<float4*>(out)[q] = r;
         } else {
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
         float2 prev;
         if (i > 0 || has_prev) prev = in2[i - 1];
         else prev = make_float2(last_re, last_im);
-        out[i] = fm_phase_sel(cur, prev);
+        out[i] = fm_phase_tern(cur, prev);
     }
 }
 
