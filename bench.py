@@ -181,6 +181,7 @@ def main():
     torch.cuda.set_device(dev)
     L.check(L.lib.sdrhip_set_device(dev), "sdrhip_set_device")
     comm = None
+    rccl_hung = False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -193,11 +194,30 @@ def main():
                 box, ok = [None], 0
             dist.broadcast_object_list(box, src=0)
             if box[0] is not None:
-                try:
-                    comm = L.Comm(world, rank, box[0])
-                except Exception as e:               # noqa: BLE001 -- SURVEY 8(e) fallback: same halos through host memory
-                    sys.stderr.write(f"bench: sdrhip_comm_init_rank failed on rank {rank} ({e!r})\n")
+                # ncclCommInitRank is a collective that cannot be cancelled: run it beside a watchdog, so that a rendezvous that
+                # never completes (a mis-set environment on the box) costs two minutes and the host-memory fallback, not the run
+                import threading
+                res = {}
+
+                def _init():
+                    try:
+                        L.check(L.lib.sdrhip_set_device(dev), "sdrhip_set_device")
+                        res["comm"] = L.Comm(world, rank, box[0])
+                    except Exception as e:           # noqa: BLE001 -- SURVEY 8(e) fallback: same halos through host memory
+                        res["err"] = e
+
+                th = threading.Thread(target=_init, daemon=True)
+                th.start()
+                th.join(float(os.environ.get("BENCH_RCCL_INIT_TIMEOUT", "120")))
+                if th.is_alive():
+                    sys.stderr.write(f"bench: sdrhip_comm_init_rank did not return on rank {rank} within the time limit\n")
                     ok = 0
+                    rccl_hung = True
+                elif "err" in res:
+                    sys.stderr.write(f"bench: sdrhip_comm_init_rank failed on rank {rank} ({res['err']!r})\n")
+                    ok = 0
+                else:
+                    comm = res["comm"]
             flag = torch.tensor([ok if box[0] is not None else 0], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if not bool(flag.item()):
@@ -520,6 +540,9 @@ def main():
         comm.close()
     if world > 1:
         dist.destroy_process_group()
+    if rccl_hung:
+        sys.stdout.flush()
+        os._exit(0)          # a thread is still inside ncclCommInitRank: do not wait for it at interpreter exit
 
 
 if __name__ == "__main__":
