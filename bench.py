@@ -229,9 +229,10 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
-    def measure(blocks, steps, warmup, passes, ramp_s, timing):
+    def measure(blocks, steps, warmup, passes, ramp_s, timing, graph=False):
         """One configuration: `blocks` 8192-sample blocks per GPU per pass.  Returns the max-over-ranks wall time of
-        `steps` steps of `passes` passes each, the per-stage HIP-event times and the plan."""
+        `steps` steps of `passes` passes each, the per-stage HIP-event times and the plan.  graph: the chain's kernels of
+        one pass replayed from a hipGraph captured once (sdrhip_fm_chain_graph_*): one launch per pass instead of nine."""
         S_len = blocks * BLOCK
         plan = sharding.ShardPlan(chain, rank, world, S_len)          # owned outputs + halo for this rank
         gen = torch.Generator(device="cuda").manual_seed(S.SEED_IQ + rank)
@@ -254,19 +255,38 @@ def main():
             else:
                 sharding.halo_exchange(buf, plan, dist, via_host=True)
 
+        g_all = g_a = g_b = None
+        if graph:
+            if not overlap:
+                g_all = L.FmGraph(chain, buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q1, ws.data_ptr(), ws_bytes)
+            else:
+                g_a = L.FmGraph(chain, buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q_mid, ws.data_ptr(), ws_bytes)
+                if plan.q1 > plan.q_mid:
+                    g_b = L.FmGraph(chain_b, buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr() + 4 * (plan.q_mid - plan.q0), plan.q_mid,
+                                    plan.q1, ws_b.data_ptr(), ws_bytes)
+
         def one_pass():
             if not overlap:
                 if world > 1:
                     exchange(stream)
-                chain.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q1, ws.data_ptr(), ws_bytes, stream=sptr)
+                if g_all is not None:
+                    g_all.launch(sptr)
+                else:
+                    chain.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q1, ws.data_ptr(), ws_bytes, stream=sptr)
                 return
             aux.wait_stream(stream)                      # the previous pass's readers of the halo region are done
             with torch.cuda.stream(aux):
                 exchange(aux)
                 if plan.q1 > plan.q_mid:
-                    chain_b.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr() + 4 * (plan.q_mid - plan.q0), plan.q_mid, plan.q1,
-                                ws_b.data_ptr(), ws_bytes, stream=aux.cuda_stream)
-            chain.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q_mid, ws.data_ptr(), ws_bytes, stream=sptr)
+                    if g_b is not None:
+                        g_b.launch(aux.cuda_stream)
+                    else:
+                        chain_b.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr() + 4 * (plan.q_mid - plan.q0), plan.q_mid, plan.q1,
+                                    ws_b.data_ptr(), ws_bytes, stream=aux.cuda_stream)
+            if g_a is not None:
+                g_a.launch(sptr)
+            else:
+                chain.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q_mid, ws.data_ptr(), ws_bytes, stream=sptr)
             stream.wait_stream(aux)
 
         # Clock / power-state ramp: the first ~15 ms of sustained work of a fresh process run 10 % slow; spin for ramp_s first.
@@ -329,6 +349,7 @@ def main():
                 gathered = [None] * world
                 dist.all_gather_object(gathered, crc[0])
                 crc = gathered
+        del g_all, g_a, g_b
         del buf, audio, ws
         return {"elapsed": elapsed, "passes": passes, "stage_ms": stage_ms, "plan": plan, "S_len": S_len, "overlap": overlap, "crc": crc}
 
@@ -365,11 +386,20 @@ def main():
     # halo exchange matters; reported next to the main line, same run
     shard_1m = None
     if extras and args.blocks != 128:
-        r1 = measure(128, max(2, args.steps // 4), 1, 0, 0.05, False)
+        st1 = max(2, args.steps // 4)
+        r1 = measure(128, st1, 1, 0, 0.05, False)
         shard_1m = {"samples_per_gpu_per_pass": r1["S_len"], "passes_per_step": r1["passes"],
-                    "value": round(world * r1["S_len"] * r1["passes"] * max(2, args.steps // 4) / r1["elapsed"] / 1e6, 1), "unit": "Msamples/s",
-                    "us_per_pass": round(r1["elapsed"] / (r1["passes"] * max(2, args.steps // 4)) * 1e6, 2),
+                    "value": round(world * r1["S_len"] * r1["passes"] * st1 / r1["elapsed"] / 1e6, 1), "unit": "Msamples/s",
+                    "us_per_pass": round(r1["elapsed"] / (r1["passes"] * st1) * 1e6, 2),
                     "note": "BASELINE configs[4] shard size (1M-sample block per GPU per pass): launch/latency-bound"}
+        try:
+            r2 = measure(128, st1, 1, 0, 0.05, False, graph=True)
+            shard_1m["hipgraph"] = {"value": round(world * r2["S_len"] * r2["passes"] * st1 / r2["elapsed"] / 1e6, 1),
+                                    "us_per_pass": round(r2["elapsed"] / (r2["passes"] * st1) * 1e6, 2),
+                                    "what": "the same pass with the chain's kernels replayed from a hipGraph captured once "
+                                            "(sdrhip_fm_chain_graph_*): one launch instead of nine" + ("; the halo exchange stays outside the graph" if world > 1 else "")}
+        except Exception as e:                          # noqa: BLE001
+            shard_1m["hipgraph"] = f"failed: {e!r}"
 
     dbg("shard_1m done")
     # BASELINE configs[1] (the north_star's roofline kernel): the same decimate-by-8 kernel fed cfloat IQ (8 B read + 1 B

@@ -300,6 +300,15 @@ size_t sdrhip_fm_chain_workspace_bytes(const sdrhip_fm_chain *c, int64_t n_in);
 int sdrhip_fm_chain_run(sdrhip_fm_chain *c, void *stream, const uint8_t *d_in_iq, int64_t s0, int64_t n_in,
                         float *d_audio, int64_t q0, int64_t q1, void *d_workspace, size_t workspace_bytes);
 
+/* One run with FIXED arguments (pointers, ranges) captured into a hipGraph: a launch-bound batch -- a 2^20-sample shard is
+ * nine small kernels -- then costs one graph launch per pass.  Captured from the code path sdrhip_fm_chain_run takes (a
+ * plain run precedes the capture: tap uploads and argument checks happen there).  Timing and pipelining must be off. */
+typedef struct sdrhip_fm_graph sdrhip_fm_graph;
+int sdrhip_fm_chain_graph_create(sdrhip_fm_graph **g, sdrhip_fm_chain *c, const uint8_t *d_in_iq, int64_t s0, int64_t n_in,
+                                 float *d_audio, int64_t q0, int64_t q1, void *d_workspace, size_t workspace_bytes);
+int sdrhip_fm_chain_graph_launch(sdrhip_fm_graph *g, void *stream);
+void sdrhip_fm_chain_graph_destroy(sdrhip_fm_graph *g);
+
 /* One run can be software-pipelined over `nsub` sub-batches of the output range (default 1 = off;
  * measured slower than off on MI355X, see chain.cpp):
  * the decimate kernel of sub-batch i+1 runs on the caller's stream while fmDemod / resample /

@@ -386,6 +386,55 @@ int sdrhip_fm_chain_run(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
     return SDRHIP_OK;
 }
 
+// ---- one run with fixed arguments as a hipGraph: launch-bound batches (a 2^20-sample shard is nine small kernels) pay one
+// graph launch instead of nine kernel launches.  Captured from the very code path sdrhip_fm_chain_run takes.
+struct sdrhip_fm_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap = nullptr;
+    ~sdrhip_fm_graph()
+    {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (cap) (void)hipStreamDestroy(cap);
+    }
+};
+
+int sdrhip_fm_chain_graph_create(sdrhip_fm_graph** out, sdrhip_fm_chain* c, const uint8_t* d_in_iq, int64_t s0, int64_t n_in, float* d_audio,
+                                 int64_t q0, int64_t q1, void* d_workspace, size_t workspace_bytes)
+{
+    SDRHIP_REQUIRE(out != nullptr && c != nullptr, "sdrhip_fm_chain_graph_create");
+    *out = nullptr;
+    SDRHIP_REQUIRE(!c->timing && c->nsub == 1, "sdrhip_fm_chain_graph_create: per-stage timing and sub-batch pipelining record events on the "
+                                               "chain's own streams: switch them off for a captured run");
+    sdrhip_fm_graph* g = new sdrhip_fm_graph();
+    hipError_t e = hipStreamCreateWithFlags(&g->cap, hipStreamNonBlocking);
+    if (e != hipSuccess) { set_error("sdrhip_fm_chain_graph_create: %s", hipGetErrorString(e)); delete g; return SDRHIP_ERR_HIP; }
+    // a plain run first: tap uploads, kernel attributes and argument checks happen outside the capture
+    int rc = sdrhip_fm_chain_run(c, (void*)g->cap, d_in_iq, s0, n_in, d_audio, q0, q1, d_workspace, workspace_bytes);
+    if (rc == SDRHIP_OK && hipStreamSynchronize(g->cap) != hipSuccess) { set_error("sdrhip_fm_chain_graph_create: warm-up run failed"); rc = SDRHIP_ERR_HIP; }
+    if (rc != SDRHIP_OK) { delete g; return rc; }
+    e = hipStreamBeginCapture(g->cap, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { set_error("hipStreamBeginCapture: %s", hipGetErrorString(e)); delete g; return SDRHIP_ERR_HIP; }
+    rc = sdrhip_fm_chain_run(c, (void*)g->cap, d_in_iq, s0, n_in, d_audio, q0, q1, d_workspace, workspace_bytes);
+    e = hipStreamEndCapture(g->cap, &g->graph);
+    if (rc != SDRHIP_OK) { delete g; return rc; }
+    if (e != hipSuccess || g->graph == nullptr) { set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); delete g; return SDRHIP_ERR_HIP; }
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); delete g; return SDRHIP_ERR_HIP; }
+    *out = g;
+    return SDRHIP_OK;
+}
+
+int sdrhip_fm_chain_graph_launch(sdrhip_fm_graph* g, void* stream)
+{
+    SDRHIP_REQUIRE(g != nullptr && g->exec != nullptr, "sdrhip_fm_chain_graph_launch");
+    SDRHIP_CHECK_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return SDRHIP_OK;
+}
+
+void sdrhip_fm_chain_graph_destroy(sdrhip_fm_graph* g) { delete g; }
+
 int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain* c, int nsub)
 {
     SDRHIP_REQUIRE(c != nullptr && nsub >= 1 && nsub <= 16, "sdrhip_fm_chain_set_pipelining");

@@ -119,6 +119,10 @@ lib.sdrhip_fm_chain_workspace_bytes.argtypes = [_vp, _i64]
 lib.sdrhip_fm_chain_workspace_bytes.restype = C.c_size_t
 lib.sdrhip_fm_chain_run.argtypes = [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, C.c_size_t]
 
+lib.sdrhip_fm_chain_graph_create.argtypes = [C.POINTER(_vp), _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, C.c_size_t]
+lib.sdrhip_fm_chain_graph_launch.argtypes = [_vp, _vp]
+lib.sdrhip_fm_chain_graph_destroy.argtypes = [_vp]
+lib.sdrhip_fm_chain_graph_destroy.restype = None
 lib.sdrhip_fm_chain_set_pipelining.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_set_fused_tail.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_enable_timing.argtypes = [_vp, C.c_int]
@@ -525,6 +529,20 @@ def halo_exchange_all(comms, streams, d_send, d_recv, nbytes):
     sd = (_vp * n)(*[_vp(p) for p in d_send])
     rv = (_vp * n)(*[_vp(p) for p in d_recv])
     check(lib.sdrhip_halo_exchange_all(hs, n, ss, sd, rv, nbytes), "sdrhip_halo_exchange_all")
+
+
+class FmGraph(_Handle):
+    """One FmChain.run with fixed arguments as a hipGraph (sdrhip_fm_chain_graph_*): one launch per pass."""
+    _destroy = lib.sdrhip_fm_chain_graph_destroy
+
+    def __init__(self, chain, d_in_u8, s0, n_in, d_audio, q0, q1, d_ws, ws_bytes):
+        super().__init__()
+        self.chain = chain
+        check(lib.sdrhip_fm_chain_graph_create(C.byref(self.h), chain.h, d_in_u8, s0, n_in, d_audio, q0, q1, d_ws, ws_bytes),
+              "sdrhip_fm_chain_graph_create")
+
+    def launch(self, stream=None):
+        check(lib.sdrhip_fm_chain_graph_launch(self.h, stream), "sdrhip_fm_chain_graph_launch")
 
 
 class FmStream(_Handle):

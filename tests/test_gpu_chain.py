@@ -348,3 +348,38 @@ def test_fused_tail_equals_stage_kernels(hip, oracle, block):
         got = _run(hip, ch, d, 0, total, 0, q1)
         assert exp.size >= B
         assert_bit_equal(got[: exp.size], exp, "fused tail vs restated pipes")
+
+
+def test_chain_run_as_hipgraph(hip, oracle):
+    """sdrhip_fm_chain_graph_*: one run with fixed arguments captured into a hipGraph replays to the same audio, for as many
+    launches as wanted and after the input changes under it."""
+    nblk = 40
+    total = nblk * B
+    ch = _chain(hip)
+    u8 = S.iq_u8_fm(total)
+    d = to_dev(u8)
+    q0, q1, _ = ch.plan(0, total, total)
+    ws_bytes = ch.workspace_bytes(total)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    ref = _run(hip, ch, d, 0, total, q0, q1)
+    out = dev_empty_f32(q1 - q0)
+    g = hip.FmGraph(ch, ptr(d), 0, total, ptr(out), q0, q1, ptr(ws), ws_bytes)
+    st = torch.cuda.current_stream()
+    for _ in range(3):
+        out.zero_()
+        g.launch(st.cuda_stream)
+        torch.cuda.synchronize()
+        assert_bit_equal(to_host(out), ref, "graph replay")
+    # new samples in the same buffer: the graph reads the buffer, not a snapshot
+    u8b = S.iq_u8(total)
+    d.copy_(torch.from_numpy(u8b).cuda())
+    refb = _run(hip, ch, d, 0, total, q0, q1)
+    g.launch(st.cuda_stream)
+    torch.cuda.synchronize()
+    assert_bit_equal(to_host(out), refb, "graph replay on new input")
+    with pytest.raises(hip.SdrHipError):
+        ch.enable_timing(True)
+        try:
+            hip.FmGraph(ch, ptr(d), 0, total, ptr(out), q0, q1, ptr(ws), ws_bytes)
+        finally:
+            ch.enable_timing(False)
