@@ -1,6 +1,7 @@
 // abi_device.cpp -- layer (2) of include/sdr_hip.h: descriptors + device-pointer
 // `_run` calls, plus the memory/stream helpers.
 #include <stdarg.h>
+#include <math.h>
 #include <string.h>
 
 #include <mutex>
@@ -56,6 +57,7 @@ int FirDesc::ensure_device() const
     if (d_taps) return SDRHIP_OK;
     if ((rc = upload_floats(&d_cross, h_plain)) != SDRHIP_OK) return rc;
     d_plain = d_cross;
+    if (!h_scaled.empty() && (rc = upload_floats(&d_scaled, h_scaled)) != SDRHIP_OK) return rc;
     return upload_floats(&d_taps, h_kernel);
 }
 int ResampDesc::ensure_device() const
@@ -72,6 +74,7 @@ FirDesc::~FirDesc()
 {
     if (d_taps) (void)hipFree(d_taps);
     if (d_cross) (void)hipFree(d_cross);
+    if (d_scaled) (void)hipFree(d_scaled);
 }
 ResampDesc::~ResampDesc()
 {
@@ -109,6 +112,18 @@ int fir_create(FirDesc* d, int order, bool cplx, int factor, const float* coeffs
         d->h_kernel.resize(2 * d->Lp);
         for (int i = 0; i < d->Lp; i++) d->h_kernel[2 * i] = d->h_kernel[2 * i + 1] = d->h_plain[i];
         d->ntaps_kernel = 2 * d->Lp;
+        // taps / 128 for the u8-fused tiled kernel (its loader keeps u - 128 instead of (u - 128)/128): only when the division
+        // is exact for every tap, i.e. no nonzero tap below 2^-119 (nothing a filter design produces; such a descriptor simply
+        // takes the convert-then-decimate route)
+        bool exact = true;
+        for (int i = 0; i < d->Lp; i++) {
+            const float t = d->h_plain[i];
+            if (t != 0.0f && !(fabsf(t) >= 0x1p-119f)) exact = false;      // NaN taps fail the test as well
+        }
+        if (exact) {
+            d->h_scaled.resize(d->Lp);
+            for (int i = 0; i < d->Lp; i++) d->h_scaled[i] = d->h_plain[i] * (1.0f / 128.0f);
+        }
     } else {
         d->h_kernel = d->h_plain;
         d->ntaps_kernel = d->Lp;
@@ -163,10 +178,11 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
     g.seamBI = seam_block;
     if (d->cplx) {
         if (d->corder == CO_L4 &&
-            launch_decimate_c4_fast(s, g, d->d_plain, d->Lp, d->d_cross, d_in, in_u8, d_out)) {
+            (!in_u8 || d->d_scaled) &&
+            launch_decimate_c4_fast(s, g, in_u8 ? d->d_scaled : d->d_plain, d->Lp, d->d_cross, d_in, in_u8, d_out)) {
             // specialised kernel took it
-        } else if (d->corder != CO_L4 && !d->sym &&
-                   launch_decimate_c_orders_fast(s, g, d->corder, d->d_plain, d->Lp, d->d_cross, d_in, in_u8, d_out)) {
+        } else if (d->corder != CO_L4 && !d->sym && (!in_u8 || d->d_scaled) &&
+                   launch_decimate_c_orders_fast(s, g, d->corder, in_u8 ? d->d_scaled : d->d_plain, d->Lp, d->d_cross, d_in, in_u8, d_out)) {
             // the same tiled kernel with the SSE / RC2 partial-sum layout took it
         } else if (d->corder == CO_L4 && !in_u8 &&
                    launch_filter_cplx4_fast(s, g, d->d_taps, d->Lp, d->d_cross, (const float*)d_in, d_out)) {

@@ -33,6 +33,7 @@ struct sdrhip_fm_chain {
     {
         const int D = decim.factor;
         if (!((D == 4 || D == 8 || D == 16) && decim.Lp > D && decim.Lp % 4 == 0)) return false;
+        if (decim.h_scaled.empty()) return false;      // a tap too small to pre-scale by 1/128 exactly (descriptors.hpp)
         if (decim.corder == CO_L4) return decim.Lp <= (D == 4 ? 128 : 256);
         return decim.corder == CO_L2 && decim.Lp <= 128;      // the SSE order's fused instantiations (kernels_fast_orders.hip)
     }

@@ -176,16 +176,19 @@ struct Stage {
                 if constexpr (!U8) {
                     *reinterpret_cast<uint4*>(&lds[T::lds_idx(s)]) = r[i];
                 } else {
-                    const uint32_t w[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+                    // u8 IQ: LDS receives m = u - 128 as a float (xor 0x80 turns the biased byte into a signed one: one
+                    // v_cvt_f32_i32 with a sign-extended byte operand per component), and the kernel's taps arrive pre-scaled by
+                    // 1/128 -- round((h/128) * m) and the reference's round(h * (m/128)) are the correctly rounded value of the same
+                    // real number (h/128 is exact for every tap the launcher lets through), so no bit changes and the
+                    // (u - 128) * (1/128) multiply disappears from the loader
+                    const uint32_t w[4] = {r[i].x ^ 0x80808080u, r[i].y ^ 0x80808080u, r[i].z ^ 0x80808080u, r[i].w ^ 0x80808080u};
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         float4 f;
-                        // (u - 128) * (1/128) == fma(u, 1/128, -1) exactly: every result is
-                        // representable, so the single rounding of the fma returns the same bits
-                        f.x = __builtin_fmaf((float)(w[k] & 0xff), 1.0f / 128.0f, -1.0f);
-                        f.y = __builtin_fmaf((float)((w[k] >> 8) & 0xff), 1.0f / 128.0f, -1.0f);
-                        f.z = __builtin_fmaf((float)((w[k] >> 16) & 0xff), 1.0f / 128.0f, -1.0f);
-                        f.w = __builtin_fmaf((float)(w[k] >> 24), 1.0f / 128.0f, -1.0f);
+                        f.x = (float)(signed char)(w[k] & 0xff);
+                        f.y = (float)(signed char)((w[k] >> 8) & 0xff);
+                        f.z = (float)(signed char)((w[k] >> 16) & 0xff);
+                        f.w = (float)(signed char)(w[k] >> 24);
                         const int ss = s + 2 * k;
                         if (ss < T::SPAN + 1) *reinterpret_cast<float4*>(&lds[T::lds_idx(ss)]) = f;
                     }

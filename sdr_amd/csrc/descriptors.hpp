@@ -25,6 +25,8 @@ struct FirDesc {
     mutable float* d_taps = nullptr;   // real: padded plain (or half for sym); complex RC: duplicated
     mutable float* d_cross = nullptr;  // Lp plain taps for the sequential Cross outputs
     mutable float* d_plain = nullptr;  // padded plain taps (aliases d_cross)
+    mutable float* d_scaled = nullptr; // complex stages: plain taps / 128 for the u8-fused tiled kernel (null: some tap too small to scale exactly)
+    std::vector<float> h_scaled;
     std::vector<float> h_plain;        // Lp plain taps (sym: c ++ reverse c)
     std::vector<float> h_kernel;       // what d_taps holds
     int ensure_device() const;
