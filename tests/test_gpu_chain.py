@@ -383,3 +383,31 @@ def test_chain_run_as_hipgraph(hip, oracle):
             hip.FmGraph(ch, ptr(d), 0, total, ptr(out), q0, q1, ptr(ws), ws_bytes)
         finally:
             ch.enable_timing(False)
+
+
+def test_fm_stream_crosses_the_in_place_threshold(hip, oracle):
+    """sdrhip_fm_stream: pushes of 1 block (in place, fused tail), 7 blocks (in place: 61k samples with the tail), 8 and 16
+    blocks (copy engines, stage kernels) in one stream, against one device-resident run."""
+    pattern = [1, 1, 7, 16, 1, 8, 1, 1, 16, 7, 1, 2, 8, 1]
+    nblk = sum(pattern) * 3
+    total = nblk * B
+    u8 = S.iq_u8_fm(total)
+    chain = _chain(hip)
+    _, q1, _ = chain.plan(0, total, total)
+    full = _run(hip, chain, to_dev(u8), 0, total, 0, q1)
+    st = hip.FmStream(chain, 16 * B, B)
+    got, pos = [], 0
+    for rep in range(3):
+        for k, n in enumerate(pattern):
+            chunk = u8[2 * pos * B: 2 * (pos + n) * B]
+            if (k + rep) % 2:
+                view = st.input_buffer(n * B)
+                view[: chunk.size] = chunk
+                got += st.push_inplace(view[: chunk.size])
+            else:
+                got += st.push(chunk)
+            pos += n
+    got += st.flush()
+    got = np.concatenate(got)
+    assert got.size == q1 // B * B
+    assert_bit_equal(got, full[: got.size], "mixed in-place / copied pushes vs resident")

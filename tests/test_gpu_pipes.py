@@ -293,3 +293,24 @@ def test_uniform_block_pipes_coalesced_sweep(hip, oracle):
         _cmp(got, exp, label + " (coalesced, zero-copy every third push)")
         ran += 1
     assert ran >= 20
+
+
+def test_pipes_cross_the_in_place_threshold(hip, oracle):
+    """Small pushes run in place (kernels read / write the pinned buffers over PCIe), large ones go through the copy
+    engines; the carried tail comes from the host-side history either way.  Pushes on both sides of the threshold, in both
+    orders, and the 65536-float block of BASELINE configs[3] (in place) -- same blocks as the restated Pipe."""
+    taps = S.taps_resamp191()
+    sizes = [65536, 200000, 65536, 8192, 300000, 65536, 131072, 140000, 4096, 65536]          # 512 KiB = 131072 floats
+    x = S.real_block(sum(sizes))
+    blocks = _cut(x, 1, sizes)
+    exp, _ = PM.fir_resampler_pipe(PM.ResamplerModel(oracle, 3, 10, taps, PM.ORDER_AVX), blocks, B)
+    r = hip.Resampler(3, 10, taps, hip.ORDER_AVX)
+    _cmp(_drive(hip.firResampler(r, B), blocks), exp, "firResampler across the in-place threshold")
+    # complex decimator: 8192-sample blocks in place, a 100000-sample block through the copy path
+    xc = S.cfloat_block(8192 * 3 + 100000 + 8192 * 2)
+    csizes = [8192, 8192, 100000, 8192, 8192, 8192]
+    cblocks = _cut(xc, 2, csizes)
+    t127 = S.taps_decim127()
+    expd, _ = PM.fir_decimator_pipe(PM.FilterModel(oracle, t127, PM.ORDER_AVX, complex_=True, factor=8), cblocks, 1024)
+    d = hip.Decimator(8, t127, hip.ORDER_AVX, complex_=True)
+    _cmp(_drive(hip.firDecimator(d, 1024), cblocks), expd, "firDecimator across the in-place threshold")
