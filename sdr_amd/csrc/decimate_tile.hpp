@@ -223,7 +223,9 @@ __device__ __forceinline__ float2 fold_partials(const float2 (&a)[NP])
 template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false, int NP = 4, int ORD = 0>
 __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in, int64_t x0 /* sample index of output 0's window in `in` */,
                                                     int count, const float* __restrict__ taps, float* __restrict__ out,
-                                                    int p_eff /* GUARD: taps of the filter (multiple of TC, <= P); else unused */)
+                                                    int p_eff /* GUARD: taps of the filter (multiple of TC, <= P); else unused */,
+                                                    int inl_seam /* > 0: compute the Cross outputs of buffers this long HERE */,
+                                                    int inl_r0 /* window start of output 0 inside its buffer */)
 {
     using T = Tile<D, P, R, NT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -266,6 +268,33 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
     float2 res[R];
 #pragma unroll
     for (int r = 0; r < R; r++) res[r] = fold_partials<NP, ORD>(acc[r]);
+    if (inl_seam > 0) {
+        // Small launches (one host block per push): the seam fix-up is not worth a launch of its own.  An output whose window
+        // straddles a multiple of inl_seam samples is recomputed right here in the reference's sequential order
+        // (decimateCrossHighLevel, FilterInternal.hs:397-402) from the same LDS tile.  rt = the tile's first window start
+        // inside its buffer (one 64-bit modulo per workgroup); a tile spans less than one buffer (the launcher checks).
+        const int plen = GUARD ? p_eff : P;
+        const int rt = (int)(((int64_t)inl_r0 + s0) % inl_seam);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            int rr = rt + (threadIdx.x * R + r) * D;
+            if (rr >= inl_seam) rr -= inl_seam;
+            if (rr + plen > inl_seam) {
+                // `taps` IS the plain tap array in tap order (for u8 input pre-scaled by 1/128 like the samples in LDS are
+                // un-scaled: the products are the reference's, see Stage::store); the window of output r starts r*D
+                // samples into the thread's
+                float re = 0.0f, im = 0.0f;
+                for (int j = 0; j < plen; j++) {
+                    const int sidx = r * D + j;
+                    const float2 x = win[sidx + 2 * (sidx / T::CHUNK)];
+                    const float h = taps[j];
+                    re = re + x.x * h;
+                    im = im + x.y * h;
+                }
+                res[r] = make_float2(re, im);
+            }
+        }
+    }
     if (R % 2 == 0 && o + R <= count) {
         float4* dst = reinterpret_cast<float4*>(out + 2 * (int64_t)o);
 #pragma unroll
@@ -388,8 +417,11 @@ __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const
     *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
 }
 
+// inline_cross: the kernel computes the Cross outputs itself (no fix-up launch); *inlined tells whether the geometry allowed
+// it (a tile must span less than one buffer)
 template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false, int NP = 4, int ORD = 0>
-void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, float* out)
+void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, float* out, bool inline_cross = false,
+               bool* inlined = nullptr)
 {
     using T = Tile<D, P, R, NT>;
     // the dynamic-LDS attribute is per device: one flag per (instantiation, device); idempotent, a race only repeats the call
@@ -405,7 +437,13 @@ void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, 
     int tiles = (g.count + T::OUTS - 1) / T::OUTS;
     int grid = ((tiles + 63) / 64) * 64;       // whole groups of 64: the kernel permutes blockIdx -> tile within a group
     int64_t x0 = g.k_begin * D - g.in_base;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, taps, out, g.Lp);
+    int inl_seam = 0, inl_r0 = 0;
+    if (inline_cross && g.seamBI >= (int64_t)T::OUTS * D + g.Lp && g.seamBI < (1 << 30)) {
+        inl_seam = (int)g.seamBI;
+        inl_r0 = (int)((g.k_begin * D) % g.seamBI);
+    }
+    if (inlined) *inlined = inl_seam > 0;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, taps, out, g.Lp, inl_seam, inl_r0);
 }
 
 

@@ -51,13 +51,17 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
         if (((base + 8 * (uintptr_t)x0) & 15) != 0) return false;
     }
     if ((reinterpret_cast<uintptr_t>(d_out) & 15) != 0) return false;
+    // Small launches (a host block per push: <= 8 tiles) compute their Cross outputs inside the main kernel: one launch
+    // instead of two.  Large launches keep the separate fix-up (a diverging wave per tile costs more than the 4 % it takes).
+    const bool inl = g.seamBI > 0 && g.count <= 8 * 512;
+    bool inlined = false;
     // R = 2 outputs per thread, 256 threads, 4 workgroups per CU.  Alternatives measured on MI355X and dropped:
     // R = 4 (the compiler's SGPR allocation for the sliding tap window collapses into spills), 512-thread
     // workgroups (same rate), and a persistent kernel that prefetches the next tile into registers during the
     // MAC phase (same rate: with random data the kernel is power/clock-limited, the exposed load phase is ~4 %).
     if (guarded) {
-#define GUARDED(DV, PV, TCV) do { if (in_is_u8) launch_c4<DV, PV, 2, 256, true, TCV, true>(s, g, d_plain_taps, d_in, d_out); \
-                                  else launch_c4<DV, PV, 2, 256, false, TCV, true>(s, g, d_plain_taps, d_in, d_out); } while (0)
+#define GUARDED(DV, PV, TCV) do { if (in_is_u8) launch_c4<DV, PV, 2, 256, true, TCV, true>(s, g, d_plain_taps, d_in, d_out, inl, &inlined); \
+                                  else launch_c4<DV, PV, 2, 256, false, TCV, true>(s, g, d_plain_taps, d_in, d_out, inl, &inlined); } while (0)
         if (g.D == 4) GUARDED(4, 128, 4);
         else if (g.D == 16 && P <= 128) { if (P % 8 == 0) GUARDED(16, 128, 8); else GUARDED(16, 128, 4); }
         else if (g.D == 16) { if (P % 8 == 0) GUARDED(16, 256, 8); else GUARDED(16, 256, 4); }
@@ -66,14 +70,14 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
 #undef GUARDED
     } else if (P == 52) {
         // the tap count of the reference FM example's RF decimation filter (51 -> 52)
-        if (in_is_u8) launch_c4<8, 52, 2, 256, true>(s, g, d_plain_taps, d_in, d_out);
-        else launch_c4<8, 52, 2, 256, false>(s, g, d_plain_taps, d_in, d_out);
+        if (in_is_u8) launch_c4<8, 52, 2, 256, true>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
+        else launch_c4<8, 52, 2, 256, false>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
     } else {
-        if (in_is_u8) launch_c4<8, 128, 2, 256, true>(s, g, d_plain_taps, d_in, d_out);
-        else launch_c4<8, 128, 2, 256, false>(s, g, d_plain_taps, d_in, d_out);
+        if (in_is_u8) launch_c4<8, 128, 2, 256, true>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
+        else launch_c4<8, 128, 2, 256, false>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
     }
 
-    if (g.seamBI != 0) {
+    if (g.seamBI != 0 && !inlined) {
         // seams whose straddling outputs may fall in [k_begin, k_end)
         int64_t v_lo = g.k_begin * g.D, v_hi = (g.k_begin + g.count - 1) * g.D + g.Lp;
         int64_t first = v_lo / g.seamBI + 1;          // first boundary strictly above v_lo
