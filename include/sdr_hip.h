@@ -157,6 +157,12 @@ const char *sdrhip_last_error(void);
 int sdrhip_device_count(void);
 int sdrhip_set_device(int dev);
 int sdrhip_device_name(char *buf, int buflen);
+/* Tuning / test knob.  A seamed launch (seam_block > 0) of a real filter or resampler with at most this many outputs --
+ * one host block going through a Pipe -- takes the generic kernel, which decides One / Cross per output in ONE launch;
+ * longer launches take the tiled kernels plus a second launch for the seam outputs.  Results are identical either way.
+ * Default 32768 (also: environment SDRHIP_SMALL_LAUNCH); 0 = always the tiled kernels; negative = restore the default.
+ * Returns the previous value. */
+int sdrhip_set_small_launch_outputs(int outputs);
 
 /* Thin memory / stream helpers so a non-C++ host (Haskell, ctypes) needs no HIP
  * bindings of its own.  `stream` arguments are hipStream_t passed as void*

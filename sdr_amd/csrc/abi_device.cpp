@@ -4,11 +4,16 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "descriptors.hpp"
 
 namespace sdrhip {
+
+// outputs: seamed launches of the real filter / resampler no longer than this take the one-launch generic kernel
+constexpr int kSmallSeamedLaunch = 32768;
+static std::atomic<int> g_small_launch{getenv("SDRHIP_SMALL_LAUNCH") ? atoi(getenv("SDRHIP_SMALL_LAUNCH")) : kSmallSeamedLaunch};
 
 static thread_local char g_err[512] = "";
 
@@ -198,7 +203,14 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
         if (gain != 1.0f) launch_scale(s, gain, d_out, d_out, 2 * (int64_t)g.count);
     } else {
         SDRHIP_REQUIRE(!in_u8, "fir_run: u8 input is IQ data, complex stages only");
-        if (d->lanes == 8 &&
+        // A seamed launch this short is one host block passing through a Pipe: the generic kernel does it in ONE launch (Cross
+        // outputs decided per output) where the tiled kernels need a second one for the seams, and launches are what such a
+        // push costs (measured, 8192-float blocks: 15.7 -> 14.1 us per push).
+        const bool small = g.seamBI > 0 && g.count <= g_small_launch.load(std::memory_order_relaxed);
+        if (small) {
+            launch_fir_real(s, g, d->lanes, d->sym, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out);
+            if (gain != 1.0f) launch_scale(s, gain, d_out, d_out, g.count);
+        } else if (d->lanes == 8 &&
             launch_fir_real8_fast(s, g, d->sym, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out, gain, gain != 1.0f)) {
             // LDS-tiled kernel took it (gain fused)
         } else if (launch_fir_split(s, g, false, d->lanes, CO_SEQ, d->sym, d->sym ? d->d_taps : d->d_plain,
@@ -305,11 +317,16 @@ int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in
     t.ntaps_plain = r->ntaps;
     t.force_seq = 0;
     for (int q = 0; q < r->num_groups; q++) t.fo[q] = r->offsets[q];
+    // as in fir_run: one launch instead of up to four (lead-in, tiles, tail, seams) for a single host block
+    // (configs[3]'s 65536-float blocks: 34 -> 22 us per push)
+    const int small_generic_r = g_small_launch.load(std::memory_order_relaxed);
     if (r->cplx) {
         if (launch_resample3c_fast(s, g, r->corder, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
             // specialised complex 3-group kernel took it
         } else if (!launch_resample_split(s, g, true, r->lanes, r->corder, t, r->d_groups, r->d_plain, d_in, d_out))
             launch_resample_cplx(s, g, r->corder, t, r->d_groups, r->d_plain, d_in, d_out);
+    } else if (g.seamBI > 0 && g.count <= small_generic_r) {
+        launch_resample_real(s, g, r->lanes, t, r->d_groups, r->d_plain, d_in, d_out);
     } else if (r->lanes == 8 && launch_resample_3_10_fast(s, g, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
         // specialised 3-group kernel took it
     } else if (launch_resample_split(s, g, false, r->lanes, r->corder, t, r->d_groups, r->d_plain, d_in, d_out)) {
@@ -324,6 +341,11 @@ int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in
 using namespace sdrhip;
 
 extern "C" {
+
+int sdrhip_set_small_launch_outputs(int outputs)
+{
+    return g_small_launch.exchange(outputs < 0 ? kSmallSeamedLaunch : outputs);
+}
 
 const char* sdrhip_version(void) { return "sdr_hip 0.1 (gfx950)"; }
 const char* sdrhip_last_error(void) { return get_error(); }

@@ -62,6 +62,8 @@ lib = _load()
 
 # ---- signatures -----------------------------------------------------------------
 lib.sdrhip_version.restype = C.c_char_p
+lib.sdrhip_set_small_launch_outputs.argtypes = [C.c_int]
+lib.sdrhip_set_small_launch_outputs.restype = C.c_int
 lib.sdrhip_last_error.restype = C.c_char_p
 lib.sdrhip_device_name.argtypes = [C.c_char_p, C.c_int]
 lib.sdrhip_malloc.argtypes = [C.POINTER(_vp), C.c_size_t]
@@ -203,6 +205,11 @@ def check(rc, what="sdrhip call"):
     if rc < 0:
         raise SdrHipError(f"{what} failed ({rc}): {lib.sdrhip_last_error().decode()}")
     return rc
+
+
+def set_small_launch_outputs(outputs):
+    """sdrhip_set_small_launch_outputs: returns the previous threshold."""
+    return lib.sdrhip_set_small_launch_outputs(int(outputs))
 
 
 def version():

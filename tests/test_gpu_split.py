@@ -43,6 +43,15 @@ _PARTIALS = {(PM.ORDER_AVX, False): 8, (PM.ORDER_SSE, False): 4,      # real: 8 
              (PM.ORDER_AVX, True): 4, (PM.ORDER_SSE, True): 2}        # complex RC: 4 / 2 complex lanes (decimate.c:84-113)
 
 
+@pytest.fixture(autouse=True)
+def _tiled_route(hip):
+    """These tests are about the tiled kernels: switch off the one-launch route that short seamed launches of the real
+    filters / resamplers take by default (sdrhip_set_small_launch_outputs; tests/test_gpu_stream.py runs both routes)."""
+    prev = hip.set_small_launch_outputs(0)
+    yield
+    hip.set_small_launch_outputs(prev)
+
+
 def _fits(taps_walked, order, complex_, resampler=False):
     """The tiled kernel keeps one tap per partial-sum chunk in registers: at most 64 chunks."""
     m = _PARTIALS[(order, complex_)]

@@ -63,8 +63,17 @@ def test_decimator_lone_block_is_all_one(hip, oracle):
     assert_bit_equal(got, oracle.decimate_rc(4, 1009, 8, np.repeat(h, 2), x), "lone block")
 
 
+@pytest.fixture(params=["one launch for short seamed launches", "tiled kernels + seam launch"])
+def launch_route(hip, request):
+    """Short seamed launches of the real filter / resampler take the one-launch generic kernel by default
+    (sdrhip_set_small_launch_outputs); the tests that feed them run under both routes."""
+    prev = hip.set_small_launch_outputs(-1 if request.param.startswith("one") else 0)
+    yield request.param
+    hip.set_small_launch_outputs(prev)
+
+
 @pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE])
-def test_filter_sym_stream(hip, oracle, order):
+def test_filter_sym_stream(hip, oracle, order, launch_route):
     x = S.real_block(4 * B)
     half = S.taps_audio_half64()
     model = PM.FilterModel(oracle, half, order, sym=True)
@@ -78,7 +87,7 @@ def test_filter_sym_stream(hip, oracle, order):
 
 @pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE, PM.ORDER_SCALAR])
 @pytest.mark.parametrize("complex_", [False, True])
-def test_filter_decimator_generic_stream(hip, oracle, order, complex_):
+def test_filter_decimator_generic_stream(hip, oracle, order, complex_, launch_route):
     w = 2 if complex_ else 1
     x = S.cfloat_block(3 * 4096) if complex_ else S.real_block(3 * 4096)
     taps = S.gauss_taps(77, 3)
@@ -93,7 +102,7 @@ def test_filter_decimator_generic_stream(hip, oracle, order, complex_):
 
 @pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE, PM.ORDER_SCALAR])
 @pytest.mark.parametrize("complex_", [False, True])
-def test_resampler_stream(hip, oracle, order, complex_):
+def test_resampler_stream(hip, oracle, order, complex_, launch_route):
     w = 2 if complex_ else 1
     x = S.cfloat_block(4 * B) if complex_ else S.real_block(4 * B)
     taps = S.taps_resamp191()
@@ -112,7 +121,7 @@ def test_resampler_stream(hip, oracle, order, complex_):
 
 
 @pytest.mark.parametrize("I,D", [(2, 3), (5, 7), (7, 11), (3, 23)])
-def test_resampler_other_ratios(hip, oracle, I, D):
+def test_resampler_other_ratios(hip, oracle, I, D, launch_route):
     x = S.real_block(3 * 4096)
     taps = S.gauss_taps(150, I + D)
     model = PM.ResamplerModel(oracle, I, D, taps, PM.ORDER_AVX)
