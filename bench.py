@@ -126,9 +126,14 @@ def cpu_baseline(seconds_single=6.0, seconds_all=8.0):
 
 
 # --------------------------------------------------------------------------------------
-def _sha256(path):
+def k2_source_sha256():
+    """Digest of the dominant kernel's sources (the tile kernel + its launcher): profiles/k2_traffic.json is only quoted
+    while it was measured on this version of them (tools/summarize_profile.py writes the same digest)."""
     import hashlib
-    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+    h = hashlib.sha256()
+    for name in ("decimate_tile.hpp", "kernels_fast.hip"):
+        h.update(open(os.path.join(ROOT, "sdr_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
 
 
 def main():
@@ -504,9 +509,9 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                now = _sha256(os.path.join(ROOT, "sdr_amd", "csrc", "kernels_fast.hip"))
+                now = k2_source_sha256()
                 if tj.get("kernels_fast_sha256") != now:
-                    traffic_note = "profiles/k2_traffic.json was measured on another version of kernels_fast.hip: re-run tools/profile_bench.sh"
+                    traffic_note = "profiles/k2_traffic.json was measured on another version of decimate_tile.hpp / kernels_fast.hip: re-run tools/profile_bench.sh"
                 elif tj.get("samples_per_launch") != plan.k2_samples:
                     traffic_note = "profiles/k2_traffic.json was measured at another launch size"
                 else:

@@ -66,10 +66,11 @@ k2 = next(k for k in ours if k.startswith("k_decimate_c4<"))
 fetch_kib = ours[k2].get("FETCH_SIZE", float("nan"))
 write_kib = ours[k2].get("WRITE_SIZE", float("nan"))
 samples = bench["roofline"]["algorithmic_bytes_per_launch"] / 3.0
-import hashlib
+sys.path.insert(0, ROOT)
+from bench import k2_source_sha256
 traffic = {
     "kernel": k2,
-    "kernels_fast_sha256": hashlib.sha256(open(os.path.join(ROOT, "sdr_amd", "csrc", "kernels_fast.hip"), "rb").read()).hexdigest(),
+    "kernels_fast_sha256": k2_source_sha256(),      # decimate_tile.hpp + kernels_fast.hip
     "samples_per_launch": int(round(samples)),
     "FETCH_SIZE_KiB_raw": fetch_kib,
     "WRITE_SIZE_KiB_raw": write_kib,
@@ -88,7 +89,8 @@ json.dump(bench, open(os.path.join(dst, f"{tag}_bench_unprofiled.json"), "w"), i
 try:
     c_f = pmc("pmc_fetch_k2c")
     c_w = pmc("pmc_write_k2c")
-    kc = next(k for k in c_f if k.startswith("k_decimate_c4<") and k.rstrip(">").endswith("false"))
+    # template arguments <D, P, R, NT, U8, TC, GUARD, NP, ORD>: the cfloat-in instantiation has U8 = false
+    kc = next(k for k in c_f if k.startswith("k_decimate_c4<") and k[k.index("<") + 1:].split(",")[4].strip() == "false")
     n_c = 1 << 27
     fk, wk = c_f[kc].get("FETCH_SIZE", float("nan")), c_w[kc].get("WRITE_SIZE", float("nan"))
     json.dump({"kernel": kc, "samples_per_launch": n_c, "FETCH_SIZE_KiB_raw": fk, "WRITE_SIZE_KiB_raw": wk,
