@@ -7,9 +7,12 @@
 // Haskell program that resolves its `foreign import ccall` against this library
 // produces the same bits whichever variant SDR.CPUID.featureSelect picks.
 //
-// A process-wide scratch context (device in/out/tap buffers + one HIP stream)
-// is guarded by a mutex: the reference calls these from a single pipeline thread,
-// but nothing stops another caller.
+// Every call leases a scratch context (one HIP stream, pinned staging, device buffers, the taps it uploaded last) from
+// a per-device pool, so concurrent pipeline threads run side by side instead of queueing on one mutex and one stream.
+// Calls that move at most kDirectBytes each way -- the reference's own block sizes (8192 samples, fm.hs:17) -- run in
+// place: the input is copied into pinned memory by the host, the kernel reads it and writes the pinned result over PCIe,
+// nothing goes through the copy engines (a pageable hipMemcpyAsync pair costs more than such a kernel).  Larger calls use
+// hipMemcpyAsync from / to the caller's buffers.  Taps are re-uploaded only when their bytes differ from the last call's.
 #include <string.h>
 
 #include <mutex>
@@ -21,21 +24,56 @@ using namespace sdrhip;
 
 namespace {
 
-struct Scratch {
-    std::mutex mu;
+constexpr size_t kDirectBytes = 512 << 10;
+
+struct Ctx {
+    int device = 0;
     hipStream_t stream = nullptr;
-    DevBuf in, out, taps, taps2;
-    hipStream_t s()
+    PinBuf hin, hout;
+    DevBuf in, out, taps, taps2, work;
+    std::vector<unsigned char> taps_now, taps2_now;   // the bytes taps / taps2 hold
+};
+
+struct Pool {
+    std::mutex mu;
+    std::vector<Ctx*> idle;
+    Ctx* acquire()
     {
-        if (!stream) SDRHIP_DIE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        return stream;
+        int dev = 0;
+        SDRHIP_DIE_HIP(hipGetDevice(&dev));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < idle.size(); i++)
+                if (idle[i]->device == dev) {
+                    Ctx* c = idle[i];
+                    idle[i] = idle.back();
+                    idle.pop_back();
+                    return c;
+                }
+        }
+        Ctx* c = new Ctx();   // contexts live as long as the process: no destructor-order games at exit
+        c->device = dev;
+        SDRHIP_DIE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        return c;
+    }
+    void release(Ctx* c)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        idle.push_back(c);
     }
 };
-Scratch& scratch()
+Pool& pool()
 {
-    static Scratch* sc = new Scratch();  // intentionally leaked: no destructor-order games at exit
-    return *sc;
+    static Pool* p = new Pool();
+    return *p;
 }
+struct Lease {
+    Ctx* c;
+    Lease() : c(pool().acquire()) {}
+    ~Lease() { pool().release(c); }
+    Lease(const Lease&) = delete;
+    Lease& operator=(const Lease&) = delete;
+};
 
 void die_if(int rc, const char* what)
 {
@@ -45,15 +83,49 @@ void die_if(int rc, const char* what)
     }
 }
 
-void up(Scratch& sc, DevBuf& b, const void* h, size_t bytes)
+bool fits_direct(size_t in_bytes, size_t out_bytes) { return in_bytes <= kDirectBytes && out_bytes <= kDirectBytes; }
+
+// device-visible copy of the caller's input
+const void* stage_in(Ctx& c, bool direct, const void* h, size_t bytes)
 {
-    die_if(b.ensure(bytes), "device buffer");
-    if (bytes) SDRHIP_DIE_HIP(hipMemcpyAsync(b.p, h, bytes, hipMemcpyHostToDevice, sc.s()));
+    if (direct) {
+        die_if(c.hin.ensure(bytes + 64), "pinned buffer");
+        if (bytes) memcpy(c.hin.p, h, bytes);
+        return c.hin.dev;
+    }
+    die_if(c.in.ensure(bytes + 64), "device buffer");
+    if (bytes) SDRHIP_DIE_HIP(hipMemcpyAsync(c.in.p, h, bytes, hipMemcpyHostToDevice, c.stream));
+    return c.in.p;
 }
-void down(Scratch& sc, void* h, const DevBuf& b, size_t bytes)
+void* stage_out(Ctx& c, bool direct, size_t bytes)
 {
-    if (bytes) SDRHIP_DIE_HIP(hipMemcpyAsync(h, b.p, bytes, hipMemcpyDeviceToHost, sc.s()));
-    SDRHIP_DIE_HIP(hipStreamSynchronize(sc.s()));
+    if (direct) {
+        die_if(c.hout.ensure(bytes + 64), "pinned buffer");
+        return c.hout.dev;
+    }
+    die_if(c.out.ensure(bytes + 64), "device buffer");
+    return c.out.p;
+}
+void finish(Ctx& c, bool direct, void* h, size_t bytes)
+{
+    SDRHIP_DIE_HIP(hipGetLastError());
+    if (direct) {
+        SDRHIP_DIE_HIP(hipStreamSynchronize(c.stream));
+        if (bytes) memcpy(h, c.hout.p, bytes);
+        return;
+    }
+    if (bytes) SDRHIP_DIE_HIP(hipMemcpyAsync(h, c.out.p, bytes, hipMemcpyDeviceToHost, c.stream));
+    SDRHIP_DIE_HIP(hipStreamSynchronize(c.stream));
+}
+// the taps on the device; uploaded only when they differ from what the buffer holds
+const float* taps_on_device(Ctx& c, DevBuf& b, std::vector<unsigned char>& now, const void* h, size_t bytes)
+{
+    if (b.p != nullptr && now.size() == bytes && (bytes == 0 || memcmp(now.data(), h, bytes) == 0)) return (const float*)b.p;
+    die_if(b.ensure(bytes + 64), "device buffer");
+    now.assign((const unsigned char*)h, (const unsigned char*)h + bytes);
+    // `now` outlives the call, so the copy may still be in flight when this returns; every entry point ends on a sync
+    if (bytes) SDRHIP_DIE_HIP(hipMemcpyAsync(b.p, now.data(), bytes, hipMemcpyHostToDevice, c.stream));
+    return (const float*)b.p;
 }
 
 Geom flat_geom(int num, int D, int Lp)
@@ -73,34 +145,33 @@ Geom flat_geom(int num, int D, int Lp)
 void fir_real(int lanes, bool sym, int num, int factor, int numCoeffs, float* coeffs, float* in, float* out)
 {
     if (num <= 0) return;
-    Scratch& sc = scratch();
-    std::lock_guard<std::mutex> lk(sc.mu);
+    Lease l;
+    Ctx& c = *l.c;
     int span = sym ? 2 * numCoeffs : numCoeffs;
     size_t nin = (size_t)(num - 1) * factor + span;
-    up(sc, sc.taps, coeffs, (size_t)numCoeffs * 4);
-    up(sc, sc.in, in, nin * 4);
-    die_if(sc.out.ensure((size_t)num * 4), "device buffer");
-    launch_fir_real(sc.s(), flat_geom(num, factor, span), lanes, sym, (const float*)sc.taps.p, numCoeffs, nullptr,
-                    (const float*)sc.in.p, (float*)sc.out.p);
-    SDRHIP_DIE_HIP(hipGetLastError());
-    down(sc, out, sc.out, (size_t)num * 4);
+    const bool direct = fits_direct(nin * 4, (size_t)num * 4);
+    const float* d_taps = taps_on_device(c, c.taps, c.taps_now, coeffs, (size_t)numCoeffs * 4);
+    const float* d_in = (const float*)stage_in(c, direct, in, nin * 4);
+    float* d_out = (float*)stage_out(c, direct, (size_t)num * 4);
+    launch_fir_real(c.stream, flat_geom(num, factor, span), lanes, sym, d_taps, numCoeffs, nullptr, d_in, d_out);
+    finish(c, direct, out, (size_t)num * 4);
 }
 
 // real taps, complex data.  numCoeffs is the length of the array as passed.
 void fir_cplx(ComplexOrder order, bool sym, int num, int factor, int numCoeffs, float* coeffs, float* in, float* out)
 {
     if (num <= 0) return;
-    Scratch& sc = scratch();
-    std::lock_guard<std::mutex> lk(sc.mu);
+    Lease l;
+    Ctx& c = *l.c;
     int P = (order == CO_L2 || order == CO_L4) ? numCoeffs / 2 : numCoeffs;  // complex taps walked
     int span = sym ? 2 * P : P;
     size_t nin = (size_t)(num - 1) * factor + span;
-    up(sc, sc.taps, coeffs, (size_t)numCoeffs * 4);
-    up(sc, sc.in, in, nin * 8);
-    die_if(sc.out.ensure((size_t)num * 8), "device buffer");
+    const bool direct = fits_direct(nin * 8, (size_t)num * 8);
+    const float* d_in = (const float*)stage_in(c, direct, in, nin * 8);
+    float* d_out = (float*)stage_out(c, direct, (size_t)num * 8);
     Geom g = flat_geom(num, factor, span);
     bool done = false;
-    std::vector<float> plain;  // must outlive the stream sync in down()
+    std::vector<float> plain;
     if (order == CO_L4 && !sym) {
         // the LDS-tiled kernel wants plain taps; only valid when the array really is a duplicate
         bool dup = true;
@@ -108,16 +179,15 @@ void fir_cplx(ComplexOrder order, bool sym, int num, int factor, int numCoeffs, 
         if (dup) {
             plain.resize(P);
             for (int i = 0; i < P; i++) plain[i] = coeffs[2 * i];
-            up(sc, sc.taps2, plain.data(), (size_t)P * 4);
-            done = launch_decimate_c4_fast(sc.s(), g, (const float*)sc.taps2.p, P, nullptr, sc.in.p, false,
-                                           (float*)sc.out.p);
+            const float* d_plain = taps_on_device(c, c.taps2, c.taps2_now, plain.data(), (size_t)P * 4);
+            done = launch_decimate_c4_fast(c.stream, g, d_plain, P, nullptr, d_in, false, d_out);
         }
     }
-    if (!done)
-        launch_fir_cplx(sc.s(), g, order, sym, (const float*)sc.taps.p, numCoeffs, nullptr, (const float*)sc.in.p,
-                        (float*)sc.out.p);
-    SDRHIP_DIE_HIP(hipGetLastError());
-    down(sc, out, sc.out, (size_t)num * 8);
+    if (!done) {
+        const float* d_taps = taps_on_device(c, c.taps, c.taps_now, coeffs, (size_t)numCoeffs * 4);
+        launch_fir_cplx(c.stream, g, order, sym, d_taps, numCoeffs, nullptr, d_in, d_out);
+    }
+    finish(c, direct, out, (size_t)num * 8);
 }
 
 // polyphase resamplers (resample.c:34-142)
@@ -130,8 +200,8 @@ int resample_groups(bool cplx, int lanes_or_order, int buf_size, int num_coeffs,
     }
     int end_group = (int)(((int64_t)starting_group + (buf_size > 0 ? buf_size : 0)) % num_groups);
     if (buf_size <= 0) return starting_group;
-    Scratch& sc = scratch();
-    std::lock_guard<std::mutex> lk(sc.mu);
+    Lease l;
+    Ctx& c = *l.c;
     int simd;
     ComplexOrder co = CO_SEQ;
     if (cplx) {
@@ -161,27 +231,27 @@ int resample_groups(bool cplx, int lanes_or_order, int buf_size, int num_coeffs,
     int64_t last = buf_size - 1;
     size_t nin = (size_t)((last / num_groups) * (int64_t)t.period + t.pre[last % num_groups] + nloop);
     size_t esz = cplx ? 8 : 4;
-    up(sc, sc.taps, table.data(), table.size() * 4);
-    up(sc, sc.in, in, nin * esz);
-    die_if(sc.out.ensure((size_t)buf_size * esz), "device buffer");
+    const bool direct = fits_direct(nin * esz, (size_t)buf_size * esz);
+    const float* d_taps = taps_on_device(c, c.taps, c.taps_now, table.data(), table.size() * 4);
+    const float* d_in = (const float*)stage_in(c, direct, in, nin * esz);
+    float* d_out = (float*)stage_out(c, direct, (size_t)buf_size * esz);
     Geom g = flat_geom(buf_size, 1, 0);
-    if (cplx) launch_resample_cplx(sc.s(), g, co, t, (const float*)sc.taps.p, nullptr, (const float*)sc.in.p, (float*)sc.out.p);
-    else launch_resample_real(sc.s(), g, simd, t, (const float*)sc.taps.p, nullptr, (const float*)sc.in.p, (float*)sc.out.p);
-    SDRHIP_DIE_HIP(hipGetLastError());
-    down(sc, out, sc.out, (size_t)buf_size * esz);
+    if (cplx) launch_resample_cplx(c.stream, g, co, t, d_taps, nullptr, d_in, d_out);
+    else launch_resample_real(c.stream, g, simd, t, d_taps, nullptr, d_in, d_out);
+    finish(c, direct, out, (size_t)buf_size * esz);
     return end_group;
 }
 
 template <class Fn>
 void elementwise(const void* in, size_t in_bytes, void* out, size_t out_bytes, Fn launch)
 {
-    Scratch& sc = scratch();
-    std::lock_guard<std::mutex> lk(sc.mu);
-    up(sc, sc.in, in, in_bytes);
-    die_if(sc.out.ensure(out_bytes), "device buffer");
-    launch(sc.s(), sc.in.p, sc.out.p);
-    SDRHIP_DIE_HIP(hipGetLastError());
-    down(sc, out, sc.out, out_bytes);
+    Lease l;
+    Ctx& c = *l.c;
+    const bool direct = fits_direct(in_bytes, out_bytes);
+    const void* d_in = stage_in(c, direct, in, in_bytes);
+    void* d_out = stage_out(c, direct, out_bytes);
+    launch(c.stream, d_in, d_out);
+    finish(c, direct, out, out_bytes);
 }
 
 }  // namespace
@@ -195,7 +265,7 @@ void convertC(int num, uint8_t* in, float* out)
 {
     if (num <= 0) return;
     elementwise(in, (size_t)num, out, (size_t)num * 4,
-                [&](hipStream_t s, void* di, void* dout) { launch_convert_u8(s, (const uint8_t*)di, (float*)dout, num); });
+                [&](hipStream_t s, const void* di, void* dout) { launch_convert_u8(s, (const uint8_t*)di, (float*)dout, num); });
 }
 void convertCSSE(int num, uint8_t* in, float* out) { convertC(num, in, out); }
 void convertCAVX(int num, uint8_t* in, float* out) { convertC(num, in, out); }
@@ -204,14 +274,14 @@ void convertCBladeRF(int num, int16_t* in, float* out)
 {
     if (num <= 0) return;
     elementwise(in, (size_t)num * 2, out, (size_t)num * 4,
-                [&](hipStream_t s, void* di, void* dout) { launch_convert_i16(s, (const int16_t*)di, (float*)dout, num); });
+                [&](hipStream_t s, const void* di, void* dout) { launch_convert_i16(s, (const int16_t*)di, (float*)dout, num); });
 }
 void convertCSSEBladeRF(int num, int16_t* in, float* out) { convertCBladeRF(num, in, out); }
 void convertCAVXBladeRF(int num, int16_t* in, float* out) { convertCBladeRF(num, in, out); }
 void convertBladeRFTransmit(int num, float* in, int16_t* out)
 {
     if (num <= 0) return;
-    elementwise(in, (size_t)num * 4, out, (size_t)num * 2, [&](hipStream_t s, void* di, void* dout) {
+    elementwise(in, (size_t)num * 4, out, (size_t)num * 2, [&](hipStream_t s, const void* di, void* dout) {
         launch_convert_f32_to_i16_bladerf(s, (const float*)di, (int16_t*)dout, num);
     });
 }
@@ -221,7 +291,7 @@ void scale(int num, float factor, float* in_buf, float* out_buf)
 {
     if (num <= 0) return;
     elementwise(in_buf, (size_t)num * 4, out_buf, (size_t)num * 4,
-                [&](hipStream_t s, void* di, void* dout) { launch_scale(s, factor, (const float*)di, (float*)dout, num); });
+                [&](hipStream_t s, const void* di, void* dout) { launch_scale(s, factor, (const float*)di, (float*)dout, num); });
 }
 void scaleSSE(int num, float factor, float* in_buf, float* out_buf) { scale(num, factor, in_buf, out_buf); }
 void scaleAVX(int num, float factor, float* in_buf, float* out_buf) { scale(num, factor, in_buf, out_buf); }
@@ -248,18 +318,25 @@ void dcBlocker(int num, float lastSample, float lastOutput, float* finalSample, 
         *finalOutput = lastOutput;
         return;
     }
-    Scratch& sc = scratch();
-    std::lock_guard<std::mutex> lk(sc.mu);
-    up(sc, sc.in, inBuf, (size_t)num * 4);
-    die_if(sc.out.ensure((size_t)num * 4 + 16), "device buffer");
-    die_if(sc.taps2.ensure(dc_blocker_workspace_bytes(num)), "device buffer");
-    float* dout = (float*)sc.out.p;   // {finalSample, finalOutput, -, -} then the block, 16-byte aligned
-    launch_dc_blocker(sc.s(), num, lastSample, lastOutput, (const float*)sc.in.p, dout + 4, dout, sc.taps2.p, 0);
+    Lease l;
+    Ctx& c = *l.c;
+    const size_t ob = (size_t)num * 4 + 16;   // {finalSample, finalOutput, -, -} then the block, 16-byte aligned
+    const bool direct = fits_direct((size_t)num * 4, ob);
+    const float* d_in = (const float*)stage_in(c, direct, inBuf, (size_t)num * 4);
+    float* dout = (float*)stage_out(c, direct, ob);
+    die_if(c.work.ensure(dc_blocker_workspace_bytes(num)), "device buffer");
+    launch_dc_blocker(c.stream, num, lastSample, lastOutput, d_in, dout + 4, dout, c.work.p, 0);
     SDRHIP_DIE_HIP(hipGetLastError());
     float fin[2];
-    SDRHIP_DIE_HIP(hipMemcpyAsync(fin, dout, 8, hipMemcpyDeviceToHost, sc.s()));
-    SDRHIP_DIE_HIP(hipMemcpyAsync(outBuf, dout + 4, (size_t)num * 4, hipMemcpyDeviceToHost, sc.s()));
-    SDRHIP_DIE_HIP(hipStreamSynchronize(sc.s()));
+    if (direct) {
+        SDRHIP_DIE_HIP(hipStreamSynchronize(c.stream));
+        memcpy(fin, c.hout.p, 8);
+        memcpy(outBuf, (const float*)c.hout.p + 4, (size_t)num * 4);
+    } else {
+        SDRHIP_DIE_HIP(hipMemcpyAsync(fin, dout, 8, hipMemcpyDeviceToHost, c.stream));
+        SDRHIP_DIE_HIP(hipMemcpyAsync(outBuf, dout + 4, (size_t)num * 4, hipMemcpyDeviceToHost, c.stream));
+        SDRHIP_DIE_HIP(hipStreamSynchronize(c.stream));
+    }
     *finalSample = fin[0];
     *finalOutput = fin[1];
 }
@@ -289,8 +366,8 @@ void resampleRR(int buf_size, int coeff_size, int interpolation, int decimation,
         fprintf(stderr, "libsdr_hip: resampleRR: need 1 <= interpolation <= 64 < decimation\n");
         abort();
     }
-    Scratch& sc = scratch();
-    std::lock_guard<std::mutex> lk(sc.mu);
+    Lease l;
+    Ctx& c = *l.c;
     ResampTable t;
     // walk the recurrence from filter_offset until it repeats
     int off = filter_offset, ng = 0, acc = 0;
@@ -312,14 +389,14 @@ void resampleRR(int buf_size, int coeff_size, int interpolation, int decimation,
     int64_t last = buf_size - 1;
     int maxlen = (coeff_size + interpolation - 1) / interpolation;
     size_t nin = (size_t)((last / ng) * (int64_t)t.period + t.pre[last % ng] + maxlen);
-    up(sc, sc.taps, coeffs, (size_t)coeff_size * 4);
-    up(sc, sc.in, in_buf, nin * 4);
-    die_if(sc.out.ensure((size_t)buf_size * 4), "device buffer");
+    const bool direct = fits_direct(nin * 4, (size_t)buf_size * 4);
+    const float* d_taps = taps_on_device(c, c.taps, c.taps_now, coeffs, (size_t)coeff_size * 4);
+    const float* d_in = (const float*)stage_in(c, direct, in_buf, nin * 4);
+    float* d_out = (float*)stage_out(c, direct, (size_t)buf_size * 4);
     Geom g = flat_geom(buf_size, decimation, 0);
     g.I = interpolation;
-    launch_resample_real(sc.s(), g, 1, t, nullptr, (const float*)sc.taps.p, (const float*)sc.in.p, (float*)sc.out.p);
-    SDRHIP_DIE_HIP(hipGetLastError());
-    down(sc, out_buf, sc.out, (size_t)buf_size * 4);
+    launch_resample_real(c.stream, g, 1, t, nullptr, d_taps, d_in, d_out);
+    finish(c, direct, out_buf, (size_t)buf_size * 4);
 }
 
 int resample2RR(int n, int nc, int sg, int ng, int* inc, float** c, float* in, float* out) { return resample_groups(false, 1, n, nc, sg, ng, inc, c, in, out); }
@@ -333,7 +410,7 @@ int resampleAVXRC(int n, int nc, int sg, int ng, int* inc, float** c, float* in,
 void fmDemodF(int num, float last_re, float last_im, const float* in_iq, float* out)
 {
     if (num <= 0) return;
-    elementwise(in_iq, (size_t)num * 8, out, (size_t)num * 4, [&](hipStream_t s, void* di, void* dout) {
+    elementwise(in_iq, (size_t)num * 8, out, (size_t)num * 4, [&](hipStream_t s, const void* di, void* dout) {
         launch_fm_demod_fast(s, (const float*)di, (float*)dout, num, false, last_re, last_im);
     });
 }

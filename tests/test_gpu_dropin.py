@@ -279,3 +279,36 @@ def test_dropin_random_sweep_against_the_reference_build(hip, oracle, ref):
             assert_bit_equal(got, exp, f"trial {trial}: {symbol} {I}/{D} taps={ntaps} num={num} g0={g0}")
         done += 1
     assert done == 120 * SWEEP_SCALE
+
+
+def test_dropin_calls_from_several_threads(hip, oracle):
+    """Each call leases its own scratch context (stream, staging, tap cache: abi_dropin.cpp), so pipeline threads do not
+    share state: four threads hammer different symbols with different taps at once and every result is still exact."""
+    import threading
+    x = S.cfloat_block(8192)
+    xr = S.real_block(8192)
+    jobs = []
+    for t in range(4):
+        taps = S.gauss_taps(64 + 16 * t, 40 + t)
+        hd = duplicate(taps)
+        num_c = (8192 - taps.size) // 8 + 1
+        num_r = 8192 - taps.size + 1
+        jobs.append((("decimateAVXRC", num_c, 8, hd, x, True), oracle.decimate_rc(4, num_c, 8, hd, x),
+                     ("filterAVXRR", num_r, taps, xr), oracle.filter_rr(8, num_r, taps, xr)))
+    errors = []
+
+    def work(job):
+        dargs, dexp, fargs, fexp = job
+        try:
+            for _ in range(25):
+                assert_bit_equal(hip.DropIn.decim(*dargs), dexp, "decimateAVXRC from a thread")
+                assert_bit_equal(hip.DropIn.filt(*fargs), fexp, "filterAVXRR from a thread")
+        except Exception as e:          # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[0]
