@@ -396,7 +396,7 @@ int main(int argc, char** argv)
     auto k0 = k_decimate_c4<D, P, R, NT, false>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES));
     const int grid0 = ((ntiles + 63) / 64) * 64;
-    auto run0 = [&](float* o) { hipLaunchKernelGGL(k0, dim3(grid0), dim3(NT), T::LDS_BYTES, 0, (const void*)dx, (int64_t)0, (int)nout, dt, o, P); };
+    auto run0 = [&](float* o) { hipLaunchKernelGGL(k0, dim3(grid0), dim3(NT), T::LDS_BYTES, 0, (const void*)dx, (int64_t)0, (int)nout, dt, o, P, 0, 0); };
     run0(dref);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(href.data(), dref, (size_t)nout * 8, hipMemcpyDeviceToHost));
