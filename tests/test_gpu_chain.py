@@ -386,16 +386,16 @@ def test_chain_run_as_hipgraph(hip, oracle):
 
 
 def test_fm_stream_crosses_the_in_place_threshold(hip, oracle):
-    """sdrhip_fm_stream: pushes of 1 block (in place, fused tail), 7 blocks (in place: 61k samples with the tail), 8 and 16
-    blocks (copy engines, stage kernels) in one stream, against one device-resident run."""
-    pattern = [1, 1, 7, 16, 1, 8, 1, 1, 16, 7, 1, 2, 8, 1]
+    """sdrhip_fm_stream: pushes of 1 block (in place, fused tail), 7, 16 and 32 blocks (in place, stage kernels: the limit is
+    33 blocks including the carried tail), 33 and 40 blocks (copy engines) in one stream, against one device-resident run."""
+    pattern = [1, 1, 7, 33, 1, 16, 1, 32, 40, 7, 1, 2, 33, 1]
     nblk = sum(pattern) * 3
     total = nblk * B
     u8 = S.iq_u8_fm(total)
     chain = _chain(hip)
     _, q1, _ = chain.plan(0, total, total)
     full = _run(hip, chain, to_dev(u8), 0, total, 0, q1)
-    st = hip.FmStream(chain, 16 * B, B)
+    st = hip.FmStream(chain, 40 * B, B)
     got, pos = [], 0
     for rep in range(3):
         for k, n in enumerate(pattern):
