@@ -275,24 +275,47 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
         // inside its buffer (one 64-bit modulo per workgroup); a tile spans less than one buffer (the launcher checks).
         const int plen = GUARD ? p_eff : P;
         const int rt = (int)(((int64_t)inl_r0 + s0) % inl_seam);
+        bool cross[R];
+        bool any = false;
 #pragma unroll
         for (int r = 0; r < R; r++) {
             int rr = rt + (threadIdx.x * R + r) * D;
             if (rr >= inl_seam) rr -= inl_seam;
-            if (rr + plen > inl_seam) {
-                // `taps` IS the plain tap array in tap order (for u8 input pre-scaled by 1/128 like the samples in LDS are
-                // un-scaled: the products are the reference's, see Stage::store); the window of output r starts r*D
-                // samples into the thread's
-                float re = 0.0f, im = 0.0f;
-                for (int j = 0; j < plen; j++) {
-                    const int sidx = r * D + j;
-                    const float2 x = win[sidx + 2 * (sidx / T::CHUNK)];
-                    const float h = taps[j];
-                    re = re + x.x * h;
-                    im = im + x.y * h;
+            cross[r] = rr + plen > inl_seam;
+            any |= cross[r];
+        }
+        if (any) {
+            // `taps` IS the plain tap array in tap order (for u8 input pre-scaled by 1/128 like the samples in LDS are
+            // un-scaled: the products are the reference's, see Stage::store); the window of output r starts r*D samples
+            // into the thread's.  All R chains advance together (a thread's outputs usually straddle together), four taps
+            // per step so that the LDS reads and the tap load of a step are in flight at once.
+            float re[R], im[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) re[r] = im[r] = 0.0f;
+#pragma unroll 1
+            for (int j0 = 0; j0 < plen; j0 += 4) {           // plen is a multiple of TC (4 or 8)
+                float2 x[R][4];
+                float h[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    h[u] = taps[j0 + u];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int sidx = r * D + j0 + u;
+                        x[r][u] = win[sidx + 2 * (sidx / T::CHUNK)];
+                    }
                 }
-                res[r] = make_float2(re, im);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        re[r] = re[r] + x[r][u].x * h[u];
+                        im[r] = im[r] + x[r][u].y * h[u];
+                    }
             }
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (cross[r]) res[r] = make_float2(re[r], im[r]);
         }
     }
     if (R % 2 == 0 && o + R <= count) {

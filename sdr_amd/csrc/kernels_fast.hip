@@ -53,7 +53,8 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
     if ((reinterpret_cast<uintptr_t>(d_out) & 15) != 0) return false;
     // Small launches (a host block per push: <= 8 tiles) compute their Cross outputs inside the main kernel: one launch
     // instead of two.  Large launches keep the separate fix-up (a diverging wave per tile costs more than the 4 % it takes).
-    const bool inl = g.seamBI > 0 && g.count <= 8 * 512;
+    static const int64_t inl_max = getenv("SDRHIP_INLINE_CROSS_MAX") ? atoll(getenv("SDRHIP_INLINE_CROSS_MAX")) : 8 * 512;
+    const bool inl = g.seamBI > 0 && g.count <= inl_max;
     bool inlined = false;
     // R = 2 outputs per thread, 256 threads, 4 workgroups per CU.  Alternatives measured on MI355X and dropped:
     // R = 4 (the compiler's SGPR allocation for the sliding tap window collapses into spills), 512-thread
