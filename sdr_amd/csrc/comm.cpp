@@ -47,7 +47,8 @@ Rccl* rccl()
             if (r.handle) break;
         }
         if (!r.handle) {
-            r.why = dlerror() ? dlerror() : "librccl.so.1 not found";
+            const char* e = dlerror();        // one call: it clears the message it returns
+            r.why = e ? e : "librccl.so.1 not found";
             return;
         }
         bool ok = true;
@@ -98,6 +99,7 @@ struct sdrhip_comm {
     int transport = SDRHIP_TRANSPORT_RCCL;
     ncclComm_t nccl = nullptr;
     hipEvent_t ev_head = nullptr;       // peer copy: "this rank's stream has produced its head"
+    hipEvent_t ev_pulled = nullptr;     // peer copy: "this rank has finished reading its RIGHT neighbour's head"
     bool local = false;                 // created by init_local (all ranks in this process)
 };
 
@@ -167,9 +169,20 @@ int sdrhip_comm_init_local(sdrhip_comm** comms, int ndev, const int* devices, in
         cm->transport = transport;
         cm->nccl = nc[i];
         cm->local = true;
+        comms[i] = cm;
         if (transport == SDRHIP_TRANSPORT_PEER_COPY) {
-            (void)hipSetDevice(devs[i]);
-            (void)hipEventCreateWithFlags(&cm->ev_head, hipEventDisableTiming);
+            hipError_t e = hipSetDevice(devs[i]);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_head, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&cm->ev_pulled, hipEventDisableTiming);
+            if (e != hipSuccess) {
+                set_error("sdrhip_comm_init_local: device %d: %s", devs[i], hipGetErrorString(e));
+                for (int k = 0; k <= i; k++) {
+                    sdrhip_comm_destroy(comms[k]);
+                    comms[k] = nullptr;
+                }
+                (void)hipSetDevice(prev);
+                return SDRHIP_ERR_HIP;
+            }
             // direct xGMI access to the right neighbour's memory where the topology offers it (the copy works without)
             const int right = devs[(i + 1) % ndev];
             int can = 0;
@@ -178,7 +191,6 @@ int sdrhip_comm_init_local(sdrhip_comm** comms, int ndev, const int* devices, in
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
             }
         }
-        comms[i] = cm;
     }
     (void)hipSetDevice(prev);
     return SDRHIP_OK;
@@ -189,6 +201,7 @@ void sdrhip_comm_destroy(sdrhip_comm* c)
     if (!c) return;
     if (c->nccl && rccl()->handle) (void)rccl()->CommDestroy(c->nccl);
     if (c->ev_head) (void)hipEventDestroy(c->ev_head);
+    if (c->ev_pulled) (void)hipEventDestroy(c->ev_pulled);
     delete c;
 }
 
@@ -247,7 +260,8 @@ int sdrhip_halo_exchange_all(sdrhip_comm* const* comms, int ndev, void* const* s
         return SDRHIP_OK;
     }
     // peer copy: every rank first marks "my head is final" on its own stream, then each rank's stream waits for its RIGHT
-    // neighbour's mark and pulls the head across
+    // neighbour's mark and pulls the head across; the neighbour's stream in turn waits for that pull before anything queued
+    // after this call may overwrite the head (with RCCL the send sits on the owner's own stream and orders itself)
     int prev = 0;
     SDRHIP_CHECK_HIP(hipGetDevice(&prev));
     for (int i = 0; i < ndev; i++) {
@@ -260,6 +274,13 @@ int sdrhip_halo_exchange_all(sdrhip_comm* const* comms, int ndev, void* const* s
         SDRHIP_CHECK_HIP(hipStreamWaitEvent((hipStream_t)streams[i], comms[right]->ev_head, 0));
         SDRHIP_CHECK_HIP(hipMemcpyPeerAsync(d_recv[i], comms[i]->device, d_send[right], comms[right]->device, bytes,
                                             (hipStream_t)streams[i]));
+        SDRHIP_CHECK_HIP(hipEventRecord(comms[i]->ev_pulled, (hipStream_t)streams[i]));
+    }
+    for (int i = 0; i < ndev; i++) {
+        const int right = (i + 1) % ndev;
+        if (right == i) continue;
+        SDRHIP_CHECK_HIP(hipSetDevice(comms[right]->device));
+        SDRHIP_CHECK_HIP(hipStreamWaitEvent((hipStream_t)streams[right], comms[i]->ev_pulled, 0));
     }
     SDRHIP_CHECK_HIP(hipSetDevice(prev));
     return SDRHIP_OK;

@@ -37,7 +37,11 @@ HipFft* hipfft()
             f.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (f.handle) break;
         }
-        if (!f.handle) { f.why = dlerror() ? dlerror() : "libhipfft.so.0 not found"; return; }
+        if (!f.handle) {
+            const char* e = dlerror();        // one call: it clears the message it returns
+            f.why = e ? e : "libhipfft.so.0 not found";
+            return;
+        }
         bool ok = true;
 #define SYM(field, name) do { *reinterpret_cast<void**>(&f.field) = dlsym(f.handle, name); if (!f.field) { ok = false; f.why = std::string("missing symbol ") + name; } } while (0)
         SYM(PlanMany, "hipfftPlanMany");
