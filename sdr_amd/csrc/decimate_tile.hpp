@@ -292,12 +292,16 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
             float re[R], im[R];
 #pragma unroll
             for (int r = 0; r < R; r++) re[r] = im[r] = 0.0f;
+#ifndef SDRHIP_INL_STEP
+#define SDRHIP_INL_STEP 4
+#endif
+            constexpr int IS = (TC % SDRHIP_INL_STEP == 0 || SDRHIP_INL_STEP % TC == 0) && (!GUARD || SDRHIP_INL_STEP <= TC) ? SDRHIP_INL_STEP : 4;
 #pragma unroll 1
-            for (int j0 = 0; j0 < plen; j0 += 4) {           // plen is a multiple of TC (4 or 8)
-                float2 x[R][4];
-                float h[4];
+            for (int j0 = 0; j0 < plen; j0 += IS) {           // plen is a multiple of TC (4 or 8)
+                float2 x[R][IS];
+                float h[IS];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < IS; u++) {
                     h[u] = taps[j0 + u];
 #pragma unroll
                     for (int r = 0; r < R; r++) {
@@ -306,7 +310,7 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < IS; u++)
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         re[r] = re[r] + x[r][u].x * h[u];

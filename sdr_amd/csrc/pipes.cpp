@@ -18,7 +18,7 @@
 // stream, kernels(i) on the compute stream (after H2D(i)'s event) and D2H(i) on the download stream (after the kernels'
 // event), and only then harvests slot i-1 -- so the upload of block i and the download of block i-1 overlap the compute
 // between them.  Small submissions (<= kDirectBytes of input) skip both copies: the kernels read the pinned staging buffer
-// and write the pinned result buffer directly over PCIe, which leaves two or three kernel launches and one event per push
+// and write the pinned result buffer directly over PCIe, which leaves one kernel launch (seams decided inside it) and one event per push
 // -- the reference's own block sizes (8192 .. 65536 elements) are launch-bound, not bandwidth-bound.  Results lag by one
 // push; sdrhip_pipe_flush() drains the in-flight slot.
 #include <stdlib.h>
