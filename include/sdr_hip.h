@@ -398,6 +398,15 @@ int sdrhip_fm_stream_flush(sdrhip_fm_stream *st);
  * latency; the audio blocks are the same.  Call with nothing staged. */
 int sdrhip_fm_stream_set_coalesce(sdrhip_fm_stream *st, int samples);
 int sdrhip_fm_stream_pop(sdrhip_fm_stream *st, float *out, int capacity);
+/* Checkpoint / resume.  Between two pushes the operator's state is the stream position, the last ~4k input samples and
+ * the audio not yet popped (the reference keeps the equivalent in Pipe closures: overlap remainder, resampler phase, last
+ * demod sample, output fill level -- Filter.hs:536-727, Demod.hs:21-38); everything else is a closed form of the position.
+ * save: drains the operator (like flush) and writes the state (at most sdrhip_fm_stream_state_bytes, *used = its size);
+ * restore: into a freshly created stream over a chain of the same taps and block sizes; returns the number of audio blocks
+ * ready to pop.  A restored stream fed the remaining samples yields the audio the uninterrupted stream would have. */
+size_t sdrhip_fm_stream_state_bytes(const sdrhip_fm_stream *st);
+int sdrhip_fm_stream_save(sdrhip_fm_stream *st, void *buf, size_t capacity, size_t *used);
+int sdrhip_fm_stream_restore(sdrhip_fm_stream *st, const void *buf, size_t bytes);
 
 /* ---- spectrum path (hs_sources/SDR/FFT.hs:44-168) on hipFFT ---- */
 /* fftw' / fftw (complex-to-complex forward DFT of n Complex Double), fftwReal' / fftwReal (n Double -> n/2+1 bins) and

@@ -729,6 +729,84 @@ int sdrhip_fm_stream_flush(sdrhip_fm_stream* st)
     return st->ready();
 }
 
+// ---- checkpoint / resume ------------------------------------------------------------------------
+// The whole state of the operator between two pushes is small and explicit (the reference keeps it in Pipe
+// closures -- overlap remainder, resampler phase, last demod sample, output fill level): the stream position, the number of
+// audio samples produced, the last head_cap input samples, and the audio not yet popped.  Everything else (resampler group,
+// demod history, seam positions) is a closed form of the position.
+namespace {
+struct StreamStateHeader {
+    uint32_t magic, version;
+    int64_t N, q_done, head_cap, hist_n, pending;   // pending: audio floats in the fifo
+    int32_t block_out, chain_block;
+    int64_t chain_halo;
+};
+constexpr uint32_t kStateMagic = 0x53444d46u;   // "FMDS"
+}  // namespace
+
+size_t sdrhip_fm_stream_state_bytes(const sdrhip_fm_stream* st)
+{
+    if (st == nullptr) return 0;
+    return sizeof(StreamStateHeader) + (size_t)(2 * st->head_cap) + (st->fifo.size() - st->head + (size_t)st->capacity()) * sizeof(float);
+}
+
+int sdrhip_fm_stream_save(sdrhip_fm_stream* st, void* buf, size_t capacity, size_t* used)
+{
+    SDRHIP_REQUIRE(st != nullptr && buf != nullptr && used != nullptr, "sdrhip_fm_stream_save");
+    int rc = sdrhip_fm_stream_flush(st);             // submits what is staged, drains both slots into the fifo
+    if (rc < 0) return rc;
+    StreamStateHeader h;
+    memset(&h, 0, sizeof h);
+    h.magic = kStateMagic;
+    h.version = 1;
+    h.N = st->N;
+    h.q_done = st->q_done;
+    h.head_cap = st->head_cap;
+    h.hist_n = st->hist_n;
+    h.pending = (int64_t)(st->fifo.size() - st->head);
+    h.block_out = st->block_out;
+    h.chain_block = st->c->block;
+    h.chain_halo = sdrhip_fm_chain_max_halo(st->c);
+    const size_t need = sizeof h + (size_t)(2 * h.hist_n) + (size_t)h.pending * sizeof(float);
+    if (capacity < need) {
+        set_error("sdrhip_fm_stream_save: %zu bytes needed, %zu given", need, capacity);
+        return SDRHIP_ERR_ARG;
+    }
+    unsigned char* p = (unsigned char*)buf;
+    memcpy(p, &h, sizeof h);
+    p += sizeof h;
+    memcpy(p, st->hist.data(), (size_t)(2 * h.hist_n));
+    p += 2 * h.hist_n;
+    if (h.pending > 0) memcpy(p, st->fifo.data() + st->head, (size_t)h.pending * sizeof(float));
+    *used = need;
+    return SDRHIP_OK;
+}
+
+int sdrhip_fm_stream_restore(sdrhip_fm_stream* st, const void* buf, size_t bytes)
+{
+    SDRHIP_REQUIRE(st != nullptr && buf != nullptr && bytes >= sizeof(StreamStateHeader), "sdrhip_fm_stream_restore");
+    SDRHIP_REQUIRE(st->N == 0 && st->staged == 0 && st->pushes == 0, "sdrhip_fm_stream_restore: only into a stream that has not been pushed to");
+    StreamStateHeader h;
+    memcpy(&h, buf, sizeof h);
+    SDRHIP_REQUIRE(h.magic == kStateMagic && h.version == 1, "sdrhip_fm_stream_restore: not a stream state");
+    SDRHIP_REQUIRE(h.block_out == st->block_out && h.chain_block == st->c->block && h.head_cap == st->head_cap &&
+                       h.chain_halo == sdrhip_fm_chain_max_halo(st->c),
+                   "sdrhip_fm_stream_restore: the state belongs to a stream of another geometry (chain taps / block sizes)");
+    SDRHIP_REQUIRE(h.hist_n >= 0 && h.hist_n <= h.head_cap && h.pending >= 0 && h.N >= h.hist_n && h.q_done >= 0,
+                   "sdrhip_fm_stream_restore: inconsistent state");
+    SDRHIP_REQUIRE(bytes >= sizeof h + (size_t)(2 * h.hist_n) + (size_t)h.pending * sizeof(float), "sdrhip_fm_stream_restore: truncated state");
+    const unsigned char* p = (const unsigned char*)buf + sizeof h;
+    memcpy(st->hist.data(), p, (size_t)(2 * h.hist_n));
+    p += 2 * h.hist_n;
+    st->hist_n = h.hist_n;
+    st->N = h.N;
+    st->q_done = h.q_done;
+    st->fifo.resize((size_t)h.pending);
+    st->head = 0;
+    if (h.pending > 0) memcpy(st->fifo.data(), p, (size_t)h.pending * sizeof(float));
+    return st->ready();
+}
+
 int sdrhip_fm_stream_pop(sdrhip_fm_stream* st, float* out, int capacity)
 {
     SDRHIP_REQUIRE(st != nullptr && out != nullptr, "sdrhip_fm_stream_pop");

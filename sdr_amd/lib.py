@@ -590,6 +590,22 @@ class FmStream(_Handle):
     def flush(self):
         return self._pop(check(lib.sdrhip_fm_stream_flush(self.h), "sdrhip_fm_stream_flush"))
 
+    def save(self):
+        """sdrhip_fm_stream_save: drains the operator and returns its state as bytes (audio blocks that became ready stay
+        inside the state / the stream: pop them from either)."""
+        lib.sdrhip_fm_stream_state_bytes.restype = C.c_size_t
+        lib.sdrhip_fm_stream_state_bytes.argtypes = [C.c_void_p]
+        cap = lib.sdrhip_fm_stream_state_bytes(self.h)                   # includes room for the audio the drain adds
+        buf = (C.c_ubyte * cap)()
+        used = C.c_size_t()
+        lib.sdrhip_fm_stream_save.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        check(lib.sdrhip_fm_stream_save(self.h, buf, cap, C.byref(used)), "sdrhip_fm_stream_save")
+        return bytes(buf[: used.value])
+
+    def restore(self, state):
+        lib.sdrhip_fm_stream_restore.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        return self._pop(check(lib.sdrhip_fm_stream_restore(self.h, state, len(state)), "sdrhip_fm_stream_restore"))
+
 
 class Pipe(_Handle):
     """firFilter / firDecimator / firResampler / fmDemod on host blocks (Filter.hs:532-727, Demod.hs:40-46)."""

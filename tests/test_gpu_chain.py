@@ -411,3 +411,42 @@ def test_fm_stream_crosses_the_in_place_threshold(hip, oracle):
     got = np.concatenate(got)
     assert got.size == q1 // B * B
     assert_bit_equal(got, full[: got.size], "mixed in-place / copied pushes vs resident")
+
+
+@pytest.mark.parametrize("blocks_per_push", [1, 5])
+def test_fm_stream_save_and_restore(hip, oracle, blocks_per_push):
+    """Checkpoint / resume (sdrhip_fm_stream_save / _restore): a stream saved after some pushes, destroyed, restored into a
+    fresh operator (over a fresh chain object with the same taps) and fed the rest yields the uninterrupted stream's audio."""
+    nblk = 40
+    u8 = S.iq_u8_fm(nblk * B)
+    chain = _chain(hip)
+    whole = hip.FmStream(chain, 8 * B, 2048)
+    exp = []
+    for i in range(0, nblk, blocks_per_push):
+        exp += whole.push(u8[2 * i * B: 2 * (i + blocks_per_push) * B])
+    exp += whole.flush()
+    exp = np.concatenate(exp)
+
+    first = hip.FmStream(chain, 8 * B, 2048)
+    got = []
+    cut = 15 if blocks_per_push == 5 else 17
+    for i in range(0, cut, blocks_per_push):
+        got += first.push(u8[2 * i * B: 2 * (i + blocks_per_push) * B])
+    state = first.save()
+    assert len(state) < 64 * 1024 + 4 * 2048 * 8, "the state is the position, ~4k samples of history and the unpopped audio"
+    del first
+    chain2 = _chain(hip)
+    second = hip.FmStream(chain2, 8 * B, 2048)
+    got += second.restore(state)
+    with pytest.raises(hip.SdrHipError):
+        hip.FmStream(chain2, 8 * B, 2048).restore(state[: 40])       # truncated
+    with pytest.raises(hip.SdrHipError):
+        second.restore(state)                                        # only into a stream that has not been pushed to
+    for i in range(cut, nblk, blocks_per_push):
+        got += second.push(u8[2 * i * B: 2 * (i + blocks_per_push) * B])
+    got += second.flush()
+    got = np.concatenate(got)
+    assert_bit_equal(got, exp, "saved + restored stream vs uninterrupted")
+    other = hip.FmStream(chain2, 8 * B, 4096)
+    with pytest.raises(hip.SdrHipError):
+        other.restore(state)                             # another output block size
