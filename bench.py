@@ -237,7 +237,7 @@ def main():
     def measure(blocks, steps, warmup, passes, ramp_s, timing, graph=False):
         """One configuration: `blocks` 8192-sample blocks per GPU per pass.  Returns the max-over-ranks wall time of
         `steps` steps of `passes` passes each, the per-stage HIP-event times and the plan.  graph: the chain's kernels of
-        one pass replayed from a hipGraph captured once (sdrhip_fm_chain_graph_*): one launch per pass instead of nine."""
+        one pass replayed from a hipGraph captured once (sdrhip_fm_chain_graph_*): one launch per pass instead of one per kernel."""
         S_len = blocks * BLOCK
         plan = sharding.ShardPlan(chain, rank, world, S_len)          # owned outputs + halo for this rank
         gen = torch.Generator(device="cuda").manual_seed(S.SEED_IQ + rank)
@@ -402,7 +402,7 @@ def main():
             shard_1m["hipgraph"] = {"value": round(world * r2["S_len"] * r2["passes"] * st1 / r2["elapsed"] / 1e6, 1),
                                     "us_per_pass": round(r2["elapsed"] / (r2["passes"] * st1) * 1e6, 2),
                                     "what": "the same pass with the chain's kernels replayed from a hipGraph captured once "
-                                            "(sdrhip_fm_chain_graph_*): one launch instead of nine" + ("; the halo exchange stays outside the graph" if world > 1 else "")}
+                                            "(sdrhip_fm_chain_graph_*): one graph launch instead of one launch per kernel" + ("; the halo exchange stays outside the graph" if world > 1 else "")}
         except Exception as e:                          # noqa: BLE001
             shard_1m["hipgraph"] = f"failed: {e!r}"
 

@@ -157,11 +157,12 @@ const char *sdrhip_last_error(void);
 int sdrhip_device_count(void);
 int sdrhip_set_device(int dev);
 int sdrhip_device_name(char *buf, int buflen);
-/* Tuning / test knob.  A seamed launch (seam_block > 0) of a real filter or resampler with at most this many outputs --
- * one host block going through a Pipe -- takes the generic kernel, which decides One / Cross per output in ONE launch;
- * longer launches take the tiled kernels plus a second launch for the seam outputs.  Results are identical either way.
- * Default 32768 (also: environment SDRHIP_SMALL_LAUNCH); 0 = always the tiled kernels; negative = restore the default.
- * Returns the previous value. */
+/* Tuning / test knob: the "short seamed launch" scale v.  A launch with seam_block > 0 that is short enough to be
+ * launch-bound decides its One / Cross outputs inside ONE kernel instead of a tiled kernel plus a fix-up launch for the
+ * seam outputs: real filters up to v/2 outputs and real resamplers up to 2v outputs take the generic kernel, the tiled
+ * complex decimator computes its seam outputs in place up to 5v outputs.  Results are identical either way.
+ * Default v = 32768 (also: environment SDRHIP_SMALL_LAUNCH); 0 = always the tiled kernels + fix-up launches; negative =
+ * restore the default.  Returns the previous value. */
 int sdrhip_set_small_launch_outputs(int outputs);
 
 /* Thin memory / stream helpers so a non-C++ host (Haskell, ctypes) needs no HIP

@@ -11,9 +11,15 @@
 
 namespace sdrhip {
 
-// outputs: seamed launches of the real filter / resampler no longer than this take the one-launch generic kernel
+// The "short seamed launch" scale v (sdrhip_set_small_launch_outputs; default 32768 outputs).  A seamed launch that short
+// is launch-bound, so it decides its Cross outputs inside ONE launch instead of a main kernel plus fix-ups -- measured per
+// stage at 8192 .. 131072 outputs:
+//   real filter      <= v/2 outputs : the generic kernel           (8192: 15.7 -> 14.1 us per push; at 39k it loses 4 us)
+//   real resampler   <= 2v outputs  : the generic kernel           (19.6k: 34 -> 22 us per push; 39k: 17.8 -> 11.9 us)
+//   tiled decimator  <= 5v outputs  : Cross outputs in the tile kernel (1k: 2 -> 1 launch; 131k: 14.3 -> 10.3 us)
 constexpr int kSmallSeamedLaunch = 32768;
 static std::atomic<int> g_small_launch{getenv("SDRHIP_SMALL_LAUNCH") ? atoi(getenv("SDRHIP_SMALL_LAUNCH")) : kSmallSeamedLaunch};
+int small_launch_outputs() { return g_small_launch.load(std::memory_order_relaxed); }
 
 static thread_local char g_err[512] = "";
 
@@ -206,7 +212,7 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
         // A seamed launch this short is one host block passing through a Pipe: the generic kernel does it in ONE launch (Cross
         // outputs decided per output) where the tiled kernels need a second one for the seams, and launches are what such a
         // push costs (measured, 8192-float blocks: 15.7 -> 14.1 us per push).
-        const bool small = g.seamBI > 0 && g.count <= g_small_launch.load(std::memory_order_relaxed);
+        const bool small = g.seamBI > 0 && g.count <= small_launch_outputs() / 2;
         if (small) {
             launch_fir_real(s, g, d->lanes, d->sym, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out);
             if (gain != 1.0f) launch_scale(s, gain, d_out, d_out, g.count);
@@ -319,7 +325,7 @@ int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in
     for (int q = 0; q < r->num_groups; q++) t.fo[q] = r->offsets[q];
     // as in fir_run: one launch instead of up to four (lead-in, tiles, tail, seams) for a single host block
     // (configs[3]'s 65536-float blocks: 34 -> 22 us per push)
-    const int small_generic_r = g_small_launch.load(std::memory_order_relaxed);
+    const int64_t small_generic_r = 2 * (int64_t)small_launch_outputs();
     if (r->cplx) {
         if (launch_resample3c_fast(s, g, r->corder, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
             // specialised complex 3-group kernel took it

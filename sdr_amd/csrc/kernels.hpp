@@ -143,6 +143,9 @@ bool launch_fm_tail_fused(hipStream_t s, const float* d_d, int64_t kd0, int64_t 
                           int64_t q0, int64_t q1, const float* d_groups, int row_stride, int nloop, const int* increments,
                           int ngroups, int I, int D, int rLp, const float* d_rplain, int ntaps, const float* d_fhalf, int nhalf,
                           const float* d_fplain, float gain, int64_t seam);
+// abi_device.cpp: the short-seamed-launch scale v (sdrhip_set_small_launch_outputs)
+int small_launch_outputs();
+
 bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps,
                              const void* d_in, bool in_is_u8, float* d_out);
 // kernels_fast_orders.hip: the same tiled decimator for the SSE "RC" and the "RC2" summation orders (CO_L2, CO_X4, CO_X2)

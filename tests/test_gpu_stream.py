@@ -31,8 +31,18 @@ def _run_ranges(desc, d_in, in_total, out_width, K, seam, cuts, u8=False, out_bl
     return to_host(out)
 
 
+@pytest.fixture(params=["one launch for short seamed launches", "tiled kernels + seam launch"])
+def launch_route(hip, request):
+    """Short seamed launches decide their Cross outputs inside one kernel by default (real filter / resampler: the generic
+    kernel; tiled complex decimator: in the tile kernel -- sdrhip_set_small_launch_outputs); the tests that feed them run
+    under both routes."""
+    prev = hip.set_small_launch_outputs(-1 if request.param.startswith("one") else 0)
+    yield request.param
+    hip.set_small_launch_outputs(prev)
+
+
 @pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE, PM.ORDER_SCALAR])
-def test_decimator_complex_stream(hip, oracle, order):
+def test_decimator_complex_stream(hip, oracle, order, launch_route):
     nblk = 5
     u8 = S.iq_u8(nblk * B)
     x = oracle.convert_u8(u8)
@@ -61,15 +71,6 @@ def test_decimator_lone_block_is_all_one(hip, oracle):
     got = _run_ranges(dec, to_dev(x), B, 2, 1009, 0, [])
     h = np.concatenate([taps, np.zeros(1, np.float32)])
     assert_bit_equal(got, oracle.decimate_rc(4, 1009, 8, np.repeat(h, 2), x), "lone block")
-
-
-@pytest.fixture(params=["one launch for short seamed launches", "tiled kernels + seam launch"])
-def launch_route(hip, request):
-    """Short seamed launches of the real filter / resampler take the one-launch generic kernel by default
-    (sdrhip_set_small_launch_outputs); the tests that feed them run under both routes."""
-    prev = hip.set_small_launch_outputs(-1 if request.param.startswith("one") else 0)
-    yield request.param
-    hip.set_small_launch_outputs(prev)
 
 
 @pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE])
@@ -230,7 +231,7 @@ def test_fm_demod_random_bit_patterns(hip, oracle):
 
 @pytest.mark.parametrize("factor", [8, 4, 16])
 @pytest.mark.parametrize("ntaps", [9, 12, 31, 51, 60, 77, 100, 121, 127, 130, 200, 253])
-def test_decimator_by_8_any_length_up_to_128(hip, oracle, ntaps, factor):
+def test_decimator_by_8_any_length_up_to_128(hip, oracle, ntaps, factor, launch_route):
     """The FM chain's decimator kernel serves every tap count up to 128 (exact kernels for 128 and 52, run-time guarded
     blocks otherwise) and the decimation factors 4, 8 and 16: cfloat and u8 input, seams, cut launches -- and it is that
     kernel, not a fallback, that runs."""
