@@ -234,7 +234,7 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
-    def measure(blocks, steps, warmup, passes, ramp_s, timing, graph=False):
+    def measure(blocks, steps, warmup, passes, ramp_s, timing, graph=False, do_exchange=True):
         """One configuration: `blocks` 8192-sample blocks per GPU per pass.  Returns the max-over-ranks wall time of
         `steps` steps of `passes` passes each, the per-stage HIP-event times and the plan.  graph: the chain's kernels of
         one pass replayed from a hipGraph captured once (sdrhip_fm_chain_graph_*): one launch per pass instead of one per kernel."""
@@ -255,6 +255,8 @@ def main():
             ws_b = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
 
         def exchange(on_stream):
+            if not do_exchange:          # "replicas only": the same passes with the halo left as it is (upper bound of the scaling)
+                return
             if comm is not None:
                 comm.chain_halo_exchange(chain, buf.data_ptr(), S_len, stream=on_stream.cuda_stream)   # ncclSend/ncclRecv on that stream
             else:
@@ -406,6 +408,18 @@ def main():
         except Exception as e:                          # noqa: BLE001
             shard_1m["hipgraph"] = f"failed: {e!r}"
 
+    # N > 1: what the exchange costs -- the same passes with the halo exchange left out ("replicas only" as the
+    # trivially-parallel upper bound)
+    replicas = None
+    if extras and world > 1:
+        st1 = max(2, args.steps // 4)
+        rm = measure(args.blocks, st1, 1, main_run["passes"], 0.05, False, do_exchange=False)
+        replicas = {"what": "the same shards and passes without the halo exchange (independent replicas): the upper bound of the scaling",
+                    "value": round(world * rm["S_len"] * rm["passes"] * st1 / rm["elapsed"] / 1e6, 1), "unit": "Msamples/s"}
+        if args.blocks != 128:
+            rs = measure(128, st1, 1, 0, 0.05, False, do_exchange=False)
+            replicas["shard_1M_samples_per_gpu"] = {"value": round(world * rs["S_len"] * rs["passes"] * st1 / rs["elapsed"] / 1e6, 1),
+                                                    "us_per_pass": round(rs["elapsed"] / (rs["passes"] * st1) * 1e6, 2)}
     dbg("shard_1m done")
     # BASELINE configs[1] (the north_star's roofline kernel): the same decimate-by-8 kernel fed cfloat IQ (8 B read + 1 B
     # written per input sample), device-resident, 8192-sample seams -- next to what the memory system of THIS box delivers
@@ -566,6 +580,7 @@ def main():
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
             "tail_ms": round(tail_ms, 5),
             "shard_1M_samples_per_gpu": shard_1m,
+            "without_halo_exchange": replicas,
             "host_streamed": host,
             "cpu_baseline": cpu,
         }
