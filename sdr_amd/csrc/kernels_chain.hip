@@ -85,18 +85,30 @@ __global__ void __launch_bounds__(NT) k_fir_real8_fast(const float* __restrict__
     const int64_t av64 = total_avail - out0;
     const int avail = av64 > span ? span : (int)av64;
     const float* src = in + x0 + out0;
-    for (int v = threadIdx.x; v < span4 + 3; v += NT) {       // + 3: the last window's reads run 12 floats past it
-        const int s = 4 * v;
-        float4 val;
-        if (aligned && s + 3 < avail) {
-            val = *reinterpret_cast<const float4*>(src + s);
-        } else {
-            val.x = s + 0 < avail ? src[s + 0] : 0.0f;
-            val.y = s + 1 < avail ? src[s + 1] : 0.0f;
-            val.z = s + 2 < avail ? src[s + 2] : 0.0f;
-            val.w = s + 3 < avail ? src[s + 3] : 0.0f;
+    const int nvec = span4 + 3;                                // + 3: the last window's reads run 12 floats past it
+    if (aligned && av64 >= 4 * (int64_t)nvec && nvec <= 2 * NT) {      // the floats past the tile's span exist (they feed no output)
+        // interior tile of a filter of up to ~250 taps: both 16-byte loads of a thread in flight at once (a load-store loop
+        // pays one HBM round trip per iteration)
+        const int v0 = threadIdx.x, v1 = threadIdx.x + NT;
+        const float4 a = *reinterpret_cast<const float4*>(src + 4 * v0);
+        float4 b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (v1 < nvec) b = *reinterpret_cast<const float4*>(src + 4 * v1);
+        *reinterpret_cast<float4*>(&lds[4 * v0]) = a;
+        if (v1 < nvec) *reinterpret_cast<float4*>(&lds[4 * v1]) = b;
+    } else {
+        for (int v = threadIdx.x; v < nvec; v += NT) {
+            const int s = 4 * v;
+            float4 val;
+            if (aligned && s + 3 < avail) {
+                val = *reinterpret_cast<const float4*>(src + s);
+            } else {
+                val.x = s + 0 < avail ? src[s + 0] : 0.0f;
+                val.y = s + 1 < avail ? src[s + 1] : 0.0f;
+                val.z = s + 2 < avail ? src[s + 2] : 0.0f;
+                val.w = s + 3 < avail ? src[s + 3] : 0.0f;
+            }
+            *reinterpret_cast<float4*>(&lds[s]) = val;
         }
-        *reinterpret_cast<float4*>(&lds[s]) = val;
     }
     __syncthreads();
 
@@ -276,18 +288,31 @@ __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restric
     const int avail = av64 > SPAN ? SPAN : (int)av64;
     const float* src = in + base;
     const bool al = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
-    for (int v = threadIdx.x; v < SPAN4; v += NT) {
-        const int s = 4 * v;
-        float4 val;
-        if (al && s + 3 < avail) {
-            val = *reinterpret_cast<const float4*>(src + s);
-        } else {
-            val.x = s + 0 < avail ? src[s + 0] : 0.0f;
-            val.y = s + 1 < avail ? src[s + 1] : 0.0f;
-            val.z = s + 2 < avail ? src[s + 2] : 0.0f;
-            val.w = s + 3 < avail ? src[s + 3] : 0.0f;
+    // all of the tile's global loads in flight at once, then one wait: a load-store loop pays one HBM round trip per
+    // iteration (2.6 of them here), and those round trips, not the arithmetic, were what a workgroup's life consisted of
+    constexpr int NV = (SPAN4 + NT - 1) / NT;
+    float4 val[NV];
+    if (al && avail >= 4 * SPAN4) {
+        // interior tile (all but the last workgroup of an aligned launch): branch-free 16-byte loads
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int v = threadIdx.x + i * NT;
+            val[i] = v < SPAN4 ? *reinterpret_cast<const float4*>(src + 4 * v) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
-        *reinterpret_cast<float4*>(&lds[s]) = val;
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int s = 4 * (threadIdx.x + i * NT);
+            val[i].x = s + 0 < avail ? src[s + 0] : 0.0f;
+            val[i].y = s + 1 < avail ? src[s + 1] : 0.0f;
+            val[i].z = s + 2 < avail ? src[s + 2] : 0.0f;
+            val[i].w = s + 3 < avail ? src[s + 3] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const int v = threadIdx.x + i * NT;
+        if (v < SPAN4) *reinterpret_cast<float4*>(&lds[4 * v]) = val[i];
     }
     __syncthreads();
 
