@@ -369,13 +369,32 @@ __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const
             constexpr int SPV = U8 ? 8 : 2;                              // samples per 16-byte vector
             constexpr int NV = (UNI + SPV - 1) / SPV;
             float2* row = lds + sl * ROW;
-            for (int v = lane; v < NV; v += PER) {
+            // every 16-byte load of the lane in flight before the first conversion / LDS store: the kernel is a few
+            // microseconds of latency, a load-store loop would pay one HBM round trip per iteration
+            constexpr int NIT = (NV + PER - 1) / PER;
+            uint4 raw[NIT];
+            bool whole[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int v = lane + it * PER;
+                const int64_t idx = u0 + (int64_t)v * SPV;
+                // vectors that poke outside the launch's own windows only feed discarded candidates
+                whole[it] = v < NV && idx >= lo && idx + SPV <= hi;
+                raw[it] = make_uint4(0u, 0u, 0u, 0u);
+                if (whole[it]) {
+                    if constexpr (U8) raw[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(in) + 2 * idx);
+                    else raw[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(in) + 2 * idx);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int v = lane + it * PER;
+                if (v >= NV) continue;
                 const int64_t idx = u0 + (int64_t)v * SPV;
                 float2 smp[SPV];
-                // vectors that poke outside the launch's own windows only feed discarded candidates
-                if (idx >= lo && idx + SPV <= hi) {
+                if (whole[it]) {
+                    const uint4 q = raw[it];
                     if constexpr (U8) {
-                        const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(in) + 2 * idx);
                         const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
@@ -385,9 +404,8 @@ __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const
                                                          ((float)(w[k] >> 24) - 128.0f) * (1.0f / 128.0f));
                         }
                     } else {
-                        const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(in) + 2 * idx);
-                        smp[0] = make_float2(q.x, q.y);
-                        smp[1] = make_float2(q.z, q.w);
+                        smp[0] = make_float2(__uint_as_float(q.x), __uint_as_float(q.y));
+                        smp[1] = make_float2(__uint_as_float(q.z), __uint_as_float(q.w));
                     }
                 } else {
 #pragma unroll
