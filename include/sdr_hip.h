@@ -329,6 +329,12 @@ int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain *c, int nsub);
  * for runs of at most one tile (2046 audio outputs, i.e. pushes of one to six 8192-sample source blocks), where one
  * launch replaces eight; on large batches the stage kernels are ~15 % faster (every stage is VALU-bound).  Same bits. */
 int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain *c, int mode);
+/* fmDemod inside the resampler's tile loader for large batches (>= 2^18 resampler outputs per run): the demodulated stream
+ * never makes its round trip through HBM (12 B per decimated sample less traffic); the per-stage timing then books the pair
+ * under `resample`.  Same bits.  Off by default (environment SDRHIP_FUSE_DEMOD=1 turns it on): measured, the pair takes
+ * 0.275-0.28 ms against 0.168 + 0.093 for the two stage kernels -- the chip is power-limited, the arithmetic is the same --
+ * and the whole chain gains 0.5-1 %. */
+int sdrhip_fm_chain_set_demod_fusion(sdrhip_fm_chain *c, int enable);
 /* Per-stage timing with HIP events recorded around each stage's kernels on the stream they are
  * launched on; stages {decimate(+seam fix-up), fmDemod, resample, filter(+gain), fused tail (the three in one kernel)}.
  * read_timing waits for the recorded runs, returns the SUM of elapsed ms per stage over

@@ -31,6 +31,8 @@ if os.environ.get("SDRHIP_SPLIT_DEFS"):   # tuning experiments, e.g. "-DSPLIT_CB
     FILE_FLAGS["kernels_split.hip"] = FILE_FLAGS["kernels_split.hip"] + os.environ["SDRHIP_SPLIT_DEFS"].split()
 if os.environ.get("SDRHIP_NO_SLP_FAST"):
     FILE_FLAGS["kernels_fast.hip"] = ["-fno-slp-vectorize"]
+if os.environ.get("SDRHIP_CHAIN_DEFS"):   # tuning experiments on the tail kernels
+    FILE_FLAGS["kernels_chain.hip"] = FILE_FLAGS["kernels_chain.hip"] + os.environ["SDRHIP_CHAIN_DEFS"].split()
 if os.environ.get("SDRHIP_FAST_DEFS"):    # tuning experiments on the tiled decimator, e.g. "-DSDRHIP_INL_STEP=8"
     FILE_FLAGS["kernels_fast.hip"] = FILE_FLAGS.get("kernels_fast.hip", []) + os.environ["SDRHIP_FAST_DEFS"].split()
 

@@ -18,6 +18,9 @@ namespace sdrhip {
 //   real resampler   <= 2v outputs  : the generic kernel           (19.6k: 34 -> 22 us per push; 39k: 17.8 -> 11.9 us)
 //   tiled decimator  <= 5v outputs  : Cross outputs in the tile kernel (1k: 2 -> 1 launch; 131k: 14.3 -> 10.3 us)
 constexpr int kSmallSeamedLaunch = 32768;
+// resampler launches of at least this many outputs take fmDemod into their tile loader (below, the two edge launches it adds
+// cost more than the round trip of y through HBM it saves)
+constexpr int kFusedDemodMinOutputs = 1 << 18;
 static std::atomic<int> g_small_launch{getenv("SDRHIP_SMALL_LAUNCH") ? atoi(getenv("SDRHIP_SMALL_LAUNCH")) : kSmallSeamedLaunch};
 int small_launch_outputs() { return g_small_launch.load(std::memory_order_relaxed); }
 
@@ -282,6 +285,18 @@ int resamp_create(ResampDesc* r, int order, bool cplx, int I, int D, const float
 int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in_base, float* d_out,
                int64_t k_begin, int64_t k_end, int64_t seam_block, int64_t out_block)
 {
+    return resamp_run_demod(r, s, nullptr, false, 0, d_in, in_base, d_out, k_begin, k_end, seam_block, out_block, nullptr);
+}
+
+// d_iq != nullptr: the inputs are still the decimator's complex output (d_iq = the sample whose phase step is input `in_base`,
+// y_count inputs from there) and d_in is the buffer fmDemod would fill: the FM chain's shape gets fmDemod fused into the
+// resampler's tile loader (*demod_fused = true; d_in is then written only where the lead / tail / seam kernels read it),
+// every other shape a stand-alone fmDemod launch first.
+int resamp_run_demod(const ResampDesc* r, hipStream_t s, const float* d_iq, bool iq_has_prev, int64_t y_count, const float* d_in,
+                     int64_t in_base, float* d_out, int64_t k_begin, int64_t k_end, int64_t seam_block, int64_t out_block,
+                     bool* demod_fused)
+{
+    if (demod_fused) *demod_fused = false;
     SDRHIP_REQUIRE(r != nullptr, "resamp_run");
     SDRHIP_REQUIRE(k_end >= k_begin && k_end - k_begin < (int64_t)0x7fffffff, "resamp_run");
     SDRHIP_REQUIRE(k_begin >= 0, "resamp_run");
@@ -326,6 +341,17 @@ int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in
     // as in fir_run: one launch instead of up to four (lead-in, tiles, tail, seams) for a single host block
     // (configs[3]'s 65536-float blocks: 34 -> 22 us per push)
     const int64_t small_generic_r = 2 * (int64_t)small_launch_outputs();
+    if (d_iq != nullptr) {
+        SDRHIP_REQUIRE(!r->cplx && y_count > 0, "resamp_run_demod: fmDemod feeds a real resampler");
+        const bool small = g.seamBI > 0 && g.count <= small_generic_r;
+        if (!small && r->lanes == 8 && g.count >= kFusedDemodMinOutputs &&
+            launch_resample_3_10_fast(s, g, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out, d_iq, iq_has_prev, y_count)) {
+            if (demod_fused) *demod_fused = true;
+            SDRHIP_CHECK_HIP(hipGetLastError());
+            return SDRHIP_OK;
+        }
+        launch_fm_demod_fast(s, d_iq, const_cast<float*>(d_in), y_count, iq_has_prev, 0.0f, 0.0f);
+    }
     if (r->cplx) {
         if (launch_resample3c_fast(s, g, r->corder, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
             // specialised complex 3-group kernel took it

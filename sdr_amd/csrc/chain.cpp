@@ -52,6 +52,7 @@ struct sdrhip_fm_chain {
     // instead of eight.  mode 0 = never, 1 = always, 2 = auto (runs of at most one tile): sdrhip_fm_chain_set_fused_tail,
     // SDRHIP_FUSED_TAIL=0/1/2.
     int fused_tail = getenv("SDRHIP_FUSED_TAIL") ? atoi(getenv("SDRHIP_FUSED_TAIL")) : 2;
+    bool fuse_demod = getenv("SDRHIP_FUSE_DEMOD") ? atoi(getenv("SDRHIP_FUSE_DEMOD")) != 0 : false;   // fmDemod in the resampler's tile loader
     bool tail_shape_ok(int64_t n_out) const
     {
         if (fused_tail == 0 || (fused_tail == 2 && n_out > kTailTileOutputs)) return false;
@@ -364,14 +365,23 @@ int sdrhip_fm_chain_run(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
             }
             if (c->timing && c->ev_used > 0) c->ev_used--;      // the span's begin event goes back to the pool
         }
-        // K3: fmDemod; at stream start the carried sample is 0 (Demod.hs:41)
-        if ((rc = begin_span(1, st, &b)) != SDRHIP_OK) return rc;
-        launch_fm_demod_fast(st, d_d + 2 * (r.ky0 - r.kd0), d_y, r.ky1 - r.ky0, r.ky0 > r.kd0, 0.0f, 0.0f);
-        if ((rc = end_span(1, st, b)) != SDRHIP_OK) return rc;
-        // K4: polyphase resample
-        if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;
-        if ((rc = resamp_run(&c->resamp, st, d_y, r.ky0, d_z, r.m0, r.m1, c->block, c->block)) != SDRHIP_OK) return rc;
-        if ((rc = end_span(2, st, b)) != SDRHIP_OK) return rc;
+        if (c->fuse_demod) {
+            // K3+K4: fmDemod inside the resampler's tile loader on large batches (y never reaches HBM), a stand-alone fmDemod
+            // launch first otherwise; timed as the resample stage
+            if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;
+            if ((rc = resamp_run_demod(&c->resamp, st, d_d + 2 * (r.ky0 - r.kd0), r.ky0 > r.kd0, r.ky1 - r.ky0, d_y, r.ky0, d_z, r.m0, r.m1,
+                                       c->block, c->block, nullptr)) != SDRHIP_OK) return rc;
+            if ((rc = end_span(2, st, b)) != SDRHIP_OK) return rc;
+        } else {
+            // K3: fmDemod; at stream start the carried sample is 0 (Demod.hs:41)
+            if ((rc = begin_span(1, st, &b)) != SDRHIP_OK) return rc;
+            launch_fm_demod_fast(st, d_d + 2 * (r.ky0 - r.kd0), d_y, r.ky1 - r.ky0, r.ky0 > r.kd0, 0.0f, 0.0f);
+            if ((rc = end_span(1, st, b)) != SDRHIP_OK) return rc;
+            // K4: polyphase resample
+            if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;
+            if ((rc = resamp_run(&c->resamp, st, d_y, r.ky0, d_z, r.m0, r.m1, c->block, c->block)) != SDRHIP_OK) return rc;
+            if ((rc = end_span(2, st, b)) != SDRHIP_OK) return rc;
+        }
         // K5: symmetric audio filter (+ fm.hs:40 `P.map (VG.map (* 0.2))` as the kernel's epilogue: a separate
         // f32 multiply of the rounded output)
         if ((rc = begin_span(3, st, &b)) != SDRHIP_OK) return rc;
@@ -447,6 +457,13 @@ int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain* c, int enable)
 {
     SDRHIP_REQUIRE(c != nullptr && enable >= 0 && enable <= 2, "sdrhip_fm_chain_set_fused_tail");
     c->fused_tail = enable;
+    return SDRHIP_OK;
+}
+
+int sdrhip_fm_chain_set_demod_fusion(sdrhip_fm_chain* c, int enable)
+{
+    SDRHIP_REQUIRE(c != nullptr, "sdrhip_fm_chain_set_demod_fusion");
+    c->fuse_demod = enable != 0;
     return SDRHIP_OK;
 }
 

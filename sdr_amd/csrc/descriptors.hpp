@@ -73,6 +73,11 @@ int resamp_create(ResampDesc* r, int order, bool cplx, int I, int D, const float
 // classification (kernels.hpp: late_output_is_one)
 int resamp_run(const ResampDesc* r, hipStream_t s, const float* d_in, int64_t in_base, float* d_out,
                int64_t k_begin, int64_t k_end, int64_t seam_block, int64_t out_block = 0);
+// fmDemod + resampler: d_iq = the decimator output whose phase step (fmDemod, Demod.hs:21-46) is input `in_base`, y_count
+// inputs; d_in = the buffer the stand-alone fmDemod would fill (abi_device.cpp)
+int resamp_run_demod(const ResampDesc* r, hipStream_t s, const float* d_iq, bool iq_has_prev, int64_t y_count, const float* d_in,
+                     int64_t in_base, float* d_out, int64_t k_begin, int64_t k_end, int64_t seam_block, int64_t out_block,
+                     bool* demod_fused);
 
 }  // namespace sdrhip
 

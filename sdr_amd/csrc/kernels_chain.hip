@@ -269,10 +269,22 @@ __global__ void __launch_bounds__(LP) k_filter_real_crossfix_lds(Geom g, const f
 // whose group is 0, so thread t owns outputs 3t..3t+NG-1 = groups 0..NG-1 and every
 // tap is wave-uniform.  inc[] (the per-group input increments) are compile-time.
 // ---------------------------------------------------------------------------
-template <int NG, int NLOOP, int INC0, int INC1, int INC2, int NT>
+// DEMOD: `in` is the decimator's complex output and the tile's inputs are demodulated on the way into LDS
+// (y[p] = phase(d[p] * conj d[p-1]), fmDemod, Demod.hs:21-46) -- y never makes the round trip through HBM that the
+// stand-alone fmDemod kernel pays 12 B per sample for (8 read + 4 written) and this kernel 4 more.  Only the y values
+// other kernels still read are written out (y_out): those within `ykeep` of a multiple of `yseam` (the seam fix-up's
+// windows).  in[2p] is y-input p of the launch; has_prev: in[-2..-1] exists (else the carried sample is 0, Demod.hs:41).
+struct DemodSide {
+    int has_prev;
+    float* y_out;          // y_out[p] for p relative to the launch's first input
+    int64_t y_abs0;        // absolute stream index of p = 0 (seams sit at absolute multiples of yseam)
+    int yseam, ykeep;      // yseam = 0: nothing to keep
+};
+
+template <int NG, int NLOOP, int INC0, int INC1, int INC2, int NT, bool DEMOD = false>
 __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restrict__ in, int64_t pos0, int ncycles,
                                                         int64_t avail_total, const float* __restrict__ groups,
-                                                        int row_stride, float* __restrict__ out)
+                                                        int row_stride, float* __restrict__ out, DemodSide dm)
 {
     static_assert(NG == 3, "specialised for three polyphase groups");
     constexpr int PERIOD = INC0 + INC1 + INC2;
@@ -286,6 +298,47 @@ __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restric
     const int64_t base = pos0 + (int64_t)cyc0 * PERIOD;  // first input of this workgroup, relative to `in`
     const int64_t av64 = avail_total - (int64_t)cyc0 * PERIOD;
     const int avail = av64 > SPAN ? SPAN : (int)av64;
+    if constexpr (DEMOD) {
+        // thread t demodulates inputs t, t + NT, ...: two 8-byte loads per input (the sample and its predecessor: the
+        // same cache lines one lane over), all of them in flight before the first phase is computed
+        constexpr int NP = (SPAN + NT - 1) / NT;
+        const float2* z = reinterpret_cast<const float2*>(in) + base;
+        const int m0 = dm.yseam > 0 ? (int)((dm.y_abs0 + base) % dm.yseam) : 0;      // one 64-bit modulo per workgroup
+        float2 cur[NP], prv[NP];
+        if (avail >= SPAN && (base > 0 || dm.has_prev)) {
+            // interior tile: branch-free loads (a conditional load costs a wait at its join: eleven HBM round trips in a row)
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                int p = threadIdx.x + i * NT;
+                p = p < SPAN ? p : SPAN - 1;
+                cur[i] = z[p];
+                prv[i] = z[p - 1];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const int p = threadIdx.x + i * NT;
+                cur[i] = prv[i] = make_float2(0.0f, 0.0f);
+                if (p < avail) {
+                    cur[i] = z[p];
+                    if (base + p > 0 || dm.has_prev) prv[i] = z[p - 1];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int p = threadIdx.x + i * NT;
+            if (p < SPAN) {
+                const float y = p < avail ? fm_phase_tern(cur[i], prv[i]) : 0.0f;
+                lds[p] = y;
+                if (dm.yseam > 0 && p < avail) {
+                    int m = m0 + p;                              // position inside the seam grid: SPAN <= yseam (launcher)
+                    if (m >= dm.yseam) m -= dm.yseam;
+                    if (m < dm.ykeep || m >= dm.yseam - dm.ykeep) dm.y_out[base + p] = y;
+                }
+            }
+        }
+    } else {
     const float* src = in + base;
     const bool al = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
     // all of the tile's global loads in flight at once, then one wait: a load-store loop pays one HBM round trip per
@@ -313,6 +366,7 @@ __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restric
     for (int i = 0; i < NV; i++) {
         const int v = threadIdx.x + i * NT;
         if (v < SPAN4) *reinterpret_cast<float4*>(&lds[4 * v]) = val[i];
+    }
     }
     __syncthreads();
 
@@ -467,9 +521,21 @@ bool launch_filter_cplx4_fast(hipStream_t s, const Geom& g, const float* d_dup_t
     return true;
 }
 
+// d_iq != nullptr: fmDemod fused into the tile loader (k_resample3_fast<.., DEMOD>): d_iq[2p], d_iq[2p+1] is the decimator
+// output whose phase step is input p of this launch (y_count of them), d_in is then the y BUFFER, which this call fills
+// only where other kernels read it: the first and last kEdge inputs (stand-alone fmDemod launches: the few outputs before the
+// first / after the last whole polyphase cycle) and the neighbourhood of every seam (written by the tile kernel).
 bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& t, const int* increments,
-                               const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out)
+                               const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out,
+                               const float* d_iq, bool iq_has_prev, int64_t y_count)
 {
+    constexpr int kEdge = 256, kKeep = 160;
+    if (d_iq != nullptr) {
+        // the fused form serves the FM chain's shape only; anything else: the caller demodulates first
+        const int64_t yseam = g.seamBI > 0 ? g.seamBI / g.I : 0;
+        if (t.nloop != 64 || g.I != 3 || y_count < 4 * kEdge || t.pos0 + 96 > kEdge) return false;
+        if (g.seamBI > 0 && (g.seamBI % g.I != 0 || yseam < 4096 || yseam > (1 << 30))) return false;
+    }
     // specialised for the FM chain's resampler: 3 groups, increments {4,3,3}, 64-float rows, AVX order
     if (t.ngroups != 3 || !(t.nloop == 64 || t.nloop == 16) || g.seamBI < 0 || t.force_seq) return false;
     if (!(increments[0] == 4 && increments[1] == 3 && increments[2] == 3)) return false;
@@ -483,6 +549,14 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
     const int tail = g.count - lead - 3 * ncycles;
     Geom gs = g;
     gs.seamBI = 0;  // every output as One first; seams are fixed up below
+    if (d_iq != nullptr) {
+        // the tail's windows must lie inside the last kEdge inputs
+        const int64_t tail_pos = t.pos0 + (lead > 0 ? t.pre[lead - 1] + increments[(t.group0 + lead - 1) % 3] : 0) + (int64_t)ncycles * 10;
+        if (tail_pos < y_count - kEdge + 16 || ncycles < 1) return false;
+        float* d_y = const_cast<float*>(d_in);
+        launch_fm_demod_fast(s, d_iq, d_y, kEdge, iq_has_prev, 0.0f, 0.0f);
+        launch_fm_demod_fast(s, d_iq + 2 * (y_count - kEdge), d_y + (y_count - kEdge), kEdge, true, 0.0f, 0.0f);
+    }
     if (lead > 0) {
         Geom gl = gs;
         gl.count = lead;
@@ -493,12 +567,21 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
         int64_t pos = t.pos0 + (lead > 0 ? t.pre[lead - 1] + increments[(t.group0 + lead - 1) % 3] : 0);
         const int64_t avail_total = (int64_t)(ncycles - 1) * 10 + 7 + t.nloop;
         const int blocks = (ncycles + NT - 1) / NT;
-        if (t.nloop == 64)
+        DemodSide dm = {};
+        if (d_iq != nullptr) {
+            dm.has_prev = iq_has_prev ? 1 : 0;
+            dm.y_out = const_cast<float*>(d_in);
+            dm.y_abs0 = g.in_base;
+            dm.yseam = g.seamBI > 0 ? (int)(g.seamBI / g.I) : 0;
+            dm.ykeep = kKeep;
+            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, true>), dim3(blocks), dim3(NT), 0, s, d_iq, pos, ncycles, avail_total,
+                               d_groups, t.row_stride, d_out + lead, dm);
+        } else if (t.nloop == 64)
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
-                               d_groups, t.row_stride, d_out + lead);
+                               d_groups, t.row_stride, d_out + lead, dm);
         else
             hipLaunchKernelGGL((k_resample3_fast<3, 16, 4, 3, 3, NT>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
-                               d_groups, t.row_stride, d_out + lead);
+                               d_groups, t.row_stride, d_out + lead, dm);
     }
     if (tail > 0) {
         const int done = lead + 3 * ncycles;

@@ -443,6 +443,10 @@ class FmChain(_Handle):
         """0 = stage kernels, 1 = the fused tail kernel wherever the chain's shape allows, 2 = auto (short runs only)."""
         check(lib.sdrhip_fm_chain_set_fused_tail(self.h, int(mode)), "sdrhip_fm_chain_set_fused_tail")
 
+    def set_demod_fusion(self, on=True):
+        """fmDemod inside the resampler's tile loader on large batches (sdrhip_fm_chain_set_demod_fusion)."""
+        check(lib.sdrhip_fm_chain_set_demod_fusion(self.h, int(on)), "sdrhip_fm_chain_set_demod_fusion")
+
     def enable_timing(self, on=True):
         check(lib.sdrhip_fm_chain_enable_timing(self.h, int(on)), "sdrhip_fm_chain_enable_timing")
 

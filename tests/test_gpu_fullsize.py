@@ -183,3 +183,32 @@ def test_chain_pipelining_is_invisible(hip):
         outs.append(res)
     for o in outs[1:]:
         assert torch.equal(outs[0].view(torch.int32), o.view(torch.int32))
+
+
+@pytest.mark.parametrize("start_blocks", [0, 37])
+def test_chain_demod_fusion_is_invisible(hip, start_blocks):
+    """fmDemod inside the resampler's tile loader (sdrhip_fm_chain_set_demod_fusion): the demodulated stream is then written
+    only around seams and launch edges, and every audio sample must still be the stage kernels' -- from the stream start
+    (carried sample 0) and from the middle of a stream, with 8192-sample seams and without."""
+    n = 1 << 25
+    u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda")
+    for block in (B, 0):
+        chain = hip.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, block)
+        ws = torch.empty(chain.workspace_bytes(n), dtype=torch.uint8, device="cuda")
+        s0 = start_blocks * B
+        q0, q1, _ = chain.plan(s0, s0 + n, s0 + n)
+        assert q1 - q0 > (1 << 20)
+        outs = []
+        for fused in (False, True, False):
+            chain.set_demod_fusion(fused)
+            ws.fill_(0xA5)                                         # stale workspace contents must not matter
+            out = torch.zeros(q1 - q0, dtype=torch.float32, device="cuda")
+            chain.enable_timing(True)
+            chain.run(ptr(u8), s0, n, ptr(out), q0, q1, ptr(ws), ws.numel())
+            torch.cuda.synchronize()
+            stage_ms, _ = chain.read_timing()
+            chain.enable_timing(False)
+            assert (stage_ms["fm_demod"] == 0.0) == fused, "the fused form books the pair under `resample`"
+            outs.append(out)
+        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), f"block {block}: fused differs"
+        assert torch.equal(outs[0].view(torch.int32), outs[2].view(torch.int32))
