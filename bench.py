@@ -234,14 +234,28 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
-    def measure(blocks, steps, warmup, passes, ramp_s, timing, graph=False, do_exchange=True):
+    def measure(blocks, steps, warmup, passes, ramp_s, timing, graph=False, do_exchange=True, data="uniform"):
         """One configuration: `blocks` 8192-sample blocks per GPU per pass.  Returns the max-over-ranks wall time of
         `steps` steps of `passes` passes each, the per-stage HIP-event times and the plan.  graph: the chain's kernels of
         one pass replayed from a hipGraph captured once (sdrhip_fm_chain_graph_*): one launch per pass instead of one per kernel."""
         S_len = blocks * BLOCK
         plan = sharding.ShardPlan(chain, rank, world, S_len)          # owned outputs + halo for this rank
         gen = torch.Generator(device="cuda").manual_seed(S.SEED_IQ + rank)
-        buf = torch.randint(0, 256, (2 * (S_len + plan.halo_cap),), dtype=torch.uint8, device="cuda", generator=gen)
+        if data == "fm":
+            # what an FM receiver is fed: a frequency-modulated carrier (1 kHz tone, 25 kHz deviation at 1.28 MS/s, tests/
+            # signals.py:iq_u8_fm) + a little noise, quantised to u8 IQ -- generated on the device in slices
+            buf = torch.empty(2 * (S_len + plan.halo_cap), dtype=torch.uint8, device="cuda")
+            nall, step = S_len + plan.halo_cap, 1 << 24
+            for a in range(0, nall, step):
+                b = min(nall, a + step)
+                t = torch.arange(a, b, device="cuda", dtype=torch.float64) / 1.28e6
+                ph = (25.0 * torch.sin(2 * 3.141592653589793 * 1e3 * t)).to(torch.float32)
+                nz = 0.02 * torch.randn(2, b - a, device="cuda", generator=gen)
+                buf[2 * a:2 * b:2] = torch.clamp(torch.round((0.8 * torch.cos(ph) + nz[0]) * 127.5 + 127.5), 0, 255).to(torch.uint8)
+                buf[2 * a + 1:2 * b:2] = torch.clamp(torch.round((0.8 * torch.sin(ph) + nz[1]) * 127.5 + 127.5), 0, 255).to(torch.uint8)
+            del t, ph, nz
+        else:
+            buf = torch.randint(0, 256, (2 * (S_len + plan.halo_cap),), dtype=torch.uint8, device="cuda", generator=gen)
         audio = torch.empty(plan.q1 - plan.q0, dtype=torch.float32, device="cuda")
         ws_bytes = chain.workspace_bytes(S_len + plan.halo_cap)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
@@ -436,6 +450,16 @@ def main():
         dbg("cfg1 done")
     main_run = measure(args.blocks, args.steps, args.warmup, args.passes_per_step, 0.3, True)
     dbg("main measurement done")
+    # the same run on a frequency-modulated carrier instead of uniform random bytes (the chip is power-limited and the power
+    # of a multiply depends on its operands: random bytes are the most expensive input there is)
+    fm_input = None
+    if extras:
+        stf = max(2, args.steps // 4)
+        rf = measure(args.blocks, stf, 1, main_run["passes"], 0.1, False, data="fm")
+        fm_input = {"value": round(world * rf["S_len"] * rf["passes"] * stf / rf["elapsed"] / 1e6, 1), "unit": "Msamples/s",
+                    "input": "u8 IQ of an FM carrier (1 kHz tone, 25 kHz deviation at 1.28 MS/s, amplitude 0.8 of full scale) + noise: "
+                             "what the receiver is fed; the headline `value` is measured on uniform random bytes"}
+        dbg("fm input done")
 
     # BASELINE configs[4]'s shard size: 2^20 samples (128 blocks) per GPU per pass -- launch/latency-bound, the case where the
     # halo exchange matters; reported next to the main line, same run
@@ -578,6 +602,7 @@ def main():
             "roofline_config1_cfloat_decimate": cfg1,
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
             "tail_ms": round(tail_ms, 5),
+            "fm_carrier_input": fm_input,
             "shard_1M_samples_per_gpu": shard_1m,
             "without_halo_exchange": replicas,
             "host_streamed": host,
