@@ -6,110 +6,116 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
-dst = os.path.join(ROOT, "profiles")
-os.makedirs(dst, exist_ok=True)
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
 
 
-def short(name):
-    n = name.replace("void ", "").replace("sdrhip::(anonymous namespace)::", "")
-    return n.split("(")[0]
+    def short(name):
+        n = name.replace("void ", "").replace("sdrhip::(anonymous namespace)::", "")
+        return n.split("(")[0]
 
 
-# 1. kernel-trace stats
-rows = list(csv.DictReader(open(os.path.join(src, "stats", "bench_kernel_stats.csv"))))
-with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
-    w = csv.writer(f)
-    w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns", "stddev"])
-    for r in rows:
-        w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
-                    r["MaxNs"], r["StdDev"]])
-stats_avg = {short(r["Name"]): float(r["AverageNs"]) for r in rows}
+    # 1. kernel-trace stats
+    rows = list(csv.DictReader(open(os.path.join(src, "stats", "bench_kernel_stats.csv"))))
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns", "stddev"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
+                        r["MaxNs"], r["StdDev"]])
+    stats_avg = {short(r["Name"]): float(r["AverageNs"]) for r in rows}
 
 
-# 2. PMC passes: per kernel, mean over dispatches of the per-dispatch sum over dimensions
-def pmc(sub):
-    path = os.path.join(src, sub, "bench_counter_collection.csv")
-    per = collections.defaultdict(lambda: collections.defaultdict(float))
-    dur = {}
-    for r in csv.DictReader(open(path)):
-        k = (short(r["Kernel_Name"]), r["Dispatch_Id"])
-        per[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        dur[k] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    out = collections.defaultdict(lambda: collections.defaultdict(list))
-    for (k, d), cs in per.items():
-        for c, v in cs.items():
-            out[k][c].append(v)
-        out[k]["_dur_ns"].append(dur[(k, d)])
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in out.items()}
+    # 2. PMC passes: per kernel, mean over dispatches of the per-dispatch sum over dimensions
+    def pmc(sub):
+        path = os.path.join(src, sub, "bench_counter_collection.csv")
+        per = collections.defaultdict(lambda: collections.defaultdict(float))
+        dur = {}
+        for r in csv.DictReader(open(path)):
+            k = (short(r["Kernel_Name"]), r["Dispatch_Id"])
+            per[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            dur[k] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        out = collections.defaultdict(lambda: collections.defaultdict(list))
+        for (k, d), cs in per.items():
+            for c, v in cs.items():
+                out[k][c].append(v)
+            out[k]["_dur_ns"].append(dur[(k, d)])
+        return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in out.items()}
 
 
-allc = collections.defaultdict(dict)
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
-    for k, cs in pmc(sub).items():
-        for c, v in cs.items():
-            allc[k][c if c != "_dur_ns" else f"dur_ns[{sub}]"] = v
-ours = {k: v for k, v in allc.items() if k.startswith("k_")}
-cols = sorted({c for v in ours.values() for c in v})
-with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w", newline="") as f:
-    w = csv.writer(f)
-    w.writerow(["kernel"] + cols)
+    allc = collections.defaultdict(dict)
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
+        for k, cs in pmc(sub).items():
+            for c, v in cs.items():
+                allc[k][c if c != "_dur_ns" else f"dur_ns[{sub}]"] = v
+    ours = {k: v for k, v in allc.items() if k.startswith("k_")}
+    cols = sorted({c for v in ours.values() for c in v})
+    with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel"] + cols)
+        for k, v in sorted(ours.items()):
+            w.writerow([k] + [f"{v.get(c, float('nan')):.1f}" for c in cols])
+
+    # 3. K2 HBM traffic, per launch, with the gfx950 corrections of MI355X_MICROARCH.md (HBM section):
+    #    FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE reports exactly half of a wide (16 B/lane) coalesced
+    #    streaming read on gfx950 -> doubled; WRITE_SIZE is uncalibrated -> reported as measured.
+    bench = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
+    k2 = next(k for k in ours if k.startswith("k_decimate_c4<"))
+    fetch_kib = ours[k2].get("FETCH_SIZE", float("nan"))
+    write_kib = ours[k2].get("WRITE_SIZE", float("nan"))
+    samples = bench["roofline"]["algorithmic_bytes_per_launch"] / 3.0
+    sys.path.insert(0, ROOT)
+    from bench import k2_source_sha256
+    traffic = {
+        "kernel": k2,
+        "kernels_fast_sha256": k2_source_sha256(),      # decimate_tile.hpp + kernels_fast.hip
+        "samples_per_launch": int(round(samples)),
+        "FETCH_SIZE_KiB_raw": fetch_kib,
+        "WRITE_SIZE_KiB_raw": write_kib,
+        "fetch_bytes_corrected": 2.0 * fetch_kib * 1024.0,
+        "write_bytes": write_kib * 1024.0,
+        "hbm_bytes_per_launch": 2.0 * fetch_kib * 1024.0 + write_kib * 1024.0,
+        "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+        "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 5 --warmup 2 "
+               "--no-cpu-baseline`, mean over the kernel's dispatches of the sum over counter dimensions; FETCH_SIZE x2 "
+               "(gfx950 wide-coalesced-read under-count, MI355X_MICROARCH.md HBM section), x1024 (KiB -> B)",
+    }
+    json.dump(traffic, open(os.path.join(dst, "k2_traffic.json"), "w"), indent=1)
+    json.dump(bench, open(os.path.join(dst, f"{tag}_bench_unprofiled.json"), "w"), indent=1)
+
+    # 3b. the cfloat-in instantiation (BASELINE configs[1]), from the separate passes over tools/prof_k2.py
+    try:
+        c_f = pmc("pmc_fetch_k2c")
+        c_w = pmc("pmc_write_k2c")
+        # template arguments <D, P, R, NT, U8, TC, GUARD, NP, ORD>: the cfloat-in instantiation has U8 = false
+        kc = next(k for k in c_f if k.startswith("k_decimate_c4<") and k[k.index("<") + 1:].split(",")[4].strip() == "false")
+        n_c = 1 << 27
+        fk, wk = c_f[kc].get("FETCH_SIZE", float("nan")), c_w[kc].get("WRITE_SIZE", float("nan"))
+        json.dump({"kernel": kc, "samples_per_launch": n_c, "FETCH_SIZE_KiB_raw": fk, "WRITE_SIZE_KiB_raw": wk,
+                   "fetch_bytes_corrected": 2.0 * fk * 1024.0, "write_bytes": wk * 1024.0,
+                   "hbm_bytes_per_launch": 2.0 * fk * 1024.0 + wk * 1024.0, "algorithmic_bytes_per_launch": 9.0 * n_c,
+                   "ratio": (2.0 * fk * 1024.0 + wk * 1024.0) / (9.0 * n_c),
+                   "kernels_fast_sha256": traffic["kernels_fast_sha256"],
+                   "how": "as k2_traffic.json, over `python tools/prof_k2.py 27 f32` (cfloat IQ in, 2^27 samples per launch, no seams)"},
+                  open(os.path.join(dst, "k2c_traffic.json"), "w"), indent=1)
+    except Exception as e:          # noqa: BLE001
+        print("no k2c passes:", e)
+
+    # 4. derived table for the README
+    print("kernel                                   avg_us(stats)  clock_GHz  valu_quad_busy  lds_conflict/idx")
     for k, v in sorted(ours.items()):
-        w.writerow([k] + [f"{v.get(c, float('nan')):.1f}" for c in cols])
+        d = v.get("dur_ns[pmc_lds]", float("nan"))
+        clock = v.get("GRBM_GUI_ACTIVE", float("nan")) / 8.0 / d if d == d else float("nan")
+        dsq = v.get("dur_ns[pmc_sq]", float("nan"))
+        busy = v.get("SQ_ACTIVE_INST_VALU", float("nan")) * 4.0 / 1024.0 / (dsq * clock) if dsq == dsq else float("nan")
+        lds = v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0)
+        print(f"{k[:40]:40s} {stats_avg.get(k, float('nan'))/1e3:12.1f} {clock:10.2f} {busy:14.2f} {lds:12.3f}")
+    print(json.dumps(traffic, indent=1))
 
-# 3. K2 HBM traffic, per launch, with the gfx950 corrections of MI355X_MICROARCH.md (HBM section):
-#    FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE reports exactly half of a wide (16 B/lane) coalesced
-#    streaming read on gfx950 -> doubled; WRITE_SIZE is uncalibrated -> reported as measured.
-bench = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
-k2 = next(k for k in ours if k.startswith("k_decimate_c4<"))
-fetch_kib = ours[k2].get("FETCH_SIZE", float("nan"))
-write_kib = ours[k2].get("WRITE_SIZE", float("nan"))
-samples = bench["roofline"]["algorithmic_bytes_per_launch"] / 3.0
-sys.path.insert(0, ROOT)
-from bench import k2_source_sha256
-traffic = {
-    "kernel": k2,
-    "kernels_fast_sha256": k2_source_sha256(),      # decimate_tile.hpp + kernels_fast.hip
-    "samples_per_launch": int(round(samples)),
-    "FETCH_SIZE_KiB_raw": fetch_kib,
-    "WRITE_SIZE_KiB_raw": write_kib,
-    "fetch_bytes_corrected": 2.0 * fetch_kib * 1024.0,
-    "write_bytes": write_kib * 1024.0,
-    "hbm_bytes_per_launch": 2.0 * fetch_kib * 1024.0 + write_kib * 1024.0,
-    "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-    "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 5 --warmup 2 "
-           "--no-cpu-baseline`, mean over the kernel's dispatches of the sum over counter dimensions; FETCH_SIZE x2 "
-           "(gfx950 wide-coalesced-read under-count, MI355X_MICROARCH.md HBM section), x1024 (KiB -> B)",
-}
-json.dump(traffic, open(os.path.join(dst, "k2_traffic.json"), "w"), indent=1)
-json.dump(bench, open(os.path.join(dst, f"{tag}_bench_unprofiled.json"), "w"), indent=1)
 
-# 3b. the cfloat-in instantiation (BASELINE configs[1]), from the separate passes over tools/prof_k2.py
-try:
-    c_f = pmc("pmc_fetch_k2c")
-    c_w = pmc("pmc_write_k2c")
-    # template arguments <D, P, R, NT, U8, TC, GUARD, NP, ORD>: the cfloat-in instantiation has U8 = false
-    kc = next(k for k in c_f if k.startswith("k_decimate_c4<") and k[k.index("<") + 1:].split(",")[4].strip() == "false")
-    n_c = 1 << 27
-    fk, wk = c_f[kc].get("FETCH_SIZE", float("nan")), c_w[kc].get("WRITE_SIZE", float("nan"))
-    json.dump({"kernel": kc, "samples_per_launch": n_c, "FETCH_SIZE_KiB_raw": fk, "WRITE_SIZE_KiB_raw": wk,
-               "fetch_bytes_corrected": 2.0 * fk * 1024.0, "write_bytes": wk * 1024.0,
-               "hbm_bytes_per_launch": 2.0 * fk * 1024.0 + wk * 1024.0, "algorithmic_bytes_per_launch": 9.0 * n_c,
-               "ratio": (2.0 * fk * 1024.0 + wk * 1024.0) / (9.0 * n_c),
-               "kernels_fast_sha256": traffic["kernels_fast_sha256"],
-               "how": "as k2_traffic.json, over `python tools/prof_k2.py 27 f32` (cfloat IQ in, 2^27 samples per launch, no seams)"},
-              open(os.path.join(dst, "k2c_traffic.json"), "w"), indent=1)
-except Exception as e:          # noqa: BLE001
-    print("no k2c passes:", e)
-
-# 4. derived table for the README
-print("kernel                                   avg_us(stats)  clock_GHz  valu_quad_busy  lds_conflict/idx")
-for k, v in sorted(ours.items()):
-    d = v.get("dur_ns[pmc_lds]", float("nan"))
-    clock = v.get("GRBM_GUI_ACTIVE", float("nan")) / 8.0 / d if d == d else float("nan")
-    dsq = v.get("dur_ns[pmc_sq]", float("nan"))
-    busy = v.get("SQ_ACTIVE_INST_VALU", float("nan")) * 4.0 / 1024.0 / (dsq * clock) if dsq == dsq else float("nan")
-    lds = v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0)
-    print(f"{k[:40]:40s} {stats_avg.get(k, float('nan'))/1e3:12.1f} {clock:10.2f} {busy:14.2f} {lds:12.3f}")
-print(json.dumps(traffic, indent=1))
+if __name__ == "__main__":
+    main()
