@@ -193,7 +193,8 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
     if (d->cplx) {
         if (d->corder == CO_L4 &&
             (!in_u8 || d->d_scaled) &&
-            launch_decimate_c4_fast(s, g, in_u8 ? d->d_scaled : d->d_plain, d->Lp, d->d_cross, d_in, in_u8, d_out)) {
+            launch_decimate_c4_fast(s, g, in_u8 ? d->d_scaled : d->d_plain, d->Lp, d->d_cross, d_in, in_u8, d_out,
+                                    in_u8 && (int)d->h_plain.size() == d->Lp && d->h_plain[d->Lp - 1] == 0.0f)) {
             // specialised kernel took it
         } else if (d->corder != CO_L4 && !d->sym && (!in_u8 || d->d_scaled) &&
                    launch_decimate_c_orders_fast(s, g, d->corder, in_u8 ? d->d_scaled : d->d_plain, d->Lp, d->d_cross, d_in, in_u8, d_out)) {

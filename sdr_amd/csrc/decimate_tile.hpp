@@ -47,7 +47,10 @@ __device__ __forceinline__ typename TapVec<TC>::type load_tap_chunk(const float*
 // GUARD: the filter actually has nch_eff * TC <= P taps (run-time, wave-uniform); blocks and (block, output) pairs that
 // only meet taps beyond them are skipped, so one instantiation serves every shorter filter with exactly the arithmetic of
 // an exact-length kernel (nothing is multiplied by padding).
-template <int D, int P, int R, class T, int TC, bool GUARD, int NP = 4>
+// PSKIP: the last PSKIP taps are known to be zero (the padding `Filter.hs:146-148` appends) and every sample is finite (u8
+// input): their MACs are skipped.  Exact: a partial sum that started at +0 is never -0 (x + (-x) and (+0) + (-0) are +0 in
+// round-to-nearest, and an addition never underflows to zero), so adding the product (+-0) * (finite) = +-0 leaves it as it is.
+template <int D, int P, int R, class T, int TC, bool GUARD, int NP = 4, int PSKIP = 0>
 __device__ __forceinline__ void mac_window(const float2* __restrict__ win, const float* __restrict__ taps, float2 (&acc)[R][NP],
                                            int nch_eff)
 {
@@ -86,7 +89,7 @@ __device__ __forceinline__ void mac_window(const float2* __restrict__ win, const
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         const int j = ss - r * D;
-                        if (j >= 0 && j < P) {
+                        if (j >= 0 && j < P - PSKIP) {
                             const float h = tc[j / TC][j % TC];
                             acc[r][j % NP].x = acc[r][j % NP].x + h * v[e].x;
                             acc[r][j % NP].y = acc[r][j % NP].y + h * v[e].y;
@@ -220,7 +223,7 @@ __device__ __forceinline__ float2 fold_partials(const float2 (&a)[NP])
     }
 }
 
-template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false, int NP = 4, int ORD = 0>
+template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false, int NP = 4, int ORD = 0, int PSKIP = 0>
 __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in, int64_t x0 /* sample index of output 0's window in `in` */,
                                                     int count, const float* __restrict__ taps, float* __restrict__ out,
                                                     int p_eff /* GUARD: taps of the filter (multiple of TC, <= P); else unused */,
@@ -262,7 +265,8 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
 #pragma unroll
         for (int k = 0; k < NP; k++) acc[r][k] = make_float2(0.0f, 0.0f);
 
-    mac_window<D, P, R, T, TC, GUARD, NP>(win, taps, acc, GUARD ? p_eff / TC : 0);
+    static_assert(PSKIP == 0 || (U8 && !GUARD), "skipping zero taps needs finite samples");
+    mac_window<D, P, R, T, TC, GUARD, NP, PSKIP>(win, taps, acc, GUARD ? p_eff / TC : 0);
 
     const int o = out0 + threadIdx.x * R;
     float2 res[R];
@@ -464,14 +468,14 @@ __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const
 
 // inline_cross: the kernel computes the Cross outputs itself (no fix-up launch); *inlined tells whether the geometry allowed
 // it (a tile must span less than one buffer)
-template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false, int NP = 4, int ORD = 0>
+template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false, int NP = 4, int ORD = 0, int PSKIP = 0>
 void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, float* out, bool inline_cross = false,
                bool* inlined = nullptr)
 {
     using T = Tile<D, P, R, NT>;
     // the dynamic-LDS attribute is per device: one flag per (instantiation, device); idempotent, a race only repeats the call
     static std::atomic<bool> attr_set[64];
-    auto kern = k_decimate_c4<D, P, R, NT, U8, TC, GUARD, NP, ORD>;
+    auto kern = k_decimate_c4<D, P, R, NT, U8, TC, GUARD, NP, ORD, PSKIP>;
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {

@@ -149,8 +149,9 @@ bool launch_fm_tail_fused(hipStream_t s, const float* d_d, int64_t kd0, int64_t 
 // abi_device.cpp: the short-seamed-launch scale v (sdrhip_set_small_launch_outputs)
 int small_launch_outputs();
 
+// last_tap_zero: tap P-1 is the zero the constructor padded the filter with (lets the u8 path skip its MACs)
 bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps,
-                             const void* d_in, bool in_is_u8, float* d_out);
+                             const void* d_in, bool in_is_u8, float* d_out, bool last_tap_zero = false);
 // kernels_fast_orders.hip: the same tiled decimator for the SSE "RC" and the "RC2" summation orders (CO_L2, CO_X4, CO_X2)
 bool launch_decimate_c_orders_fast(hipStream_t s, const Geom& g, ComplexOrder order, const float* d_plain_taps, int P,
                                    const float* d_cross_taps, const void* d_in, bool in_is_u8, float* d_out);

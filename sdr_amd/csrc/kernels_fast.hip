@@ -31,7 +31,7 @@ namespace {
 }  // namespace
 
 bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps,
-                             const void* d_in, bool in_is_u8, float* d_out)
+                             const void* d_in, bool in_is_u8, float* d_out, bool last_tap_zero)
 {
     if (g.I != 1 || g.count <= 0 || g.seamBI < 0) return false;
     // Decimation 8: exact kernels for 128 and 52 taps; every other length up to 128 (multiples of 4: mkDecimatorC pads
@@ -78,7 +78,9 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
         if (in_is_u8) launch_c4<8, 52, 2, 256, true>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
         else launch_c4<8, 52, 2, 256, false>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
     } else {
-        if (in_is_u8) launch_c4<8, 128, 2, 256, true>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
+        // 127 taps padded to 128 (the FM chain's decimator): the padding tap's MACs are skipped on u8 input (decimate_tile.hpp: PSKIP)
+        if (in_is_u8 && last_tap_zero) launch_c4<8, 128, 2, 256, true, 8, false, 4, 0, 1>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
+        else if (in_is_u8) launch_c4<8, 128, 2, 256, true>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
         else launch_c4<8, 128, 2, 256, false>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
     }
 
