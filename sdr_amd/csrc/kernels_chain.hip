@@ -178,17 +178,34 @@ __global__ void __launch_bounds__(NT) k_filter_cplx4_fast(const float* __restric
     const int avail = av64 > span ? span : (int)av64;
     const float2* src = reinterpret_cast<const float2*>(in) + x0 + out0;
     const bool al = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
-    for (int v = threadIdx.x; v < (span + 1) / 2 + 4; v += NT) {   // + 4: the last window's reads run 8 samples past it
-        const int s = 2 * v;
-        float4 val;
-        if (al && s + 1 < avail) {
-            val = *reinterpret_cast<const float4*>(src + s);
-        } else {
-            const float2 a = s < avail ? src[s] : make_float2(0.0f, 0.0f);
-            const float2 b = s + 1 < avail ? src[s + 1] : make_float2(0.0f, 0.0f);
-            val = make_float4(a.x, a.y, b.x, b.y);
+    const int nvec = (span + 1) / 2 + 4;                       // + 4: the last window's reads run 8 samples past it
+    if (al && av64 >= 2 * (int64_t)nvec && nvec <= 3 * NT) {
+        // interior tile of a filter of up to ~500 taps: every 16-byte load of a thread in flight before the first LDS store
+        float4 val[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            int v = threadIdx.x + i * NT;
+            v = v < nvec ? v : nvec - 1;
+            val[i] = *reinterpret_cast<const float4*>(src + 2 * v);
         }
-        *reinterpret_cast<float4*>(&lds[s]) = val;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int v = threadIdx.x + i * NT;
+            if (v < nvec) *reinterpret_cast<float4*>(&lds[2 * v]) = val[i];
+        }
+    } else {
+        for (int v = threadIdx.x; v < nvec; v += NT) {
+            const int s = 2 * v;
+            float4 val;
+            if (al && s + 1 < avail) {
+                val = *reinterpret_cast<const float4*>(src + s);
+            } else {
+                const float2 a = s < avail ? src[s] : make_float2(0.0f, 0.0f);
+                const float2 b = s + 1 < avail ? src[s + 1] : make_float2(0.0f, 0.0f);
+                val = make_float4(a.x, a.y, b.x, b.y);
+            }
+            *reinterpret_cast<float4*>(&lds[s]) = val;
+        }
     }
     __syncthreads();
 

@@ -57,17 +57,35 @@ __global__ void __launch_bounds__(NT, 4) k_resample3c_fast(const float* __restri
     const int avail = av64 > SPAN ? SPAN : (int)av64;
     const float2* src = reinterpret_cast<const float2*>(in) + base;
     const bool al = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
-    for (int v = threadIdx.x; v < SPAN2; v += NT) {
-        const int s = 2 * v;
-        float4 val;
-        if (al && s + 1 < avail) {
-            val = *reinterpret_cast<const float4*>(src + s);
-        } else {
-            const float2 a = s < avail ? src[s] : make_float2(0.0f, 0.0f);
-            const float2 b = s + 1 < avail ? src[s + 1] : make_float2(0.0f, 0.0f);
-            val = make_float4(a.x, a.y, b.x, b.y);
+    if (al && av64 >= 2 * SPAN2) {
+        // interior tile: every 16-byte load of the workgroup in flight before the first LDS store (a load-store loop pays one
+        // HBM round trip per iteration: 5.2 of them here)
+        constexpr int NV = (SPAN2 + NT - 1) / NT;
+        float4 val[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            int v = threadIdx.x + i * NT;
+            v = v < SPAN2 ? v : SPAN2 - 1;
+            val[i] = *reinterpret_cast<const float4*>(src + 2 * v);
         }
-        *reinterpret_cast<float4*>(&lds[s]) = val;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int v = threadIdx.x + i * NT;
+            if (v < SPAN2) *reinterpret_cast<float4*>(&lds[2 * v]) = val[i];
+        }
+    } else {
+        for (int v = threadIdx.x; v < SPAN2; v += NT) {
+            const int s = 2 * v;
+            float4 val;
+            if (al && s + 1 < avail) {
+                val = *reinterpret_cast<const float4*>(src + s);
+            } else {
+                const float2 a = s < avail ? src[s] : make_float2(0.0f, 0.0f);
+                const float2 b = s + 1 < avail ? src[s + 1] : make_float2(0.0f, 0.0f);
+                val = make_float4(a.x, a.y, b.x, b.y);
+            }
+            *reinterpret_cast<float4*>(&lds[s]) = val;
+        }
     }
     __syncthreads();
 
