@@ -428,6 +428,7 @@ __global__ void __launch_bounds__(256) k_resample_real_crossfix(Geom g, const fl
     static_assert(PER <= 32, "one 32-lane group per seam");
     constexpr int SPW = 8;                                        // seams per workgroup
     __shared__ float lds[SPW][UNI];
+    __shared__ float tl[256];
     const int tid = threadIdx.x, sl = tid >> 5, ci = tid & 31;
     const int si = blockIdx.x * SPW + sl;
     const bool live = si < nseams;
@@ -438,11 +439,23 @@ __global__ void __launch_bounds__(256) k_resample_real_crossfix(Geom g, const fl
         m_lo = m_hi - (PER - 1);
         if (m_lo < 0) m_lo = 0;
         p_lo = (m_lo * g.D + g.I - 1) / g.I;                     // inOff(m_lo): first input of the union
-        for (int e = ci; e < UNI; e += 32) {
-            const int64_t idx = p_lo + e - g.in_base;
-            lds[sl][e] = (idx >= 0 && idx < in_avail) ? in[idx] : 0.0f;
+        // branch-free (clamped index + select): the five loads of a lane are in flight together
+        constexpr int NE = (UNI + 31) / 32;
+        float ve[NE];
+#pragma unroll
+        for (int k = 0; k < NE; k++) {
+            const int64_t idx = p_lo + (ci + 32 * k) - g.in_base;
+            const bool ok = idx >= 0 && idx < in_avail;
+            const float x = in[ok ? idx : 0];
+            ve[k] = ok ? x : 0.0f;
         }
+#pragma unroll
+        for (int k = 0; k < NE; k++)
+            if (ci + 32 * k < UNI) lds[sl][ci + 32 * k] = ve[k];
     }
+    // the unpadded taps, once per workgroup (the sequential loop below would otherwise wait for a global load per tap)
+    const bool taps_in_lds = ntaps <= 256;
+    if (taps_in_lds) tl[tid] = tid < ntaps ? plain[tid] : 0.0f;
     __syncthreads();
     if (!live || ci >= PER) return;
     const int64_t m = m_lo + ci;
@@ -455,7 +468,11 @@ __global__ void __launch_bounds__(256) k_resample_real_crossfix(Geom g, const fl
     const int fo = (int)(pos * g.I - v);
     const float* x = lds[sl] + (pos - p_lo);
     float r = 0.0f;
-    for (int l = 0, j = fo; j < ntaps; l++, j += g.I) r = r + x[l] * plain[j];
+    if (taps_in_lds) {
+        for (int l = 0, j = fo; j < ntaps; l++, j += g.I) r = r + x[l] * tl[j];
+    } else {
+        for (int l = 0, j = fo; j < ntaps; l++, j += g.I) r = r + x[l] * plain[j];
+    }
     out[m - g.k_begin] = r;
 }
 
