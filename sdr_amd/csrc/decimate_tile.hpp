@@ -454,6 +454,40 @@ __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const
             re = re + x.x * h;
             im = im + x.y * h;
         }
+    } else if constexpr (LP % 16 == 0) {
+        // blocks of 16 taps, the next block's LDS reads and tap chunk issued BEFORE this block's MACs (the fence pins that
+        // order): left to itself the compiler reads four samples, waits, uses them -- 32 exposed LDS latencies and a full
+        // lgkmcnt drain per tap chunk in a kernel that is nothing but latency
+        typedef float cf16 __attribute__((ext_vector_type(16)));
+        auto chunk = [&](int b) -> cf16 {
+            typedef const __attribute__((address_space(4))) cf16* cp;
+            uint64_t a = reinterpret_cast<uint64_t>(xtaps) + 64u * (uint32_t)b;
+            asm volatile("" : "+s"(a));
+            return *reinterpret_cast<cp>(a);
+        };
+        float2 xs[2][16];
+        cf16 tc[2];
+        tc[0] = chunk(0);
+#pragma unroll
+        for (int i = 0; i < 16; i++) xs[0][i] = w[i + i / 8];
+#pragma unroll
+        for (int b = 0; b < LP / 16; b++) {
+            if (b + 1 < LP / 16) {
+                tc[(b + 1) & 1] = chunk(b + 1);
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int j = 16 * (b + 1) + i;
+                    xs[(b + 1) & 1][i] = w[j + j / 8];
+                }
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const float h = tc[b & 1][i];
+                re = re + xs[b & 1][i].x * h;
+                im = im + xs[b & 1][i].y * h;
+            }
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < LP; j++) {
