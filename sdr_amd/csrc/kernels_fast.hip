@@ -51,11 +51,10 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
         if (((base + 8 * (uintptr_t)x0) & 15) != 0) return false;
     }
     if ((reinterpret_cast<uintptr_t>(d_out) & 15) != 0) return false;
-    // Small launches (a host block per push: <= 8 tiles) compute their Cross outputs inside the main kernel: one launch
-    // instead of two.  Large launches keep the separate fix-up (a diverging wave per tile costs more than the 4 % it takes).
-    // launch-bound sizes compute their Cross outputs inside the tile kernel (abi_device.cpp: the 5v row); at full size that
-    // loses to the fix-up launch (0.87-1.0 ms against 0.71 per 2^29 samples: the straddlers' sequential loops hold whole
-    // workgroups' resources).  SDRHIP_INLINE_CROSS_MAX overrides for experiments.
+    // Launch-bound sizes (a host block per push .. a 2^20-sample shard) compute their Cross outputs inside the tile kernel:
+    // one launch instead of two (abi_device.cpp: the 5v row).  At full size that loses to the fix-up launch (0.87-1.0 ms
+    // against 0.71 per 2^29 samples: the straddlers' sequential loops hold whole workgroups' resources).
+    // SDRHIP_INLINE_CROSS_MAX overrides the bound for experiments.
     static const int64_t inl_env = getenv("SDRHIP_INLINE_CROSS_MAX") ? atoll(getenv("SDRHIP_INLINE_CROSS_MAX")) : -1;
     const int64_t inl_max = inl_env >= 0 ? inl_env : 5 * (int64_t)small_launch_outputs();
     const bool inl = g.seamBI > 0 && g.count <= inl_max;
