@@ -127,12 +127,17 @@ def cpu_baseline(seconds_single=6.0, seconds_all=8.0):
 
 # --------------------------------------------------------------------------------------
 def k2_source_sha256():
-    """Digest of the dominant kernel's sources (the tile kernel + its launcher): profiles/k2_traffic.json is only quoted
-    while it was measured on this version of them (tools/summarize_profile.py writes the same digest)."""
+    """Digest of the dominant kernel's sources (the tile kernel + its launcher) with comments and white space stripped:
+    profiles/k2_traffic.json is only quoted while it was measured on this version of the code (tools/summarize_profile.py
+    writes the same digest)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for name in ("decimate_tile.hpp", "kernels_fast.hip"):
-        h.update(open(os.path.join(ROOT, "sdr_amd", "csrc", name), "rb").read())
+        text = open(os.path.join(ROOT, "sdr_amd", "csrc", name), "r").read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        h.update(" ".join(text.split()).encode())
     return h.hexdigest()
 
 
