@@ -326,8 +326,9 @@ int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain *c, int nsub);
 /* fmDemod -> resampler -> audio filter (* gain) as ONE kernel (the demodulated and resampled streams never leave LDS)
  * when the chain has the FM receiver's shape (3/10 resampler with 64-float groups, 64 half-tap symmetric filter, AVX
  * order, buffers longer than one tile).  mode 0 = never (the three stage kernels), 1 = always, 2 = auto (default): only
- * for runs of at most one tile (2046 audio outputs, i.e. pushes of one to six 8192-sample source blocks), where one
- * launch replaces eight; on large batches the stage kernels are ~15 % faster (every stage is VALU-bound).  Same bits. */
+ * for runs of at most 768 audio outputs (pushes of one or two 8192-sample source blocks), where one launch replaces
+ * three; longer runs are faster on the stage kernels (every stage is VALU-bound, and a one-tile run is one workgroup).
+ * Same bits. */
 int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain *c, int mode);
 /* fmDemod inside the resampler's tile loader for large batches (>= 2^18 resampler outputs per run): the demodulated stream
  * never makes its round trip through HBM (12 B per decimated sample less traffic); the per-stage timing then books the pair

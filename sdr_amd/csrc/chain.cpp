@@ -18,6 +18,7 @@
 
 using namespace sdrhip;
 
+static const int kFusedTailAutoOutputs = 768;   // fused tail in auto mode: runs of at most this many audio outputs
 static const int kStages = 5;  // decimate(+seam fix-up), fmDemod, resample, filter, fused tail (fmDemod+resample+filter+gain in one kernel)
 
 struct sdrhip_fm_chain {
@@ -55,7 +56,9 @@ struct sdrhip_fm_chain {
     bool fuse_demod = getenv("SDRHIP_FUSE_DEMOD") ? atoi(getenv("SDRHIP_FUSE_DEMOD")) != 0 : false;   // fmDemod in the resampler's tile loader
     bool tail_shape_ok(int64_t n_out) const
     {
-        if (fused_tail == 0 || (fused_tail == 2 && n_out > kTailTileOutputs)) return false;
+        // auto: runs of up to two source blocks (measured per push, in place: fused 27.3 / 29.1 / 36.6 us for 1 / 2 / 4 blocks,
+        // the stage kernels on their one-launch routes 30.0 / 30.7 / 32.6 -- the single workgroup of a one-tile run is serial)
+        if (fused_tail == 0 || (fused_tail == 2 && n_out > kFusedTailAutoOutputs)) return false;
         return !resamp.cplx && resamp.lanes == 8 && !audio.cplx && audio.sym && audio.lanes == 8 && audio.factor == 1;
     }
     hipStream_t aux = nullptr;
