@@ -522,9 +522,9 @@ struct sdrhip_fm_stream {
     sdrhip_fm_chain* c = nullptr;
     int max_block = 0;
     int block_out = 0;
-    hipStream_t compute = nullptr, up = nullptr, down = nullptr;
+    hipStream_t compute = nullptr, compute2 = nullptr, up = nullptr, down = nullptr;   // compute2: odd slots of in-place pushes
     DevBuf din[2];         // device input of the two slots (copy mode)
-    DevBuf ws;
+    DevBuf ws, ws2;        // one workspace per compute stream
     int64_t N = 0;         // samples received so far
     int64_t q_done = 0;    // audio outputs computed so far
     int64_t head_cap = 0;  // samples of room in front of the staged samples (for the carried tail), multiple of 8
@@ -551,12 +551,12 @@ struct sdrhip_fm_stream {
 
     ~sdrhip_fm_stream()
     {
-        for (hipStream_t st : {up, compute, down})
+        for (hipStream_t st : {up, compute, compute2, down})
             if (st) (void)hipStreamSynchronize(st);
         for (auto& sl : slot)
             for (hipEvent_t e : {sl.ev, sl.ev_up, sl.ev_k})
                 if (e) (void)hipEventDestroy(e);
-        for (hipStream_t st : {up, compute, down})
+        for (hipStream_t st : {up, compute, compute2, down})
             if (st) (void)hipStreamDestroy(st);
     }
     int ready() const { return (int)((fifo.size() - head) / (size_t)block_out); }
@@ -592,6 +592,7 @@ int sdrhip_fm_stream_create(sdrhip_fm_stream** out, sdrhip_fm_chain* chain, int 
     st->head_cap = (sdrhip_fm_chain_max_halo(chain) + 8 + 15) / 8 * 8;
     st->hist.resize((size_t)(2 * st->head_cap));
     hipError_t e = hipStreamCreateWithFlags(&st->compute, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->compute2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->up, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->down, hipStreamNonBlocking);
     for (auto& sl : st->slot)
@@ -647,21 +648,30 @@ static int stream_submit(sdrhip_fm_stream* st)
     const int64_t n_out = q_new - st->q_done;
     const bool direct = st->direct_ok && tail + n <= st->direct_samples;
     sl.n_out = 0;
+    // In-place pushes alternate between two compute streams (and workspaces): a push of one source block is a few small
+    // kernels, i.e. latency, and nothing push i+1 computes depends on what push i left on the device (the carried tail
+    // comes from the host-side history) -- so two consecutive pushes overlap on the GPU.
+    hipStream_t cs = (direct && (si & 1)) ? st->compute2 : st->compute;
+    DevBuf& wsb_buf = (direct && (si & 1)) ? st->ws2 : st->ws;
     if (n_out > 0) {
         const size_t wsb = sdrhip_fm_chain_workspace_bytes(c, tail + n);
-        if ((rc = st->ws.ensure(wsb)) != SDRHIP_OK) return rc;
+        if (wsb > wsb_buf.cap) {
+            // growing frees the old buffer: nothing may still be using it
+            SDRHIP_CHECK_HIP(hipStreamSynchronize(cs));
+        }
+        if ((rc = wsb_buf.ensure(wsb)) != SDRHIP_OK) return rc;
         if ((rc = sl.hout.ensure((size_t)n_out * 4)) != SDRHIP_OK) return rc;
     }
     if (direct) {
         // zero-copy: the kernels read the pinned staging buffer and write the pinned result buffer themselves
         if (n_out > 0) {
-            if ((rc = sdrhip_fm_chain_run(c, (void*)st->compute, (const uint8_t*)sl.hin.dev_ptr(first), keep_from, tail + n,
-                                          (float*)sl.hout.dev, st->q_done, q_new, st->ws.p, st->ws.cap)) != SDRHIP_OK) return rc;
+            if ((rc = sdrhip_fm_chain_run(c, (void*)cs, (const uint8_t*)sl.hin.dev_ptr(first), keep_from, tail + n,
+                                          (float*)sl.hout.dev, st->q_done, q_new, wsb_buf.p, wsb_buf.cap)) != SDRHIP_OK) return rc;
             sl.n_out = n_out;
             sl.busy = true;
         }
         // ONE event per push: the results are in pinned memory and the staging buffer is free again when the kernels are done
-        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, st->compute));
+        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, cs));
         sl.direct = true;
     } else {
         DevBuf& dbuf = st->din[si];
@@ -709,7 +719,7 @@ int sdrhip_fm_stream_set_coalesce(sdrhip_fm_stream* st, int samples)
     SDRHIP_REQUIRE(st != nullptr && samples >= 0, "sdrhip_fm_stream_set_coalesce");
     SDRHIP_REQUIRE(st->staged == 0, "sdrhip_fm_stream_set_coalesce: samples are staged (flush first)");
     SDRHIP_REQUIRE(st->c->block == 0 || samples % st->c->block == 0, "sdrhip_fm_stream_set_coalesce: whole source blocks only");
-    for (hipStream_t s : {st->up, st->compute, st->down}) SDRHIP_CHECK_HIP(hipStreamSynchronize(s));   // staging buffers may be reallocated
+    for (hipStream_t s : {st->up, st->compute, st->compute2, st->down}) SDRHIP_CHECK_HIP(hipStreamSynchronize(s));   // staging buffers may be reallocated
     st->coalesce = samples;
     return SDRHIP_OK;
 }
