@@ -41,6 +41,7 @@ struct sdrhip_pipe {
     int I = 1, D = 1, Lp = 1;
 
     hipStream_t stream = nullptr;   // compute
+    hipStream_t stream2 = nullptr;  // compute, odd slots of in-place pushes (consecutive pushes overlap on the GPU)
     hipStream_t up = nullptr;       // H2D
     hipStream_t down = nullptr;     // D2H
     // device input of the two slots (copy mode), each holding [tail | blocks]; map pipes alternate them by `cur`
@@ -90,12 +91,12 @@ struct sdrhip_pipe {
 
     ~sdrhip_pipe()
     {
-        for (hipStream_t st : {up, stream, down})
+        for (hipStream_t st : {up, stream, stream2, down})
             if (st) (void)hipStreamSynchronize(st);
         for (auto& s : slot)
             for (hipEvent_t e : {s.ev, s.ev_up, s.ev_k})
                 if (e) (void)hipEventDestroy(e);
-        for (hipStream_t st : {up, stream, down})
+        for (hipStream_t st : {up, stream, stream2, down})
             if (st) (void)hipStreamDestroy(st);
     }
 };
@@ -105,6 +106,7 @@ static int pipe_new(sdrhip_pipe** out, PipeKind kind)
     sdrhip_pipe* p = new sdrhip_pipe();
     p->kind = kind;
     hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking);
     for (auto& sl : p->slot)
@@ -197,6 +199,9 @@ static int fir_submit(sdrhip_pipe* p, int n, int64_t uniform_seam)
         p->hist_n = keep;
     }
     const bool direct = p->direct_ok && (size_t)(tail + n) * ein <= sdrhip_pipe::kDirectBytes;
+    // in-place pushes alternate between two compute streams: nothing push i+1 computes depends on what push i left on the
+    // device (the carried tail comes from the host-side history), so consecutive pushes overlap on the GPU
+    hipStream_t cs = (direct && (si & 1)) ? p->stream2 : p->stream;
     const float* din = nullptr;
     if (direct) {
         din = (const float*)sl.hin.dev_ptr(first);
@@ -206,7 +211,7 @@ static int fir_submit(sdrhip_pipe* p, int n, int64_t uniform_seam)
         // slot si's device buffer was last read by the kernels of submission i-2, harvested before the slot was reopened
         SDRHIP_CHECK_HIP(hipMemcpyAsync(dbuf.p, first, (size_t)(tail + n) * ein, hipMemcpyHostToDevice, p->up));
         SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, p->up));
-        SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->stream, sl.ev_up, 0));
+        SDRHIP_CHECK_HIP(hipStreamWaitEvent(cs, sl.ev_up, 0));
         din = (const float*)dbuf.p;
     }
     const int64_t in_base = keep_from;
@@ -224,22 +229,22 @@ static int fir_submit(sdrhip_pipe* p, int n, int64_t uniform_seam)
         }
         if (uniform_seam > 0) {
             if (p->kind == PK_RESAMPLER)
-                rc = resamp_run(p->rs, p->stream, din, in_base, dout, p->m_done, m_end, uniform_seam, p->block_out);
+                rc = resamp_run(p->rs, cs, din, in_base, dout, p->m_done, m_end, uniform_seam, p->block_out);
             else
-                rc = fir_run(p->fir, p->stream, din, false, in_base, dout, p->m_done, m_end, uniform_seam);
+                rc = fir_run(p->fir, cs, din, false, in_base, dout, p->m_done, m_end, uniform_seam);
             if (rc != SDRHIP_OK) return rc;
         } else {
             const int64_t ncross = m_split - p->m_done;
             if (p->kind == PK_RESAMPLER) {
-                if (ncross > 0 && (rc = resamp_run(p->rs, p->stream, din, in_base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
-                if ((rc = resamp_run(p->rs, p->stream, din, in_base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
+                if (ncross > 0 && (rc = resamp_run(p->rs, cs, din, in_base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
+                if ((rc = resamp_run(p->rs, cs, din, in_base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
             } else {
-                if (ncross > 0 && (rc = fir_run(p->fir, p->stream, din, false, in_base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
-                if ((rc = fir_run(p->fir, p->stream, din, false, in_base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
+                if (ncross > 0 && (rc = fir_run(p->fir, cs, din, false, in_base, dout, p->m_done, m_split, -1)) != SDRHIP_OK) return rc;
+                if ((rc = fir_run(p->fir, cs, din, false, in_base, dout + ncross * p->esz_out(), m_split, m_end, 0)) != SDRHIP_OK) return rc;
             }
         }
         if (!direct) {
-            SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, p->stream));
+            SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, cs));
             SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->down, sl.ev_k, 0));
             SDRHIP_CHECK_HIP(hipMemcpyAsync(sl.hout.p, sl.dout.p, (size_t)n_out * eout, hipMemcpyDeviceToHost, p->down));
             SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, p->down));
@@ -249,7 +254,7 @@ static int fir_submit(sdrhip_pipe* p, int n, int64_t uniform_seam)
     }
     // direct mode, ONE event per push: the results are in pinned memory and the staging buffer is free again when the
     // kernels are done
-    if (direct) SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, p->stream));
+    if (direct) SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, cs));
     sl.direct = direct;
     p->m_done = m_end;
     p->E_prev = E;
