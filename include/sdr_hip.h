@@ -385,7 +385,9 @@ int sdrhip_fm_chain_halo_exchange(const sdrhip_fm_chain *chain, sdrhip_comm *com
 /* Host-block streaming front end of the chain: u8 IQ source blocks in (host memory, `block` samples
  * each or a whole multiple), audio blocks of exactly block_size_out floats out -- the five middle
  * stages of examples/fm/fm.hs:34-41 as ONE operator with every intermediate resident in HBM.  Pinned
- * staging, H2D / compute / D2H on three HIP streams, two slots: results lag one push (flush drains).
+ * staging, two slots: results lag one push (flush drains).  Large pushes: H2D / compute / D2H on three HIP streams;
+ * pushes of up to 33 source blocks: in place (the kernels read and write the pinned buffers over PCIe), two compute
+ * streams in turn so that consecutive pushes overlap on the GPU.
  * The chain must outlive the stream and must not be run concurrently by another caller. */
 typedef struct sdrhip_fm_stream sdrhip_fm_stream;
 int sdrhip_fm_stream_create(sdrhip_fm_stream **st, sdrhip_fm_chain *chain, int max_block_samples, int block_size_out);
@@ -401,9 +403,10 @@ uint8_t *sdrhip_fm_stream_input_buffer(sdrhip_fm_stream *st);
 int sdrhip_fm_stream_flush(sdrhip_fm_stream *st);
 /* Latency / throughput knob: stage pushes in the pinned buffer and submit them to the GPU together once
  * `samples` samples (a multiple of the chain's block; 0 = every push, the default) have accumulated, or on
- * flush.  One 8192-sample push costs ~80 us of launches whatever its size, so a caller that must keep the
- * reference's block size (fm.hs:17) gets ~16x the throughput from coalesce = 16 blocks, at 16 blocks of
- * latency; the audio blocks are the same.  Call with nothing staged. */
+ * flush.  One 8192-sample push costs ~19 us of launches and latency (two kernel launches, consecutive pushes
+ * overlapping on two compute streams) whatever its size, so a caller that must keep the reference's block size
+ * (fm.hs:17) gets ~10x the throughput from coalesce = 16 blocks, at 16 blocks of latency; the audio blocks are the
+ * same.  Call with nothing staged. */
 int sdrhip_fm_stream_set_coalesce(sdrhip_fm_stream *st, int samples);
 int sdrhip_fm_stream_pop(sdrhip_fm_stream *st, float *out, int capacity);
 /* Checkpoint / resume.  Between two pushes the operator's state is the stream position, the last ~4k input samples and
