@@ -477,6 +477,12 @@ float *sdrhip_pipe_input_buffer(sdrhip_pipe *p, int n);
 int sdrhip_pipe_flush(sdrhip_pipe *p);
 /* Pop one ready block into out (capacity in elements); returns its length, 0 if none. */
 int sdrhip_pipe_pop(sdrhip_pipe *p, float *out, int capacity);
+/* Checkpoint / resume, as sdrhip_fm_stream_save / _restore: save drains the pipe (like flush) and writes its state -- position,
+ * the last few input elements, the carried fmDemod sample / dcBlocker pair, the output not yet popped; restore loads it into a
+ * freshly created pipe of the same kind over a descriptor of the same taps; returns the blocks ready to pop. */
+size_t sdrhip_pipe_state_bytes(const sdrhip_pipe *p);
+int sdrhip_pipe_save(sdrhip_pipe *p, void *buf, size_t capacity, size_t *used);
+int sdrhip_pipe_restore(sdrhip_pipe *p, const void *buf, size_t bytes);
 void sdrhip_pipe_destroy(sdrhip_pipe *p);
 
 #ifdef __cplusplus

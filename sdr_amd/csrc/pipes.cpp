@@ -535,6 +535,107 @@ int sdrhip_pipe_pop(sdrhip_pipe* p, float* out, int capacity)
     return len;
 }
 
+// ---- checkpoint / resume (as sdrhip_fm_stream_save / _restore, chain.cpp) -------------------------------------------
+// Between two pushes a Pipe's state is its position (elements consumed, outputs produced), the last head_cap input elements,
+// the carried fmDemod sample / dcBlocker pair, and the output not yet popped: what the reference keeps in the Pipe's closure
+// (Filter.hs:536-727: overlap remainder, resampler (group, offset); Demod.hs:41,46; Filter.hs:730-739).
+namespace {
+struct PipeStateHeader {
+    uint32_t magic, version;
+    int32_t kind, block_out, I, D, Lp, cplx_in, cplx_out, uniform_n, all_uniform, n_blocks;
+    int64_t E_prev, m_done, head_cap, hist_n, pending;       // hist_n: elements; pending: floats in the fifo
+    float last_re, last_im, dc[4];
+};
+constexpr uint32_t kPipeMagic = 0x50504453u;   // "SDPP"
+}  // namespace
+
+size_t sdrhip_pipe_state_bytes(const sdrhip_pipe* p)
+{
+    if (p == nullptr) return 0;
+    // + what the drain inside save may add: the outputs of the staged and in-flight blocks
+    const size_t slack = (size_t)(p->staged + 2 * (p->uniform_n > 0 ? p->uniform_n : 0) + 4 * p->block_out + 65536) * 2 * sizeof(float);
+    return sizeof(PipeStateHeader) + (size_t)p->head_cap * p->esz_in() * sizeof(float) + p->fifo_size() * sizeof(float) +
+           p->demod_blocks.size() * sizeof(int32_t) + slack;
+}
+
+int sdrhip_pipe_save(sdrhip_pipe* p, void* buf, size_t capacity, size_t* used)
+{
+    SDRHIP_REQUIRE(p != nullptr && buf != nullptr && used != nullptr, "sdrhip_pipe_save");
+    int rc = sdrhip_pipe_flush(p);
+    if (rc < 0) return rc;
+    PipeStateHeader h;
+    memset(&h, 0, sizeof h);
+    h.magic = kPipeMagic;
+    h.version = 1;
+    h.kind = (int32_t)p->kind;
+    h.block_out = p->block_out;
+    h.I = p->I; h.D = p->D; h.Lp = p->Lp;
+    h.cplx_in = p->cplx_in; h.cplx_out = p->cplx_out;
+    h.uniform_n = p->uniform_n; h.all_uniform = p->all_uniform;
+    h.n_blocks = (int32_t)p->demod_blocks.size();
+    h.E_prev = p->E_prev; h.m_done = p->m_done; h.head_cap = p->head_cap; h.hist_n = p->hist_n;
+    h.pending = (int64_t)p->fifo_size();
+    h.last_re = p->last_re; h.last_im = p->last_im;
+    if (p->kind == PK_DCBLOCK && p->dc_state.p) {
+        SDRHIP_CHECK_HIP(hipStreamSynchronize(p->stream));
+        SDRHIP_CHECK_HIP(hipMemcpy(h.dc, p->dc_state.p, 16, hipMemcpyDeviceToHost));
+    }
+    const size_t hist_bytes = (size_t)h.hist_n * p->esz_in() * sizeof(float);
+    const size_t need = sizeof h + hist_bytes + (size_t)h.pending * sizeof(float) + (size_t)h.n_blocks * sizeof(int32_t);
+    if (capacity < need) {
+        set_error("sdrhip_pipe_save: %zu bytes needed, %zu given", need, capacity);
+        return SDRHIP_ERR_ARG;
+    }
+    unsigned char* o = (unsigned char*)buf;
+    memcpy(o, &h, sizeof h); o += sizeof h;
+    if (hist_bytes) memcpy(o, p->hist.data(), hist_bytes);
+    o += hist_bytes;
+    if (h.pending) memcpy(o, p->fifo.data() + p->fifo_head, (size_t)h.pending * sizeof(float));
+    o += (size_t)h.pending * sizeof(float);
+    for (int len : p->demod_blocks) { const int32_t v = len; memcpy(o, &v, sizeof v); o += sizeof v; }
+    *used = need;
+    return SDRHIP_OK;
+}
+
+int sdrhip_pipe_restore(sdrhip_pipe* p, const void* buf, size_t bytes)
+{
+    SDRHIP_REQUIRE(p != nullptr && buf != nullptr && bytes >= sizeof(PipeStateHeader), "sdrhip_pipe_restore");
+    SDRHIP_REQUIRE(p->pushes == 0 && p->E_prev == 0 && p->staged == 0 && p->fifo_size() == 0,
+                   "sdrhip_pipe_restore: only into a pipe that has not been pushed to");
+    PipeStateHeader h;
+    memcpy(&h, buf, sizeof h);
+    SDRHIP_REQUIRE(h.magic == kPipeMagic && h.version == 1, "sdrhip_pipe_restore: not a pipe state");
+    SDRHIP_REQUIRE(h.kind == (int32_t)p->kind && h.block_out == p->block_out && h.I == p->I && h.D == p->D && h.Lp == p->Lp &&
+                       h.cplx_in == (int32_t)p->cplx_in && h.cplx_out == (int32_t)p->cplx_out && h.head_cap == p->head_cap,
+                   "sdrhip_pipe_restore: the state belongs to a pipe of another kind or geometry");
+    SDRHIP_REQUIRE(h.hist_n >= 0 && h.hist_n <= h.head_cap && h.pending >= 0 && h.n_blocks >= 0 && h.E_prev >= h.hist_n && h.m_done >= 0,
+                   "sdrhip_pipe_restore: inconsistent state");
+    const size_t hist_bytes = (size_t)h.hist_n * p->esz_in() * sizeof(float);
+    SDRHIP_REQUIRE(bytes >= sizeof h + hist_bytes + (size_t)h.pending * sizeof(float) + (size_t)h.n_blocks * sizeof(int32_t),
+                   "sdrhip_pipe_restore: truncated state");
+    const unsigned char* in = (const unsigned char*)buf + sizeof h;
+    if (p->hist.size() * sizeof(float) < hist_bytes) p->hist.resize(hist_bytes / sizeof(float));
+    if (hist_bytes) memcpy(p->hist.data(), in, hist_bytes);
+    in += hist_bytes;
+    p->hist_n = h.hist_n;
+    p->E_prev = h.E_prev;
+    p->m_done = h.m_done;
+    p->uniform_n = h.uniform_n;
+    p->all_uniform = h.all_uniform != 0;
+    p->last_re = h.last_re;
+    p->last_im = h.last_im;
+    p->fifo.assign((const float*)in, (const float*)in + h.pending);
+    p->fifo_head = 0;
+    in += (size_t)h.pending * sizeof(float);
+    p->demod_blocks.clear();
+    for (int i = 0; i < h.n_blocks; i++) { int32_t v; memcpy(&v, in, sizeof v); in += sizeof v; p->demod_blocks.push_back(v); }
+    if (p->kind == PK_DCBLOCK && p->dc_state.p) {
+        SDRHIP_CHECK_HIP(hipStreamSynchronize(p->stream));       // the create call's memset
+        SDRHIP_CHECK_HIP(hipMemcpy(p->dc_state.p, h.dc, 16, hipMemcpyHostToDevice));
+    }
+    return ready_blocks(p);
+}
+
 void sdrhip_pipe_destroy(sdrhip_pipe* p) { delete p; }
 
 }  // extern "C"

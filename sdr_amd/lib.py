@@ -657,6 +657,24 @@ class Pipe(_Handle):
         ready = check(lib.sdrhip_pipe_flush(self.h), "sdrhip_pipe_flush")
         return self._pop(ready)
 
+    def save(self):
+        """sdrhip_pipe_save: drains the pipe and returns its state as bytes (blocks that became ready stay poppable)."""
+        lib.sdrhip_pipe_state_bytes.restype = C.c_size_t
+        lib.sdrhip_pipe_state_bytes.argtypes = [C.c_void_p]
+        cap = lib.sdrhip_pipe_state_bytes(self.h)
+        buf = (C.c_ubyte * cap)()
+        used = C.c_size_t()
+        lib.sdrhip_pipe_save.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        check(lib.sdrhip_pipe_save(self.h, buf, cap, C.byref(used)), "sdrhip_pipe_save")
+        return bytes(buf[: used.value])
+
+    def restore(self, state, max_block=0):
+        """max_block: fmDemod / dcBlockingFilter pipes hand blocks back at the length they came in; the longest one still
+        pending in the state (this wrapper sizes its pop buffer by the longest block it has seen pushed)."""
+        lib.sdrhip_pipe_restore.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        self._cap = max(getattr(self, "_cap", 0), int(max_block))
+        return self._pop(check(lib.sdrhip_pipe_restore(self.h, state, len(state)), "sdrhip_pipe_restore"))
+
     def _pop(self, ready):
         outs = []
         cap = max(getattr(self, "_cap", 0), self.block_size_out) * (2 if self.complex_out else 1)

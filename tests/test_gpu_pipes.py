@@ -314,3 +314,40 @@ def test_pipes_cross_the_in_place_threshold(hip, oracle):
     expd, _ = PM.fir_decimator_pipe(PM.FilterModel(oracle, t127, PM.ORDER_AVX, complex_=True, factor=8), cblocks, 1024)
     d = hip.Decimator(8, t127, hip.ORDER_AVX, complex_=True)
     _cmp(_drive(hip.firDecimator(d, 1024), cblocks), expd, "firDecimator across the in-place threshold")
+
+
+def test_pipes_save_and_restore(hip, oracle):
+    """Checkpoint / resume of every pipe kind (sdrhip_pipe_save / _restore): a pipe saved mid-stream (ragged blocks, output
+    pending), destroyed, restored into a fresh pipe over a fresh descriptor of the same taps, and fed the rest, yields the
+    uninterrupted pipe's blocks."""
+    sizes = [4096, 8192, 1000, 20000, 777, 8192, 129, 5000, 8192, 3000]
+    xc = S.cfloat_block(sum(sizes))
+    xr = S.real_block(sum(sizes))
+    taps = S.gauss_taps(100, 11)
+    half = S.taps_audio_half64()
+    rtaps = S.taps_resamp191()
+    makers = [
+        ("firDecimator", lambda: hip.firDecimator(hip.Decimator(5, taps, hip.ORDER_AVX, complex_=True), 700), xc, 2),
+        ("firFilter", lambda: hip.firFilter(hip.Filter(half, hip.ORDER_AVX, sym=True), 1024), xr, 1),
+        ("firResampler", lambda: hip.firResampler(hip.Resampler(3, 10, rtaps, hip.ORDER_AVX), 512), xr, 1),
+        ("fmDemod", lambda: hip.fmDemod(), xc, 2),
+        ("dcBlockingFilter", lambda: hip.Pipe("dc_blocker"), xr, 1),
+    ]
+    for name, make, x, width in makers:
+        blocks = _cut(x, width, sizes)
+        exp = _drive(make(), blocks)
+        for cut in (1, 4, 7):
+            first = make()
+            got = []
+            for b in blocks[:cut]:
+                got += first.push(b)
+            state = first.save()
+            del first
+            second = make()
+            got += second.restore(state, max_block=max(sizes))
+            for b in blocks[cut:]:
+                got += second.push(b)
+            got += second.flush()
+            _cmp(got, exp, f"{name}, saved after {cut} blocks")
+    with pytest.raises(hip.SdrHipError):
+        hip.fmDemod().restore(state)          # a dcBlockingFilter state into an fmDemod pipe
