@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "scratch_pool.hpp"
 
 using namespace sdrhip;
 
@@ -26,54 +27,7 @@ namespace {
 
 constexpr size_t kDirectBytes = 512 << 10;
 
-struct Ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    PinBuf hin, hout;
-    DevBuf in, out, taps, taps2, work;
-    std::vector<unsigned char> taps_now, taps2_now;   // the bytes taps / taps2 hold
-};
-
-struct Pool {
-    std::mutex mu;
-    std::vector<Ctx*> idle;
-    Ctx* acquire()
-    {
-        int dev = 0;
-        SDRHIP_DIE_HIP(hipGetDevice(&dev));
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            for (size_t i = 0; i < idle.size(); i++)
-                if (idle[i]->device == dev) {
-                    Ctx* c = idle[i];
-                    idle[i] = idle.back();
-                    idle.pop_back();
-                    return c;
-                }
-        }
-        Ctx* c = new Ctx();   // contexts live as long as the process: no destructor-order games at exit
-        c->device = dev;
-        SDRHIP_DIE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        return c;
-    }
-    void release(Ctx* c)
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        idle.push_back(c);
-    }
-};
-Pool& pool()
-{
-    static Pool* p = new Pool();
-    return *p;
-}
-struct Lease {
-    Ctx* c;
-    Lease() : c(pool().acquire()) {}
-    ~Lease() { pool().release(c); }
-    Lease(const Lease&) = delete;
-    Lease& operator=(const Lease&) = delete;
-};
+using Ctx = ScratchCtx;
 
 void die_if(int rc, const char* what)
 {
@@ -82,6 +36,19 @@ void die_if(int rc, const char* what)
         abort();
     }
 }
+
+// a leased context or abort(): the drop-in symbols cannot report
+struct Lease {
+    ScratchLease l;
+    Ctx* c;
+    Lease() : c(l.c)
+    {
+        if (!c) {
+            fprintf(stderr, "libsdr_hip: %s\n", sdrhip_last_error());
+            abort();
+        }
+    }
+};
 
 bool fits_direct(size_t in_bytes, size_t out_bytes) { return in_bytes <= kDirectBytes && out_bytes <= kDirectBytes; }
 

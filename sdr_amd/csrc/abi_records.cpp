@@ -6,54 +6,44 @@
 //   *One   = what the C SIMD kernel computes on one buffer            (FilterInternal.hs:66-71, 172-177, 335-342)
 //   *Cross = what the pure-Haskell sequential kernel computes on `drop i last ++ next` (FilterInternal.hs:397-423)
 // Host pointers in and out, synchronous, the descriptor's prepared taps stay resident on the device.  Buffers up to
-// kDirectBytes are read and written in place over PCIe (pinned staging, no copy engine): a Cross call moves a few hundred
-// bytes.  One process-wide scratch context behind a mutex, like the drop-in symbols.
+// 512 KiB are read and written in place over PCIe (pinned staging, no copy engine): a Cross call moves a few hundred
+// bytes.  Every call leases its scratch context (stream, pinned staging, device buffers) from the pool the drop-in symbols
+// use (scratch_pool.hpp), so the closures of several pipelines do not queue behind one another.
 #include <string.h>
 
-#include <mutex>
 
 #include "descriptors.hpp"
+#include "scratch_pool.hpp"
 
 using namespace sdrhip;
 
 namespace {
 
-struct RecScratch {
-    std::mutex mu;
-    hipStream_t stream = nullptr;
-    PinBuf hin, hout;
-    DevBuf din, dout;
-    static constexpr size_t kDirectBytes = 512 << 10;
-};
-RecScratch& rs()
-{
-    static RecScratch* s = new RecScratch();   // intentionally leaked (no destructor-order games at exit)
-    return *s;
-}
+using RecScratch = ScratchCtx;          // leased per call (scratch_pool.hpp): concurrent callers do not queue
+constexpr size_t kRecDirectBytes = 512 << 10;
 
 // stage `bytes` of host input (already assembled in sc.hin) and give back the device-visible input / output pointers
 int stage(RecScratch& sc, size_t in_bytes, size_t out_bytes, const float** d_in, float** d_out, bool* direct)
 {
-    if (!sc.stream) SDRHIP_CHECK_HIP(hipStreamCreateWithFlags(&sc.stream, hipStreamNonBlocking));
     int rc;
     if ((rc = sc.hout.ensure(out_bytes + 64)) != SDRHIP_OK) return rc;
-    *direct = in_bytes <= RecScratch::kDirectBytes && out_bytes <= RecScratch::kDirectBytes;
+    *direct = in_bytes <= kRecDirectBytes && out_bytes <= kRecDirectBytes;
     if (*direct) {
         *d_in = (const float*)sc.hin.dev;
         *d_out = (float*)sc.hout.dev;
         return SDRHIP_OK;
     }
-    if ((rc = sc.din.ensure(in_bytes + 64)) != SDRHIP_OK) return rc;
-    if ((rc = sc.dout.ensure(out_bytes + 64)) != SDRHIP_OK) return rc;
-    SDRHIP_CHECK_HIP(hipMemcpyAsync(sc.din.p, sc.hin.p, in_bytes, hipMemcpyHostToDevice, sc.stream));
-    *d_in = (const float*)sc.din.p;
-    *d_out = (float*)sc.dout.p;
+    if ((rc = sc.in.ensure(in_bytes + 64)) != SDRHIP_OK) return rc;
+    if ((rc = sc.out.ensure(out_bytes + 64)) != SDRHIP_OK) return rc;
+    SDRHIP_CHECK_HIP(hipMemcpyAsync(sc.in.p, sc.hin.p, in_bytes, hipMemcpyHostToDevice, sc.stream));
+    *d_in = (const float*)sc.in.p;
+    *d_out = (float*)sc.out.p;
     return SDRHIP_OK;
 }
 
 int finish(RecScratch& sc, bool direct, float* out, size_t out_bytes)
 {
-    if (!direct) SDRHIP_CHECK_HIP(hipMemcpyAsync(sc.hout.p, sc.dout.p, out_bytes, hipMemcpyDeviceToHost, sc.stream));
+    if (!direct) SDRHIP_CHECK_HIP(hipMemcpyAsync(sc.hout.p, sc.out.p, out_bytes, hipMemcpyDeviceToHost, sc.stream));
     SDRHIP_CHECK_HIP(hipStreamSynchronize(sc.stream));
     memcpy(out, sc.hout.p, out_bytes);
     return SDRHIP_OK;
@@ -80,8 +70,9 @@ int fir_one(const FirDesc* d, int num, const float* in, float* out, const char* 
     SDRHIP_REQUIRE(in != nullptr && out != nullptr, who);
     const int esz = d->cplx ? 2 : 1;
     const int64_t need = (int64_t)(num - 1) * d->factor + d->Lp;      // the elements the C kernel reads
-    RecScratch& sc = rs();
-    std::lock_guard<std::mutex> lk(sc.mu);
+    ScratchLease lease;
+    if (!lease.c) return SDRHIP_ERR_HIP;
+    RecScratch& sc = *lease.c;
     int rc = concat(sc, in, need, nullptr, 0, need, esz);
     if (rc != SDRHIP_OK) return rc;
     const float* d_in;
@@ -105,8 +96,9 @@ int fir_cross(const FirDesc* d, int num, const float* last, int n_last, const fl
         set_error("%s: %d outputs need %lld elements of last ++ next, %d + %d given", who, num, (long long)need, n_last, n_next);
         return SDRHIP_ERR_ARG;
     }
-    RecScratch& sc = rs();
-    std::lock_guard<std::mutex> lk(sc.mu);
+    ScratchLease lease;
+    if (!lease.c) return SDRHIP_ERR_HIP;
+    RecScratch& sc = *lease.c;
     int rc = concat(sc, last, n_last, next, n_next, need, esz);
     if (rc != SDRHIP_OK) return rc;
     const float* d_in;
@@ -148,8 +140,9 @@ int sdrhip_resampler_one(const sdrhip_resampler* r, int group, int num, const fl
     const int esz = r->cplx ? 2 : 1;
     const int64_t base = r->in_offset(m0);
     const int64_t need = r->in_offset(m0 + num - 1) - base + r->nloop;      // the SIMD loop walks nloop taps (zero padded)
-    RecScratch& sc = rs();
-    std::lock_guard<std::mutex> lk(sc.mu);
+    ScratchLease lease;
+    if (!lease.c) return SDRHIP_ERR_HIP;
+    RecScratch& sc = *lease.c;
     int rc = concat(sc, in, n_in, nullptr, 0, need, esz);                   // past the caller's vector the taps are zero: zero fill
     if (rc != SDRHIP_OK) return rc;
     const float* d_in;
@@ -183,8 +176,9 @@ int sdrhip_resampler_cross(const sdrhip_resampler* r, int filter_offset, int num
         set_error("sdrhip_resampler_cross: %d outputs need %lld elements of last ++ next, %d + %d given", num, (long long)need, n_last, n_next);
         return SDRHIP_ERR_ARG;
     }
-    RecScratch& sc = rs();
-    std::lock_guard<std::mutex> lk(sc.mu);
+    ScratchLease lease;
+    if (!lease.c) return SDRHIP_ERR_HIP;
+    RecScratch& sc = *lease.c;
     int rc = concat(sc, last, n_last, next, n_next, need + r->nloop, esz);
     if (rc != SDRHIP_OK) return rc;
     const float* d_in;
