@@ -453,7 +453,13 @@ def main():
                             "power-limited (DESIGN.md 7): with the same loads and no traffic its MAC phase alone takes ~0.17-0.18 ms at a "
                             "shader clock of ~1.65-1.75 GHz"}}
         dbg("cfg1 done")
-    main_run = measure(args.blocks, args.steps, args.warmup, args.passes_per_step, 0.3, True)
+    # per-stage HIP events inside the timed region (ten event records per pass) when a pass is long enough not to notice them;
+    # a launch-bound shard (e.g. --blocks 128, BASELINE configs[4]) is timed without them and its stage times come from a
+    # short separate run of the same passes
+    events_in_region = args.blocks >= 2048
+    main_run = measure(args.blocks, args.steps, args.warmup, args.passes_per_step, 0.3, events_in_region)
+    if not events_in_region:
+        main_run["stage_ms"] = measure(args.blocks, max(2, args.steps // 4), 1, main_run["passes"], 0.05, True)["stage_ms"]
     dbg("main measurement done")
     # the same run on a frequency-modulated carrier instead of uniform random bytes (the chip is power-limited and the power
     # of a multiply depends on its operands: random bytes are the most expensive input there is)
@@ -606,6 +612,7 @@ def main():
             },
             "roofline_config1_cfloat_decimate": cfg1,
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+            **({} if events_in_region else {"stage_ms_from": "a separate short run of the same passes (the timed region of a launch-bound shard carries no event records)"}),
             "tail_ms": round(tail_ms, 5),
             "fm_carrier_input": fm_input,
             "shard_1M_samples_per_gpu": shard_1m,
