@@ -108,3 +108,57 @@ def test_c_level_ring_one_process_per_rank(hip, tmp_path):
         out, err = p.communicate(timeout=300)
         assert p.returncode == 0, f"rank {r}: {err}"
         assert f"halo_ring rank {r}/{nranks}: OK (rccl" in out
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+def test_peer_copy_ring_of_several_ranks_on_one_device(hip, nranks):
+    """The single-process transport does not care that its ranks share a device: a ring of 2 / 3 / 5 ranks, each with its own
+    buffer and stream on device 0, exercises the neighbour indexing and the event ordering of sdrhip_halo_exchange_all on a
+    one-GPU box -- and then carries the whole sharded FM chain: every rank runs its shard with the halo it received, and the
+    concatenated audio equals the single-stream result (the last rank's halo is the ring's wrap-around, so it runs against
+    the stream's end instead)."""
+    import torch
+    L = hip
+    comms = L.Comm.local([0] * nranks, L.TRANSPORT_PEER_COPY)
+    ch = _chain(L)
+    halo = ch.halo_samples()
+    shard = 24 * 8192
+    total = nranks * shard
+    rng = np.random.default_rng(77 + nranks)
+    u8 = rng.integers(0, 256, 2 * total, dtype=np.uint8)
+    streams = [torch.cuda.Stream() for _ in range(nranks)]
+    bufs = []
+    for r in range(nranks):
+        b = torch.full((2 * (shard + halo),), 0xEE, dtype=torch.uint8, device="cuda")
+        b[: 2 * shard] = torch.from_numpy(u8[2 * r * shard: 2 * (r + 1) * shard]).cuda()
+        bufs.append(b)
+    torch.cuda.synchronize()
+    for _ in range(3):                      # repeated exchanges: the pull of one round is ordered before the next round's
+        L.halo_exchange_all(comms, [s.cuda_stream for s in streams], [b.data_ptr() for b in bufs],
+                            [b.data_ptr() + 2 * shard for b in bufs], 2 * halo)
+    torch.cuda.synchronize()
+    for r in range(nranks):
+        nxt = (r + 1) % nranks
+        assert np.array_equal(bufs[r][2 * shard:].cpu().numpy(), u8[2 * nxt * shard: 2 * nxt * shard + 2 * halo]), f"rank {r}"
+    # the sharded chain on those buffers
+    full_dev = torch.from_numpy(u8).cuda()
+    _, q_all, _ = ch.plan(0, total, total)
+    ws = torch.empty(ch.workspace_bytes(total + halo), dtype=torch.uint8, device="cuda")
+    ref = torch.zeros(q_all, dtype=torch.float32, device="cuda")
+    ch.run(full_dev.data_ptr(), 0, total, ref.data_ptr(), 0, q_all, ws.data_ptr(), ws.numel())
+    torch.cuda.synchronize()
+    pieces = []
+    for r in range(nranks):
+        s0, s1 = r * shard, (r + 1) * shard
+        q0, q1, _ = ch.plan(s0, s1, total)
+        n_in = shard + (halo if r + 1 < nranks else 0)      # the last shard ends with the stream
+        out = torch.zeros(q1 - q0, dtype=torch.float32, device="cuda")
+        with torch.cuda.stream(streams[r]):
+            ch.run(bufs[r].data_ptr(), s0, n_in, out.data_ptr(), q0, q1, ws.data_ptr(), ws.numel(), stream=streams[r].cuda_stream)
+        streams[r].synchronize()
+        pieces.append(out)
+    got = torch.cat(pieces)
+    assert got.numel() == q_all
+    assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), "sharded chain over the exchanged halos vs the single stream"
+    for c in comms:
+        c.close()
