@@ -450,3 +450,35 @@ def test_fm_stream_save_and_restore(hip, oracle, blocks_per_push):
     other = hip.FmStream(chain2, 8 * B, 4096)
     with pytest.raises(hip.SdrHipError):
         other.restore(state)                             # another output block size
+
+
+def test_fm_stream_many_mixed_pushes(hip):
+    """A long stream of pushes of mixed sizes -- one block (fused tail, in place), a few (stage kernels, in place, the two
+    compute streams in turn), 33 and 40 blocks (copy engines) -- zero-copy and memcpy pushes interleaved: every audio sample
+    equals the device-resident run over the whole stream.  (What a race between consecutive pushes on the two compute streams,
+    or a stale workspace / history, would break.)"""
+    rng = np.random.default_rng(515 + SWEEP_SEED)
+    choices = np.array([1, 1, 1, 2, 3, 7, 16, 33, 40, 1, 2])
+    pattern = rng.choice(choices, size=min(300 * SWEEP_SCALE, 6000))
+    nblk = int(pattern.sum())
+    total = nblk * B
+    u8 = torch.randint(0, 256, (2 * total,), dtype=torch.uint8)
+    chain = _chain(hip)
+    _, q1, _ = chain.plan(0, total, total)
+    ref = _run(hip, chain, u8.cuda(), 0, total, 0, q1)
+    st = hip.FmStream(_chain(hip), 40 * B, B)
+    host = u8.numpy()
+    got, pos = [], 0
+    for k, n in enumerate(pattern):
+        chunk = host[2 * pos * B: 2 * (pos + n) * B]
+        if k % 3 == 1:
+            view = st.input_buffer(n * B)
+            view[: chunk.size] = chunk
+            got += st.push_inplace(view[: chunk.size])
+        else:
+            got += st.push(chunk)
+        pos += n
+    got += st.flush()
+    got = np.concatenate(got)
+    assert got.size == q1 // B * B
+    assert_bit_equal(got, ref[: got.size], "mixed pushes vs resident run")
