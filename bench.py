@@ -126,6 +126,65 @@ def cpu_baseline(seconds_single=6.0, seconds_all=8.0):
 
 
 # --------------------------------------------------------------------------------------
+def self_launch(n):
+    """Re-run this command line under torch.distributed.run with n ranks on this node (free rendezvous port on
+    127.0.0.1 -- the container's host name may not resolve).  Returns the launcher's exit code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def plumbing_check(args, rank, world):
+    """BENCH_PLUMBING=1: everything of an N-rank run EXCEPT the device work -- launch, rendezvous, shard plans from the
+    library, the halo exchange (over gloo on host tensors), barrier + max-over-ranks timing -- so that the launch logic of
+    `python bench.py --gpus N` can be tested where there is no GPU.  The line it prints is marked plumbing_only and carries
+    no throughput."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import sdr_amd.lib as L
+    import signals as S
+    from sdr_amd import sharding
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    chain = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), gain=0.2, block=BLOCK)
+    S_len = min(args.blocks, 16) * BLOCK
+    plan = sharding.ShardPlan(chain, rank, world, S_len)
+    stream = S.iq_u8(world * S_len + plan.halo_cap)                # the same global stream on every rank
+    buf = torch.zeros(2 * plan.n_in, dtype=torch.uint8)
+    buf[:2 * S_len] = torch.from_numpy(stream[2 * plan.s0:2 * plan.s1].copy())
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        sharding.halo_exchange(buf, plan, dist)
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    right0 = ((rank + 1) % world) * S_len
+    ok = bool(np.array_equal(buf[2 * S_len:].numpy(), stream[2 * right0:2 * (right0 + plan.halo_cap)])) or world == 1
+    plans = [(plan.q0, plan.q1, ok)]
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        plans = [None] * world
+        dist.all_gather_object(plans, (plan.q0, plan.q1, ok))
+    if rank == 0:
+        tiles = all(a[1] == b[0] for a, b in zip(plans[:-1], plans[1:]))
+        print(json.dumps({"plumbing_only": True, "metric": "none (BENCH_PLUMBING=1: launch, plans and halo exchange only, no device work)",
+                          "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks_seen": len(plans),
+                          "halo_ok_on_every_rank": all(p[2] for p in plans), "owned_outputs_tile_the_stream": tiles,
+                          "halo_transport": "host memory through gloo", "seconds": round(float(el.item()), 4)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def k2_source_sha256():
     """Digest of the dominant kernel's sources (the tile kernel + its launcher) with comments and white space stripped:
     profiles/k2_traffic.json is only quoted while it was measured on this version of the code (tools/summarize_profile.py
@@ -160,9 +219,22 @@ def main():
         print(json.dumps({"sps": sps, "kind": kind}))
         return
 
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU), exactly
+        # the command line the driver uses, and hand back its exit code -- a plain `--gpus 8` must never run as one rank.
+        sys.exit(self_launch(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report n_gpus != --gpus\n")
+        sys.exit(2)
+    if os.environ.get("BENCH_PLUMBING") == "1":
+        plumbing_check(args, rank, world)
+        return
 
     # CPU baseline first (rank 0, N=1 only), before the GPU is touched
     cpu = None
@@ -590,6 +662,9 @@ def main():
                 "ms_per_pass": round(elapsed / (args.steps * passes) * 1e3, 4),
                 "sharding": "none" if world == 1 else f"contiguous shards x{world}, halo exchange of {plan.halo_cap} samples per pass"
                             + (", overlapped with the outputs that need no halo" if main_run["overlap"] else ""),
+                "ranks_seen_by_rccl": None if comm is None else comm.size,
+                "devices_visible": ndev,
+                **({"ranks_share_devices": True} if world > ndev else {}),
                 "halo_transport": None if world == 1 else ("rccl: ncclSend/ncclRecv inside libsdr_hip.so (sdrhip_fm_chain_halo_exchange) on the compute stream"
                                                            if comm is not None else "host memory through gloo (fallback / plumbing check)"),
                 "order": "AVX (bit-exact vs reference AVX path)",

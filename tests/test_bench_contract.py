@@ -31,3 +31,27 @@ def test_bench_emits_the_contract_fields():
     assert "Msamples/s" in base["metric"] and '"unit": "Msamples/s"' in src
     assert base["published"] == {} and '"vs_baseline": None' in src
     assert re.search(r"BLOCK = 8192", src)
+
+
+def test_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher around it must run as TWO ranks (it ran as one and printed
+    n_gpus 1).  BENCH_PLUMBING=1 leaves out the device work only: launch, rendezvous, the library's shard plans, the halo
+    exchange over gloo and the max-over-ranks timing all run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["BENCH_PLUMBING"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout                       # ONE JSON line, from rank 0
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2
+    assert r["halo_ok_on_every_rank"] and r["owned_outputs_tile_the_stream"]
+    assert r["plumbing_only"] is True and r["value"] is None  # never mistaken for a measurement
+
+
+def test_world_size_that_disagrees_with_gpus_is_refused():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BENCH_PLUMBING="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-extras"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 2 and "refusing" in out.stderr
