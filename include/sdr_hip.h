@@ -330,6 +330,18 @@ int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain *c, int nsub);
  * three; longer runs are faster on the stage kernels (every stage is VALU-bound, and a one-tile run is one workgroup).
  * Same bits. */
 int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain *c, int mode);
+/* The WHOLE chain (convert + decimator -> fmDemod -> resampler -> audio filter * gain) as ONE kernel for launch-bound runs
+ * -- BASELINE configs[4]'s 2^20-sample shard, a push of a few source blocks -- when the chain has the FM receiver's shape
+ * (decimation 8 with 128 padded taps, 3/10 resampler with 64-float groups, 64 half-tap symmetric filter, AVX order, 16-byte
+ * aligned input whose first sample index is a multiple of 8).  Nothing goes through the workspace; every workgroup recomputes
+ * the overlap of its tile (the first stage is computed ~1.9 times over), which pays exactly while a run is bound by launch
+ * latency, not by arithmetic.  mode 0 = never, 1 = always, 2 = auto (default): runs of at most max_outputs audio outputs
+ * (0 = the built-in bound, 159 * 512 = 2^21 input samples).  tile_outputs: audio outputs per workgroup (multiple of 3, at most
+ * 159; 0 = chosen from the size of the run: about one workgroup per CU).  Same bits as the stage kernels
+ * (examples/fm/fm.hs:34-41; c_sources/decimate.c:105-113, resample.c:70-87, filter.c:60-68; Demod.hs:21-46). */
+int sdrhip_fm_chain_set_small_chain(sdrhip_fm_chain *c, int mode, int64_t max_outputs, int tile_outputs);
+/* launches of that kernel so far, process-wide (tests assert that this path, not the stage kernels, ran) */
+long long sdrhip_debug_small_chain_launches(void);
 /* fmDemod inside the resampler's tile loader for large batches (>= 2^18 resampler outputs per run): the demodulated stream
  * never makes its round trip through HBM (12 B per decimated sample less traffic); the per-stage timing then books the pair
  * under `resample`.  Same bits.  Off by default (environment SDRHIP_FUSE_DEMOD=1 turns it on): measured, the pair takes
@@ -337,12 +349,13 @@ int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain *c, int mode);
  * and the whole chain gains 0.5-1 %. */
 int sdrhip_fm_chain_set_demod_fusion(sdrhip_fm_chain *c, int enable);
 /* Per-stage timing with HIP events recorded around each stage's kernels on the stream they are
- * launched on; stages {decimate(+seam fix-up), fmDemod, resample, filter(+gain), fused tail (the three in one kernel)}.
+ * launched on; stages {decimate(+seam fix-up), fmDemod, resample, filter(+gain), fused tail (the three in one kernel),
+ * whole chain in one kernel (sdrhip_fm_chain_set_small_chain)}.
  * read_timing waits for the recorded runs, returns the SUM of elapsed ms per stage over
  * `*runs` runs and resets the recorder.  With pipelining on, stages of neighbouring sub-batches
  * overlap in time, so the per-stage sums add up to more than the run's wall time. */
 int sdrhip_fm_chain_enable_timing(sdrhip_fm_chain *c, int enable);
-int sdrhip_fm_chain_read_timing(sdrhip_fm_chain *c, double ms_sum[5], int *runs);
+int sdrhip_fm_chain_read_timing(sdrhip_fm_chain *c, double ms_sum[6], int *runs);
 
 /* ---- multi-GPU: the ntaps-1 halo exchange of the sharded chain ---- */
 /* The reference has no multi-device code; these entry points are what a sharded host (one thread or process per

@@ -19,7 +19,10 @@
 using namespace sdrhip;
 
 static const int kFusedTailAutoOutputs = 768;   // fused tail in auto mode: runs of at most this many audio outputs
-static const int kStages = 5;  // decimate(+seam fix-up), fmDemod, resample, filter, fused tail (fmDemod+resample+filter+gain in one kernel)
+static const int kStages = 6;  // decimate(+seam fix-up), fmDemod, resample, filter, fused tail (fmDemod+resample+filter+gain in one kernel), whole chain in one kernel
+// the whole chain as ONE kernel (kernels_small.hip) in auto mode: runs of at most this many audio outputs -- 2^21 input samples;
+// measured on MI355X (tools/shard_pass_probe.py): see DESIGN.md 5 "one-kernel chain"
+static const int64_t kSmallChainAutoOutputs = 159 * 512;
 
 struct sdrhip_fm_chain {
     FirDesc decim;     // complex, factor D1
@@ -59,6 +62,18 @@ struct sdrhip_fm_chain {
         // auto: runs of up to two source blocks (measured per push, in place: fused 27.3 / 29.1 / 36.6 us for 1 / 2 / 4 blocks,
         // the stage kernels on their one-launch routes 30.0 / 30.7 / 32.6 -- the single workgroup of a one-tile run is serial)
         if (fused_tail == 0 || (fused_tail == 2 && n_out > kFusedTailAutoOutputs)) return false;
+        return !resamp.cplx && resamp.lanes == 8 && !audio.cplx && audio.sym && audio.lanes == 8 && audio.factor == 1;
+    }
+    // The whole chain as one kernel for launch-bound runs (kernels_small.hip): 0 = never, 1 = whenever the configuration is the
+    // one it is written for, 2 = auto (runs of at most small_chain_max audio outputs): sdrhip_fm_chain_set_small_chain,
+    // SDRHIP_SMALL_CHAIN=0/1/2, SDRHIP_SMALL_CHAIN_MAX=<outputs>, SDRHIP_SMALL_CHAIN_TILE=<audio outputs per workgroup, 0 = by size>.
+    int small_chain = getenv("SDRHIP_SMALL_CHAIN") ? atoi(getenv("SDRHIP_SMALL_CHAIN")) : 2;
+    int64_t small_chain_max = getenv("SDRHIP_SMALL_CHAIN_MAX") ? atoll(getenv("SDRHIP_SMALL_CHAIN_MAX")) : kSmallChainAutoOutputs;
+    int small_chain_tile = getenv("SDRHIP_SMALL_CHAIN_TILE") ? atoi(getenv("SDRHIP_SMALL_CHAIN_TILE")) : 0;
+    bool small_chain_ok(int64_t n_out) const
+    {
+        if (small_chain == 0 || (small_chain == 2 && n_out > small_chain_max)) return false;
+        if (!(decim.factor == 8 && decim.Lp == 128 && decim.corder == CO_L4 && !decim.h_scaled.empty())) return false;
         return !resamp.cplx && resamp.lanes == 8 && !audio.cplx && audio.sym && audio.lanes == 8 && audio.factor == 1;
     }
     hipStream_t aux = nullptr;
@@ -259,9 +274,45 @@ int sdrhip_fm_chain_run(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
     SDRHIP_REQUIRE(d_in_iq && d_audio && d_workspace, "sdrhip_fm_chain_run");
     hipStream_t s = (hipStream_t)stream;
 
+    const int64_t nq = q1 - q0;
+    if (c->small_chain_ok(nq)) {
+        // launch-bound run: the whole chain in ONE kernel, nothing through the workspace
+        const int64_t kd0 = c->resamp.in_offset(q0) > 0 ? c->resamp.in_offset(q0) - 1 : 0;
+        const int64_t kd1 = c->resamp.in_offset(q1 + c->audio.Lp - 2) + c->y_reach();
+        const int64_t n_lo = kd0 * c->decim.factor, n_hi = (kd1 - 1) * c->decim.factor + c->decim.Lp;
+        if (n_lo < s0 || n_hi > s0 + n_in) {
+            set_error("sdrhip_fm_chain_run: outputs [%lld,%lld) need samples [%lld,%lld) but d_in holds [%lld,%lld)",
+                      (long long)q0, (long long)q1, (long long)n_lo, (long long)n_hi, (long long)s0, (long long)(s0 + n_in));
+            return SDRHIP_ERR_ARG;
+        }
+        int rc2;
+        if ((rc2 = c->decim.ensure_device()) != SDRHIP_OK || (rc2 = c->resamp.ensure_device()) != SDRHIP_OK ||
+            (rc2 = c->audio.ensure_device()) != SDRHIP_OK) return rc2;
+        hipEvent_t b = nullptr, e = nullptr;
+        if (c->timing) {
+            if ((rc2 = c->new_event(&b)) != SDRHIP_OK) return rc2;
+            SDRHIP_CHECK_HIP(hipEventRecord(b, s));
+        }
+        const bool last_zero = (int)c->decim.h_plain.size() == c->decim.Lp && c->decim.h_plain[c->decim.Lp - 1] == 0.0f;
+        const bool took = launch_fm_chain_small(s, d_in_iq, s0, n_in, d_audio, q0, q1, c->decim.factor, c->decim.Lp, c->decim.d_scaled, last_zero,
+                                                c->resamp.d_groups, c->resamp.row_stride, c->resamp.nloop, c->resamp.increments.data(),
+                                                c->resamp.num_groups, c->resamp.I, c->resamp.D, c->resamp.Lp, c->resamp.d_plain, c->resamp.ntaps,
+                                                c->audio.d_taps, c->audio.ntaps_kernel, c->audio.d_cross, c->gain, c->block, c->small_chain_tile);
+        if (took) {
+            if (c->timing) {
+                if ((rc2 = c->new_event(&e)) != SDRHIP_OK) return rc2;
+                SDRHIP_CHECK_HIP(hipEventRecord(e, s));
+                c->spans.push_back({5, b, e});
+                c->runs++;
+            }
+            SDRHIP_CHECK_HIP(hipGetLastError());
+            return SDRHIP_OK;
+        }
+        if (c->timing && c->ev_used > 0) c->ev_used--;      // not this configuration after all: the stage kernels below
+    }
+
     // sub-batches: equal slices of the output range, each with its own back-to-front input ranges
     int nsub = c->nsub;
-    const int64_t nq = q1 - q0;
     if (nq < (int64_t)nsub * 65536) nsub = (int)(nq / 65536);   // below ~2^21 input samples a slice is launch-bound
     if (nsub < 1) nsub = 1;
     if (nsub > 16) nsub = 16;
@@ -462,6 +513,17 @@ int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain* c, int enable)
     c->fused_tail = enable;
     return SDRHIP_OK;
 }
+
+int sdrhip_fm_chain_set_small_chain(sdrhip_fm_chain* c, int mode, int64_t max_outputs, int tile_outputs)
+{
+    SDRHIP_REQUIRE(c != nullptr && mode >= 0 && mode <= 2 && tile_outputs >= 0, "sdrhip_fm_chain_set_small_chain");
+    c->small_chain = mode;
+    c->small_chain_max = max_outputs > 0 ? max_outputs : kSmallChainAutoOutputs;
+    c->small_chain_tile = tile_outputs;
+    return SDRHIP_OK;
+}
+
+long long sdrhip_debug_small_chain_launches(void) { return fm_chain_small_launch_count(); }
 
 int sdrhip_fm_chain_set_demod_fusion(sdrhip_fm_chain* c, int enable)
 {

@@ -201,6 +201,49 @@ struct Stage {
     }
 };
 
+// Cross outputs computed inside a tile kernel (small launches: no fix-up launch).  An output whose window straddles a buffer
+// boundary of the reference's Pipes is recomputed in the reference's sequential order (decimateCrossHighLevel,
+// FilterInternal.hs:397-402) from the same LDS tile.  `taps` IS the plain tap array in tap order (for u8 input pre-scaled
+// by 1/128 like the samples in LDS are un-scaled: the products are the reference's, see Stage::store); the window of
+// output r starts r*D samples into the thread's.  All R chains advance together (a thread's outputs usually straddle
+// together), IS taps per step so that the LDS reads and the tap load of a step are in flight at once.
+#ifndef SDRHIP_INL_STEP
+#define SDRHIP_INL_STEP 4
+#endif
+template <int D, int R, class T, int TC, bool GUARD>
+__device__ __forceinline__ void inline_cross_outputs(const float2* __restrict__ win, const float* __restrict__ taps, int plen,
+                                                     const bool (&cross)[R], float2 (&res)[R])
+{
+    float re[R], im[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) re[r] = im[r] = 0.0f;
+    constexpr int IS = (TC % SDRHIP_INL_STEP == 0 || SDRHIP_INL_STEP % TC == 0) && (!GUARD || SDRHIP_INL_STEP <= TC) ? SDRHIP_INL_STEP : 4;
+#pragma unroll 1
+    for (int j0 = 0; j0 < plen; j0 += IS) {           // plen is a multiple of TC (4 or 8)
+        float2 x[R][IS];
+        float h[IS];
+#pragma unroll
+        for (int u = 0; u < IS; u++) {
+            h[u] = taps[j0 + u];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int sidx = r * D + j0 + u;
+                x[r][u] = win[sidx + 2 * (sidx / T::CHUNK)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < IS; u++)
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                re[r] = re[r] + x[r][u].x * h[u];
+                im[r] = im[r] + x[r][u].y * h[u];
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if (cross[r]) res[r] = make_float2(re[r], im[r]);
+}
+
 // The partial sums of one output and their fold (ComplexOrder of kernels.hpp):
 //   NP = 4, ORD 0  "RC"  AVX   (L0 + L1) + (L2 + L3)                               decimate.c:105-113, common.h:82-90
 //   NP = 2, ORD 0  "RC"  SSE   L0 + L1                                             decimate.c:84-93,  common.h:77-80
@@ -288,43 +331,7 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
             cross[r] = rr + plen > inl_seam;
             any |= cross[r];
         }
-        if (any) {
-            // `taps` IS the plain tap array in tap order (for u8 input pre-scaled by 1/128 like the samples in LDS are
-            // un-scaled: the products are the reference's, see Stage::store); the window of output r starts r*D samples
-            // into the thread's.  All R chains advance together (a thread's outputs usually straddle together), four taps
-            // per step so that the LDS reads and the tap load of a step are in flight at once.
-            float re[R], im[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) re[r] = im[r] = 0.0f;
-#ifndef SDRHIP_INL_STEP
-#define SDRHIP_INL_STEP 4
-#endif
-            constexpr int IS = (TC % SDRHIP_INL_STEP == 0 || SDRHIP_INL_STEP % TC == 0) && (!GUARD || SDRHIP_INL_STEP <= TC) ? SDRHIP_INL_STEP : 4;
-#pragma unroll 1
-            for (int j0 = 0; j0 < plen; j0 += IS) {           // plen is a multiple of TC (4 or 8)
-                float2 x[R][IS];
-                float h[IS];
-#pragma unroll
-                for (int u = 0; u < IS; u++) {
-                    h[u] = taps[j0 + u];
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const int sidx = r * D + j0 + u;
-                        x[r][u] = win[sidx + 2 * (sidx / T::CHUNK)];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < IS; u++)
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        re[r] = re[r] + x[r][u].x * h[u];
-                        im[r] = im[r] + x[r][u].y * h[u];
-                    }
-            }
-#pragma unroll
-            for (int r = 0; r < R; r++)
-                if (cross[r]) res[r] = make_float2(re[r], im[r]);
-        }
+        if (any) inline_cross_outputs<D, R, T, TC, GUARD>(win, taps, plen, cross, res);
     }
     if (R % 2 == 0 && o + R <= count) {
         float4* dst = reinterpret_cast<float4*>(out + 2 * (int64_t)o);

@@ -146,6 +146,14 @@ bool launch_fm_tail_fused(hipStream_t s, const float* d_d, int64_t kd0, int64_t 
                           int64_t q0, int64_t q1, const float* d_groups, int row_stride, int nloop, const int* increments,
                           int ngroups, int I, int D, int rLp, const float* d_rplain, int ntaps, const float* d_fhalf, int nhalf,
                           const float* d_fplain, float gain, int64_t seam);
+// kernels_small.hip: the WHOLE chain (u8 IQ -> /8 decimator -> fmDemod -> 3/10 resampler -> symmetric filter * gain) as one
+// kernel for launch-bound runs; d_in holds samples [s0, s0 + n_in).  tile_outputs: audio outputs per workgroup (0 = chosen
+// from the size of the run).  false = the configuration is not the FM chain's, nothing launched
+bool launch_fm_chain_small(hipStream_t s, const uint8_t* d_in, int64_t s0, int64_t n_in, float* d_audio, int64_t q0, int64_t q1,
+                           int dD, int dP, const float* d_dscaled, bool last_tap_zero, const float* d_groups, int row_stride, int nloop,
+                           const int* increments, int ngroups, int I, int D, int rLp, const float* d_rplain, int ntaps,
+                           const float* d_fhalf, int nhalf, const float* d_fplain, float gain, int64_t seam, int tile_outputs);
+long long fm_chain_small_launch_count();   // diagnostics: launches of the one-kernel chain so far
 // abi_device.cpp: the short-seamed-launch scale v (sdrhip_set_small_launch_outputs)
 int small_launch_outputs();
 

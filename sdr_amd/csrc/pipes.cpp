@@ -331,10 +331,14 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
     // buffer can be re-allocated below (growth keeps the lent region, so the data is then already in place)
     const bool in_place = p->slot[p->pushes & 1].hin.p != nullptr &&
                           block == p->staged_base(p->slot[p->pushes & 1]) + (size_t)p->staged * p->esz_in();
+    const uint64_t pushes_at_entry = (uint64_t)p->pushes;
     if (!coalescing && p->staged > 0) {
         // a block of another size ends the uniform run: what is staged goes out as one uniform batch first
         if ((rc = fir_submit(p, p->staged, p->uniform_n)) != SDRHIP_OK) return rc;
     }
+    // that submission moved on to the other slot: a block the caller wrote into the OLD slot's lent region (still intact:
+    // the submitted run ends where the lent region starts) is not in place any more and must be copied like any other
+    const bool still_in_place = in_place && (uint64_t)p->pushes == pushes_at_entry;
     // the block must be acceptable to the reference's Pipe where it arrives
     const int64_t m_pending = p->staged > 0 ? ((p->E_prev + p->staged) * p->I >= p->Lp ? ((p->E_prev + p->staged) * p->I - p->Lp) / p->D + 1 : 0)
                                              : p->m_done;
@@ -344,7 +348,7 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
     const int64_t cap = coalescing ? (int64_t)p->coalesce * p->uniform_n : n;
     if ((rc = fir_open_slot(p, (size_t)(cap > p->staged + n ? cap : p->staged + n))) != SDRHIP_OK) return rc;
     float* dst = p->staged_base(p->slot[p->pushes & 1]) + (size_t)p->staged * p->esz_in();
-    if (!in_place) memcpy(dst, block, (size_t)n * ein);   // else: the caller filled the staging buffer in place
+    if (!still_in_place) memcpy(dst, block, (size_t)n * ein);   // else: the caller filled the staging buffer in place
     p->lent = 0;
     p->staged += n;
     if (!coalescing) {

@@ -127,6 +127,8 @@ lib.sdrhip_fm_chain_graph_destroy.argtypes = [_vp]
 lib.sdrhip_fm_chain_graph_destroy.restype = None
 lib.sdrhip_fm_chain_set_pipelining.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_set_fused_tail.argtypes = [_vp, C.c_int]
+lib.sdrhip_fm_chain_set_small_chain.argtypes = [_vp, C.c_int, _i64, C.c_int]
+lib.sdrhip_debug_small_chain_launches.restype = C.c_longlong
 lib.sdrhip_fm_chain_enable_timing.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_read_timing.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
@@ -434,7 +436,7 @@ class FmChain(_Handle):
     def workspace_bytes(self, n_in):
         return lib.sdrhip_fm_chain_workspace_bytes(self.h, n_in)
 
-    STAGES = ("decimate", "fm_demod", "resample", "filter", "fused_tail")
+    STAGES = ("decimate", "fm_demod", "resample", "filter", "fused_tail", "fused_chain")
 
     def set_pipelining(self, nsub):
         check(lib.sdrhip_fm_chain_set_pipelining(self.h, nsub), "sdrhip_fm_chain_set_pipelining")
@@ -442,6 +444,10 @@ class FmChain(_Handle):
     def set_fused_tail(self, mode=2):
         """0 = stage kernels, 1 = the fused tail kernel wherever the chain's shape allows, 2 = auto (short runs only)."""
         check(lib.sdrhip_fm_chain_set_fused_tail(self.h, int(mode)), "sdrhip_fm_chain_set_fused_tail")
+
+    def set_small_chain(self, mode=2, max_outputs=0, tile_outputs=0):
+        """0 = never, 1 = always, 2 = auto: the whole chain as one kernel for launch-bound runs (kernels_small.hip)."""
+        check(lib.sdrhip_fm_chain_set_small_chain(self.h, int(mode), int(max_outputs), int(tile_outputs)), "sdrhip_fm_chain_set_small_chain")
 
     def set_demod_fusion(self, on=True):
         """fmDemod inside the resampler's tile loader on large batches (sdrhip_fm_chain_set_demod_fusion)."""
@@ -452,7 +458,7 @@ class FmChain(_Handle):
 
     def read_timing(self):
         """-> (dict stage -> mean ms per run, runs)"""
-        ms = (C.c_double * 5)()
+        ms = (C.c_double * 6)()
         runs = C.c_int()
         check(lib.sdrhip_fm_chain_read_timing(self.h, ms, C.byref(runs)), "sdrhip_fm_chain_read_timing")
         n = max(runs.value, 1)

@@ -330,6 +330,7 @@ def test_fused_tail_equals_stage_kernels(hip, oracle, block):
     u8 = S.iq_u8_fm(total)
     d = to_dev(u8)
     ch = _chain(hip, block=block)
+    ch.set_small_chain(0)                      # this test is about the tail kernels: not the one-kernel chain
     q0, q1, _ = ch.plan(0, total, total)
     rng = np.random.default_rng(77 + SWEEP_SEED)
     ranges = [(0, q1), (0, 2046), (0, 2047), (1, 700), (2047, 2047 + 4093), (q1 - 5000, q1)]
@@ -348,6 +349,86 @@ def test_fused_tail_equals_stage_kernels(hip, oracle, block):
         got = _run(hip, ch, d, 0, total, 0, q1)
         assert exp.size >= B
         assert_bit_equal(got[: exp.size], exp, "fused tail vs restated pipes")
+
+
+@pytest.mark.parametrize("block", [B, 0, 3 * B, 1000, 200])
+def test_small_chain_equals_stage_kernels(hip, oracle, block):
+    """kernels_small.hip (the WHOLE chain in one kernel: convert + decimator, fmDemod, resampler, filter, Cross outputs of
+    every stage decided in-kernel) against the stage kernels + their seam fix-ups: whole runs, runs that start and end
+    mid-tile, one-output runs, every tile size, shards that start inside the stream (s0 > 0, right halo only)."""
+    nblk = 70
+    total = nblk * B
+    u8 = S.iq_u8_fm(total) if block != 1000 else S.iq_u8(total)
+    d = to_dev(u8)
+    ch = _chain(hip, block=block)
+    q0, q1, _ = ch.plan(0, total, total)
+    rng = np.random.default_rng(177 + SWEEP_SEED)
+    ranges = [(0, q1), (0, 159), (0, 160), (1, 2), (2, 700), (158, 158 + 4093), (q1 - 5000, q1), (q1 - 1, q1)]
+    for _ in range(6 * SWEEP_SCALE):
+        a = int(rng.integers(0, q1 - 10))
+        ranges.append((a, int(min(q1, a + rng.integers(1, 9000)))))
+    tiles = [0, 159, 96, 48, 3]
+    for i, (a, b) in enumerate(ranges):
+        ch.set_small_chain(0)
+        ref = _run(hip, ch, d, 0, total, a, b)
+        n0 = hip.lib.sdrhip_debug_small_chain_launches()
+        ch.set_small_chain(1, 0, tiles[i % len(tiles)])
+        got = _run(hip, ch, d, 0, total, a, b)
+        assert hip.lib.sdrhip_debug_small_chain_launches() == n0 + 1, "the one-kernel chain did not take the run"
+        assert_bit_equal(got, ref, f"one-kernel chain, block {block}, tile {tiles[i % len(tiles)]}, outputs [{a},{b})")
+    # shards: only [s0, s1 + halo) resident, global indices
+    for nshards in (3, 7):
+        S_len = total // nshards // 8 * 8
+        for r in range(nshards):
+            s0 = r * S_len
+            s1 = total if r == nshards - 1 else (r + 1) * S_len
+            a, b, halo = ch.plan(s0, s1, total)
+            n_in = min(total, s1 + halo) - s0
+            shard = to_dev(u8[2 * s0: 2 * (s0 + n_in)])
+            ch.set_small_chain(0)
+            ref = _run(hip, ch, shard, s0, n_in, a, b)
+            ch.set_small_chain(1)
+            got = _run(hip, ch, shard, s0, n_in, a, b)
+            assert_bit_equal(got, ref, f"one-kernel chain, block {block}, shard {r} of {nshards}")
+    if block == B:
+        exp = _model(oracle, u8, nblk)
+        ch.set_small_chain(1)
+        got = _run(hip, ch, d, 0, total, 0, q1)
+        assert exp.size >= B
+        assert_bit_equal(got[: exp.size], exp, "one-kernel chain vs restated pipes")
+
+
+def test_small_chain_on_eight_shards_of_2_to_the_20(hip, oracle):
+    """BASELINE configs[4]'s geometry on one device: 8 shards of exactly 2^20 samples (+ right halo), each through the
+    one-kernel chain (the route sdrhip_fm_chain_run takes by itself at this size), bit-equal to the single stream on the
+    stage kernels -- and, over the first blocks, to the restated Pipes."""
+    S_len, nshards = 1 << 20, 8
+    chain = _chain(hip)
+    halo_cap = chain.halo_samples()
+    total = nshards * S_len + halo_cap
+    u8 = S.iq_u8(total)
+    d = to_dev(u8)
+    ref_chain = _chain(hip)
+    ref_chain.set_small_chain(0)
+    Q0, _, _ = chain.plan(0, S_len, -1)
+    _, Q1, _ = chain.plan((nshards - 1) * S_len, nshards * S_len, -1)
+    full = _run(hip, ref_chain, d, 0, total, Q0, Q1)
+    pieces = []
+    for r in range(nshards):
+        s0, s1 = r * S_len, (r + 1) * S_len
+        a, b, halo = chain.plan(s0, s1, -1)
+        assert halo <= halo_cap
+        shard = to_dev(u8[2 * s0: 2 * (s1 + halo_cap)])
+        n0 = hip.lib.sdrhip_debug_small_chain_launches()
+        pieces.append((a, b, _run(hip, chain, shard, s0, S_len + halo_cap, a, b)))
+        assert hip.lib.sdrhip_debug_small_chain_launches() == n0 + 1, "a 2^20-sample shard must take the one-kernel route by itself"
+    assert pieces[0][0] == Q0 and pieces[-1][1] == Q1
+    for (a0, a1, _), (b0, b1, _) in zip(pieces[:-1], pieces[1:]):
+        assert a1 == b0
+    assert_bit_equal(np.concatenate([p[2] for p in pieces]), full, "8 shards of 2^20 samples")
+    nblk = 90
+    exp = _model(oracle, u8[: 2 * nblk * B], nblk)
+    assert_bit_equal(full[: exp.size], exp, "single stream vs restated pipes")
 
 
 def test_chain_run_as_hipgraph(hip, oracle):

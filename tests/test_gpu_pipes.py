@@ -295,6 +295,46 @@ def test_uniform_block_pipes_coalesced_sweep(hip, oracle):
     assert ran >= 20
 
 
+def test_short_block_through_a_coalescing_pipes_lent_buffer(hip, oracle):
+    """coalesce > 1 with blocks already staged, the caller takes input_buffer(n) and then pushes FEWER elements
+    through it (a short last block).  The short block ends the uniform run, the staged blocks are submitted and the Pipe
+    moves to its other staging slot: the block must be copied there, not assumed to be in place."""
+    t127 = S.taps_decim127()
+    for n_short in (4096, 1000, 8192 - 8):
+        sizes = [8192, 8192, n_short, 8192, 8192]
+        xc = S.cfloat_block(sum(sizes))
+        blocks = _cut(xc, 2, sizes)
+        exp, _ = PM.fir_decimator_pipe(PM.FilterModel(oracle, t127, PM.ORDER_AVX, complex_=True, factor=8), blocks, 1024)
+        pipe = hip.firDecimator(hip.Decimator(8, t127, hip.ORDER_AVX, complex_=True), 1024)
+        pipe.set_coalesce(4)
+        got = []
+        got += pipe.push(blocks[0])
+        got += pipe.push(blocks[1])
+        view = pipe.input_buffer(8192)                      # room for a whole block ...
+        view[: 2 * n_short] = blocks[2]                     # ... of which only the front is filled and pushed
+        view[2 * n_short:] = np.float32(1e30)               # anything read past the pushed part would show
+        got += pipe.push(view[: 2 * n_short])
+        got += pipe.push(blocks[3])
+        got += pipe.push(blocks[4])
+        got += pipe.flush()
+        _cmp(got, exp, f"short block of {n_short} through the lent buffer of a coalescing firDecimator")
+    # the same on a real filter Pipe
+    half = S.taps_audio_half64()
+    sizes = [8192, 3000, 8192]
+    xr = S.real_block(sum(sizes))
+    blocks = _cut(xr, 1, sizes)
+    exp, _ = PM.fir_filter_pipe(PM.FilterModel(oracle, half, PM.ORDER_AVX, sym=True), blocks, B)
+    pipe = hip.firFilter(hip.Filter(half, hip.ORDER_AVX, sym=True), B)
+    pipe.set_coalesce(8)
+    got = pipe.push(blocks[0])
+    view = pipe.input_buffer(8192)
+    view[:3000] = blocks[1]
+    got += pipe.push(view[:3000])
+    got += pipe.push(blocks[2])
+    got += pipe.flush()
+    _cmp(got, exp, "short block through the lent buffer of a coalescing firFilter")
+
+
 def test_pipes_cross_the_in_place_threshold(hip, oracle):
     """Small pushes run in place (kernels read / write the pinned buffers over PCIe), large ones go through the copy
     engines; the carried tail comes from the host-side history either way.  Pushes on both sides of the threshold, in both
