@@ -1,8 +1,11 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r03d
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^ROCm\|^Hostname\|^Librccl\|amdgpu.ids\|^RCCL\|^HIP version" | tail -8
-python tools/shard_pass_probe.py 128 2>&1 | grep blocks | tee gpurun_out/r03d/probe128.txt
-python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>gpurun_out/r03d/bench.err | tee gpurun_out/r03d/bench.json | python -c "
+mkdir -p gpurun_out/r03e
+export BENCH_TRANSPORT=host
+timeout 600 python bench.py --gpus 2 --steps 5 --warmup 1 --blocks 4096 2>gpurun_out/r03e/bench2.err | tee gpurun_out/r03e/bench2.json | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('value',d['value'],'ms_per_step',d['ms_per_step']); print('shard',d['shard_1M_samples_per_gpu']); print('host',d['host_streamed']); print('stage',d['stage_ms'])"
+print({k:d[k] for k in ('value','n_gpus','ms_per_step')}); print(d['config']); print('shard',d['shard_1M_samples_per_gpu']); print('noex',d['without_halo_exchange'])"
+tail -5 gpurun_out/r03e/bench2.err
+unset BENCH_TRANSPORT
+timeout 600 python bench.py --gpus 2 --steps 5 --warmup 1 --blocks 4096 --no-extras 2>gpurun_out/r03e/bench2r.err | tee gpurun_out/r03e/bench2r.json | cut -c1-900
+tail -5 gpurun_out/r03e/bench2r.err
