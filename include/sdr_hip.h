@@ -112,10 +112,10 @@ void decimateAVXSymmetricRC(int num, int factor, int numCoeffs, float *coeffs, f
 
 /* c_sources/resample.c:16-142.  coeffs = table of num_groups HOST pointers to
  * zero-padded polyphase groups (FilterInternal.hs:335-342); returns end group.
- * LIMIT of the drop-in symbols: at most 64 polyphase groups (interpolation <= 64 for coprime ratios; the per-group
- * offset tables travel as a kernel argument), and resampleRR needs decimation > interpolation; beyond that they print
- * the reason and abort() -- they cannot return an error.  The descriptor API (sdrhip_resampler_*) reports
- * SDRHIP_ERR_ARG instead. */
+ * Any number of polyphase groups, as in the reference (up to 64 the per-group offset tables travel as kernel arguments,
+ * beyond that in device memory).  resampleRR needs decimation > interpolation and 0 <= filter_offset < interpolation
+ * (outside these the reference's own recurrence leaves its arrays): then it prints the reason and abort()s -- it cannot
+ * return an error.  The descriptor API (sdrhip_resampler_*) reports SDRHIP_ERR_ARG instead. */
 void resampleRR(int buf_size, int coeff_size, int interpolation, int decimation, int filter_offset,
                 float *coeffs, float *in_buf, float *out_buf);
 int resample2RR(int buf_size, int num_coeffs, int starting_group, int num_groups, int *increments,

@@ -148,8 +148,8 @@ class Oracle:
         coeffs = _f32(coeffs)
         cap = round_up((coeffs.size + interp - 1) // interp + 1, n) + n
         groups = np.zeros((interp, cap), np.float32)
-        inc = np.zeros(64, np.int32)
-        off = np.zeros(64, np.int32)
+        inc = np.zeros(max(interp, 1), np.int32)
+        off = np.zeros(max(interp, 1), np.int32)
         nc, ng, pl = C.c_int(), C.c_int(), C.c_int()
         self.lib.orc_prepare_coeffs(n, interp, decim, _fp(coeffs), coeffs.size,
                                     C.byref(nc), C.byref(ng), C.byref(pl),

@@ -326,7 +326,8 @@ int orc_prepare_coeffs(int n, int interpolation, int decimation, const float *co
                        int *num_coeffs, int *num_groups, int *padded_len,
                        int *increments, int *offsets, float *groups)
 {
-    int offs[64], ng = 0, off = 0, maxlen = 0;
+    /* the walk visits at most `interpolation` offsets; they go straight into the caller's offsets[] (<= I entries) */
+    int *offs = offsets, ng = 0, off = 0, maxlen = 0;
     do {
         int len = (ncoeffs - off + interpolation - 1) / interpolation;
         if (ncoeffs - off <= 0) len = 0;
@@ -336,10 +337,9 @@ int orc_prepare_coeffs(int n, int interpolation, int decimation, const float *co
         int r = (decimation - off - 1) % interpolation;
         off = interpolation - 1 - r;
         ng++;
-    } while (off != 0 && ng < 64);
+    } while (off != 0 && ng < interpolation);
     int pl = ((maxlen + n - 1) / n) * n;
     for (int g = 0; g < ng; g++) {
-        offsets[g] = offs[g];
         float *row = groups + (size_t)g * pl;
         int j = 0;
         for (int i = offs[g]; i < ncoeffs; i += interpolation) row[j++] = coeffs[i];

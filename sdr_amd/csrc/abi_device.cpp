@@ -81,6 +81,16 @@ int ResampDesc::ensure_device() const
     if (rc != SDRHIP_OK) return rc;
     if (d_groups) return SDRHIP_OK;
     if ((rc = upload_floats(&d_plain, h_plain)) != SDRHIP_OK) return rc;
+    if (num_groups > 64) {
+        // kernels.hpp ResampTable::ext: un-rotated prefix sums of the increments, then the groups' filter offsets
+        std::vector<float> ext((size_t)2 * num_groups + 1);
+        std::vector<int> e((size_t)2 * num_groups + 1, 0);
+        for (int q = 0; q < num_groups; q++) { e[q + 1] = e[q] + increments[q]; e[num_groups + 1 + q] = offsets[q]; }
+        memcpy(ext.data(), e.data(), e.size() * sizeof(int));
+        float* d = nullptr;
+        if ((rc = upload_floats(&d, ext)) != SDRHIP_OK) return rc;
+        d_ext = reinterpret_cast<int*>(d);
+    }
     return upload_floats(&d_groups, h_groups);
 }
 
@@ -94,6 +104,7 @@ ResampDesc::~ResampDesc()
 {
     if (d_groups) (void)hipFree(d_groups);
     if (d_plain) (void)hipFree(d_plain);
+    if (d_ext) (void)hipFree(d_ext);
 }
 
 static bool order_ok(int order) { return order == SDRHIP_ORDER_SCALAR || order == SDRHIP_ORDER_SSE || order == SDRHIP_ORDER_AVX; }
@@ -264,7 +275,7 @@ int resamp_create(ResampDesc* r, int order, bool cplx, int I, int D, const float
 {
     SDRHIP_REQUIRE(order_ok(order), "resamp_create");
     SDRHIP_REQUIRE(coeffs != nullptr && ncoeffs > 0, "resamp_create");
-    SDRHIP_REQUIRE(I >= 1 && D > I && I <= 64, "resamp_create: needs decimation > interpolation (Filter.hs:641)");
+    SDRHIP_REQUIRE(I >= 1 && D > I, "resamp_create: needs decimation > interpolation (Filter.hs:641)");
     r->order = order;
     r->cplx = cplx;
     r->I = I;
@@ -330,7 +341,7 @@ int resamp_run_demod(const ResampDesc* r, hipStream_t s, const float* d_iq, bool
     t.pos0 = p0 - in_base;
     int acc = 0;
     for (int q = 0; q < r->num_groups; q++) {
-        t.pre[q] = acc;
+        if (q < 64) t.pre[q] = acc;
         acc += r->increments[(t.group0 + q) % r->num_groups];
     }
     t.period = acc;
@@ -338,7 +349,8 @@ int resamp_run_demod(const ResampDesc* r, hipStream_t s, const float* d_iq, bool
     t.nloop = r->nloop;
     t.ntaps_plain = r->ntaps;
     t.force_seq = 0;
-    for (int q = 0; q < r->num_groups; q++) t.fo[q] = r->offsets[q];
+    for (int q = 0; q < r->num_groups && q < 64; q++) t.fo[q] = r->offsets[q];
+    if (r->num_groups > 64) t.ext = r->d_ext;       // per-group tables in device memory (ensure_device)
     // as in fir_run: one launch instead of up to four (lead-in, tiles, tail, seams) for a single host block
     // (configs[3]'s 65536-float blocks: 34 -> 22 us per push)
     const int64_t small_generic_r = 2 * (int64_t)small_launch_outputs();

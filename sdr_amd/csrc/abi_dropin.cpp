@@ -161,10 +161,7 @@ void fir_cplx(ComplexOrder order, bool sym, int num, int factor, int numCoeffs, 
 int resample_groups(bool cplx, int lanes_or_order, int buf_size, int num_coeffs, int starting_group, int num_groups,
                     int* increments, float** coeffs, float* in, float* out)
 {
-    if (num_groups <= 0 || num_groups > 64) {
-        fprintf(stderr, "libsdr_hip: resample: num_groups %d unsupported (1..64)\n", num_groups);
-        abort();
-    }
+    if (num_groups <= 0) return starting_group;       // the reference's loop would divide by zero: nothing to compute
     int end_group = (int)(((int64_t)starting_group + (buf_size > 0 ? buf_size : 0)) % num_groups);
     if (buf_size <= 0) return starting_group;
     Lease l;
@@ -184,22 +181,32 @@ int resample_groups(bool cplx, int lanes_or_order, int buf_size, int num_coeffs,
     t.ngroups = num_groups;
     t.group0 = starting_group;
     t.pos0 = 0;
+    // prefix of the increments starting at starting_group; up to 64 groups it travels in the kernel arguments, beyond that as
+    // a device table of the un-rotated prefix sums (kernels.hpp: ResampTable::ext) -- the reference's C takes any count
+    std::vector<int> pre((size_t)num_groups);
     int acc = 0;
     for (int q = 0; q < num_groups; q++) {
-        t.pre[q] = acc;
+        pre[q] = acc;
         acc += increments[(starting_group + q) % num_groups];
-        t.fo[q] = 0;
     }
     t.period = acc;
+    std::vector<int> ext;
+    if (num_groups <= 64) {
+        for (int q = 0; q < num_groups; q++) { t.pre[q] = pre[q]; t.fo[q] = 0; }
+    } else {
+        ext.assign((size_t)2 * num_groups + 1, 0);
+        for (int q = 0; q < num_groups; q++) ext[q + 1] = ext[q] + increments[q];
+    }
     t.row_stride = nloop;
     t.nloop = nloop;
     t.ntaps_plain = 0;
     t.force_seq = 0;
     int64_t last = buf_size - 1;
-    size_t nin = (size_t)((last / num_groups) * (int64_t)t.period + t.pre[last % num_groups] + nloop);
+    size_t nin = (size_t)((last / num_groups) * (int64_t)t.period + pre[last % num_groups] + nloop);
     size_t esz = cplx ? 8 : 4;
     const bool direct = fits_direct(nin * esz, (size_t)buf_size * esz);
     const float* d_taps = taps_on_device(c, c.taps, c.taps_now, table.data(), table.size() * 4);
+    if (!ext.empty()) t.ext = (const int*)taps_on_device(c, c.taps2, c.taps2_now, ext.data(), ext.size() * 4);
     const float* d_in = (const float*)stage_in(c, direct, in, nin * esz);
     float* d_out = (float*)stage_out(c, direct, (size_t)buf_size * esz);
     Geom g = flat_geom(buf_size, 1, 0);
@@ -329,22 +336,32 @@ void resampleRR(int buf_size, int coeff_size, int interpolation, int decimation,
                 float* in_buf, float* out_buf)
 {
     if (buf_size <= 0) return;
-    if (interpolation < 1 || interpolation > 64 || decimation <= interpolation) {
-        fprintf(stderr, "libsdr_hip: resampleRR: need 1 <= interpolation <= 64 < decimation\n");
+    if (interpolation < 1 || decimation <= interpolation || filter_offset < 0 || filter_offset >= interpolation) {
+        // outside these the reference's own recurrence (resample.c:16-32) indexes before its arrays
+        fprintf(stderr, "libsdr_hip: resampleRR: need 1 <= interpolation < decimation and 0 <= filter_offset < interpolation\n");
         abort();
     }
     Lease l;
     Ctx& c = *l.c;
     ResampTable t;
-    // walk the recurrence from filter_offset until it repeats
+    // walk the recurrence from filter_offset until it repeats (at most `interpolation` phases)
+    std::vector<int> fo, pre;
     int off = filter_offset, ng = 0, acc = 0;
     do {
-        t.fo[ng] = off;
-        t.pre[ng] = acc;
+        fo.push_back(off);
+        pre.push_back(acc);
         acc += (decimation - off - 1) / interpolation + 1;
         off = interpolation - 1 - (decimation - off - 1) % interpolation;
         ng++;
-    } while (off != filter_offset && ng < 64);
+    } while (off != filter_offset && ng < interpolation);
+    std::vector<int> ext;
+    if (ng <= 64) {
+        for (int q = 0; q < ng; q++) { t.fo[q] = fo[q]; t.pre[q] = pre[q]; }
+    } else {
+        ext.assign((size_t)2 * ng + 1, 0);
+        for (int q = 0; q < ng; q++) { ext[q] = pre[q]; ext[ng + 1 + q] = fo[q]; }
+        ext[ng] = acc;
+    }
     t.ngroups = ng;
     t.group0 = 0;
     t.pos0 = 0;
@@ -355,9 +372,10 @@ void resampleRR(int buf_size, int coeff_size, int interpolation, int decimation,
     t.force_seq = 1;
     int64_t last = buf_size - 1;
     int maxlen = (coeff_size + interpolation - 1) / interpolation;
-    size_t nin = (size_t)((last / ng) * (int64_t)t.period + t.pre[last % ng] + maxlen);
+    size_t nin = (size_t)((last / ng) * (int64_t)t.period + pre[last % ng] + maxlen);
     const bool direct = fits_direct(nin * 4, (size_t)buf_size * 4);
     const float* d_taps = taps_on_device(c, c.taps, c.taps_now, coeffs, (size_t)coeff_size * 4);
+    if (!ext.empty()) t.ext = (const int*)taps_on_device(c, c.taps2, c.taps2_now, ext.data(), ext.size() * 4);
     const float* d_in = (const float*)stage_in(c, direct, in_buf, nin * 4);
     float* d_out = (float*)stage_out(c, direct, (size_t)buf_size * 4);
     Geom g = flat_geom(buf_size, decimation, 0);

@@ -50,6 +50,7 @@ struct ResampDesc {
     mutable int device = -1;           // the device the taps were uploaded to (-1: not yet)
     mutable float* d_groups = nullptr;
     mutable float* d_plain = nullptr;
+    mutable int* d_ext = nullptr;      // more than 64 groups: prefix sums of the increments + filter offsets (kernels.hpp ResampTable::ext)
     int ensure_device() const;
     int64_t in_offset(int64_t m) const { return ceil_div64(m * (int64_t)D, I); }
     int filter_offset(int64_t m) const { return (int)(in_offset(m) * I - m * (int64_t)D); }

@@ -88,6 +88,10 @@ struct ResampTable {
     int ntaps_plain;
     int fo[64];
     int force_seq;
+    // more than 64 groups (the reference's C runs any count, resample.c:34-142): the per-group tables live in device memory
+    // instead of the kernel arguments -- ext[0 .. ngroups] = prefix sums of the increments from group 0 (ext[ngroups] = period),
+    // ext[ngroups + 1 + g] = filter offset of group g -- and pre[] / fo[] above are unused.  Generic kernels only.
+    const int* ext = nullptr;
 };
 void launch_resample_real(hipStream_t s, const Geom& g, int lanes, const ResampTable& t, const float* d_groups,
                           const float* d_plain_taps, const float* d_in, float* d_out);

@@ -233,7 +233,19 @@ __device__ __forceinline__ void resamp_locate(const ResampTable& t, int i, int& 
     int r = i - cyc * t.ngroups;
     group = t.group0 + r;
     if (group >= t.ngroups) group -= t.ngroups;
-    pos = t.pos0 + (int64_t)cyc * t.period + t.pre[r];
+    int pre;
+    if (t.ext != nullptr) {
+        // prefix of the increments starting at group0, from the un-rotated prefix sums
+        const int a = t.group0 + r, base = t.ext[t.group0];
+        pre = a <= t.ngroups ? t.ext[a] - base : t.period - base + t.ext[a - t.ngroups];
+    } else {
+        pre = t.pre[r];
+    }
+    pos = t.pos0 + (int64_t)cyc * t.period + pre;
+}
+__device__ __forceinline__ int resamp_filter_offset(const ResampTable& t, int group)
+{
+    return t.ext != nullptr ? t.ext[t.ngroups + 1 + group] : t.fo[group];
 }
 
 template <int L>
@@ -251,7 +263,7 @@ __global__ void __launch_bounds__(256) k_resample_real(Geom g, ResampTable t, co
     float r;
     if (t.force_seq || is_cross(g, m)) {
         // FilterInternal.hs:410-423 / resample.c:16-32: stride I (drop filterOffset coeffs), sequential
-        int fo = t.fo[group];
+        int fo = resamp_filter_offset(t, group);
         r = 0.0f;
         for (int l = 0, j = fo; j < t.ntaps_plain; l++, j += g.I) r = r + x[l] * plain[j];
     } else {
@@ -292,7 +304,7 @@ __global__ void __launch_bounds__(256) k_resample_cplx(Geom g, ResampTable t, co
     LoadF32 ld{in};
     float2 r;
     if (t.force_seq || is_cross(g, m)) {
-        int fo = t.fo[group];
+        int fo = resamp_filter_offset(t, group);
         float re = 0.0f, im = 0.0f;
         for (int l = 0, j = fo; j < t.ntaps_plain; l++, j += g.I) {
             float2 v = ld(pos + l);

@@ -418,7 +418,7 @@ bool launch_fir_split(hipStream_t s, const Geom& g, bool cplx, int lanes, Comple
 bool launch_resample_split(hipStream_t s, const Geom& g, bool cplx, int lanes, ComplexOrder corder, const ResampTable& t,
                            const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out)
 {
-    if (!split_enabled() || g.count < SPLIT_MIN_OUTPUTS || g.seamBI < 0 || t.force_seq) return false;
+    if (!split_enabled() || g.count < SPLIT_MIN_OUTPUTS || g.seamBI < 0 || t.force_seq || t.ext != nullptr) return false;
     if (g.seamBI != 0 && d_plain_taps == nullptr) return false;
     OrderInfo o;
     if (!(cplx ? cplx_order(corder, o) : real_order(lanes, o))) return false;

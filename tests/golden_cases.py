@@ -136,4 +136,16 @@ def cases(p):
     prepc = orc.prepare_coeffs(8, 5, 7, hs)
     out["resampleAVXRC_5_7"] = (p.resample("resampleAVXRC", 2000, prepc, 1, xcs, True)[0], crc(xcs, hs))
     out["scaleAVX"] = (p.scale("scaleAVX", 0.2, xr), crc(xr))
+    # more than 64 polyphase groups (the drop-in symbols used to abort): 97/100, 1500 taps -> 97 groups of 16
+    h1500 = np.random.default_rng(18).uniform(-1, 1, 1500).astype(np.float32)
+    x8k = S.real_block(8192, seed=19)
+    prep97 = orc.prepare_coeffs(8, 97, 100, h1500)
+    r97, g97 = p.resample("resampleAVXRR", 7000, prep97, 0, x8k)
+    out["resampleAVXRR_97_100"] = (r97, crc(x8k, h1500))
+    out["resampleAVXRR_97_100_endgroup"] = (np.array([g97], np.float32), crc(x8k))
+    out["resampleAVXRR_97_100_start40"] = (p.resample("resampleAVXRR", 5000, prep97, 40, x8k)[0], crc(x8k, h1500))
+    out["resampleRR_legacy_97_100"] = (p.resample_legacy(6000, 97, 100, 0, h1500, x8k), crc(x8k, h1500))
+    out["resampleRR_legacy_97_100_off33"] = (p.resample_legacy(6000, 97, 100, 33, h1500, x8k), crc(x8k, h1500))
+    xc8k = S.cfloat_block(8192, seed=20)
+    out["resampleAVXRC_97_100"] = (p.resample("resampleAVXRC", 7000, prep97, 5, xc8k, True)[0], crc(xc8k, h1500))
     return out

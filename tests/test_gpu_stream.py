@@ -121,10 +121,11 @@ def test_resampler_stream(hip, oracle, order, complex_, launch_route):
     assert_bit_equal(got, exp, "cut into launches")
 
 
-@pytest.mark.parametrize("I,D", [(2, 3), (5, 7), (7, 11), (3, 23)])
+@pytest.mark.parametrize("I,D", [(2, 3), (5, 7), (7, 11), (3, 23), (97, 100), (65, 131)])
 def test_resampler_other_ratios(hip, oracle, I, D, launch_route):
+    """(97, 100) and (65, 131): more than 64 polyphase groups -- the per-group tables then live in device memory."""
     x = S.real_block(3 * 4096)
-    taps = S.gauss_taps(150, I + D)
+    taps = S.gauss_taps(150 if I < 64 else 1500, I + D)
     model = PM.ResamplerModel(oracle, I, D, taps, PM.ORDER_AVX)
     blocks, _ = PM.fir_resampler_pipe(model, _split(x, 1, 4096), 128)
     exp = np.concatenate(blocks)
