@@ -42,86 +42,73 @@ VALU_PEAK_TFLOPS = 78.6        # f32 VALU, UNFUSED mul+add (parity forbids FMA):
 # --------------------------------------------------------------------------------------
 # CPU baseline (the checker's libraries, used here only as the reported baseline)
 # --------------------------------------------------------------------------------------
-def cpu_chain_worker(seconds, nblk=64):
-    """One thread: the FM chain over 8192-sample blocks exactly as the reference runs it
-    (one C call per stage per block, Pipes re-blocking), looping for `seconds`.
-    Returns (samples_per_second, kind)."""
+def _cpu_harness():
+    """oracle/cpu_chain_bench (+ a taps file): the reference's receiver loop as a COMPILED caller -- the reference's own C
+    kernels (oracle/_ref) under the restated Pipes state machines, no Python in the loop.  Built by oracle/Makefile."""
+    import tempfile
     import numpy as np
-    from oracle.oracle import Oracle, Ref, have_ref, duplicate
     import signals as S
-    orc = Oracle()
-    ref = Ref() if have_ref() else None
-    kind = "reference" if ref is not None else "port"
-    taps_d = np.concatenate([S.taps_decim127(), np.zeros(1, np.float32)])
-    taps_dd = duplicate(taps_d)
-    half = S.taps_audio_half64()
-    prep = orc.prepare_coeffs(8, 3, 10, S.taps_resamp191())
-    u8 = S.iq_u8(nblk * BLOCK)
-    blocks = [np.ascontiguousarray(u8[2 * i * BLOCK:2 * (i + 1) * BLOCK]) for i in range(nblk)]
-    n_dec = (BLOCK - 128) // 8 + 1
+    exe = os.path.join(ROOT, "oracle", "cpu_chain_bench")
+    if not os.path.exists(exe) or not os.path.exists(os.path.join(ROOT, "oracle", "libsdr_oracle.so")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    fd, taps = tempfile.mkstemp(suffix=".taps")
+    with os.fdopen(fd, "wb") as f:
+        d, r, h = S.taps_decim127(), S.taps_resamp191(), S.taps_audio_half64()
+        np.array([d.size, r.size, h.size], np.int32).tofile(f)
+        for a in (d, r, h):
+            np.ascontiguousarray(a, np.float32).tofile(f)
+    return exe, taps
 
-    def one_pass():
-        dec_acc = []
-        for b in blocks:
-            if ref is not None:
-                x = ref.convert("convertCAVX", b)
-                d = ref.decim("decimateAVXRC", n_dec, 8, taps_dd, x, True)
-            else:
-                x = orc.convert_u8(b)
-                d = orc.decimate_rc(4, n_dec, 8, taps_dd, x)
-            dec_acc.append(d)
-            if len(dec_acc) == 8:
-                dd = np.concatenate(dec_acc)
-                dec_acc = []
-                y = orc.fm_demod(dd)                       # the reference's fmDemod is Haskell; restated
-                m = (y.size * 3 - 192) // 10 + 1
-                if ref is not None:
-                    z, _ = ref.resample("resampleAVXRR", m, prep, 0, y)
-                    ref.filt("filterAVXSymmetricRR", z.size - 127, half, z)
-                else:
-                    z, _ = orc.resample_rr(8, m, prep, 0, y)
-                    orc.filter_sym_rr(8, z.size - 127, half, z)
 
-    one_pass()
-    t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < seconds:
-        one_pass()
-        n += nblk * BLOCK
-    return n / (time.perf_counter() - t0), kind
+def _cpu_run(exe, taps, *args):
+    out = subprocess.run([exe, taps] + [str(a) for a in args], capture_output=True, text=True, check=True)
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def cpu_topology():
+    """(physical cores, hardware threads) this process may run on."""
+    threads = len(os.sched_getaffinity(0))
+    cores = set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return (min(len(cores), threads) if cores else threads), threads
 
 
 def cpu_baseline(seconds_single=6.0, seconds_all=8.0):
-    """Single-thread (how the reference actually runs) and all-cores (one independent
-    stream per core) numbers, each worker a separate process."""
-    cores = len(os.sched_getaffinity(0))
-
-    def spawn(secs):
-        return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(secs)],
-                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-
-    def collect(ps):
-        tot, kind = 0.0, "port"
-        for p in ps:
-            out, _ = p.communicate()
-            try:
-                r = json.loads(out.strip().splitlines()[-1])
-                tot += r["sps"]
-                kind = r["kind"]
-            except Exception:
-                pass
-        return tot, kind
-
-    single, kind = collect([spawn(seconds_single)])
-    allc, _ = collect([spawn(seconds_all) for _ in range(cores)])
+    """Single-thread (how the reference actually runs: one pipeline thread) and all-hardware-threads (one independent
+    receiver per thread) rates of the compiled receiver loop."""
+    exe, taps = _cpu_harness()
+    try:
+        cores, threads = cpu_topology()
+        single = _cpu_run(exe, taps, seconds_single, 1)
+        allc = _cpu_run(exe, taps, seconds_all, threads)
+        stages = _cpu_run(exe, taps, "--stages", 0.4)
+    finally:
+        os.unlink(taps)
     return {
-        "value": round(allc / 1e6, 2), "unit": "Msamples/s", "cores": cores, "kind": kind,
-        "single_thread_value": round(single / 1e6, 2),
-        "sample": (f"full FM chain on 64 x 8192-sample u8 IQ blocks looped for {seconds_all:.0f} s per core "
-                   f"({cores} independent streams, one process per core) and {seconds_single:.0f} s single-thread; "
-                   "convertCAVX/decimateAVXRC/resampleAVXRR/filterAVXSymmetricRR from the reference's own C "
-                   "(oracle/_ref, -O2 -mavx2 -msse4) when kind=reference, fmDemod from the restatement "
-                   "(the reference's is Haskell); ctypes call overhead included"),
+        "value": round(allc["sps_total"] / 1e6, 2), "unit": "Msamples/s", "cores": threads, "kind": allc["kind"],
+        "physical_cores": cores, "hardware_threads": threads,
+        "single_thread_value": round(single["sps_total"] / 1e6, 2),
+        "isolated_kernels_Melements_per_s": {k[:-len("_elements_per_s")]: round(v / 1e6, 1) for k, v in stages.items() if k.endswith("_elements_per_s")},
+        "harmonic_sum_of_isolated_kernels": round(stages["harmonic_sum_sps"] / 1e6, 2),
+        "sample": (f"oracle/cpu_chain_bench (compiled C caller, no Python in the loop): the FM receiver of examples/fm/fm.hs:34-41 block by "
+                   f"block over 64 x 8192-sample u8 IQ blocks, looped for {seconds_all:.0f} s on {threads} threads (one independent receiver "
+                   f"per hardware thread; {cores} physical cores) and {seconds_single:.0f} s single-thread; kind=reference: convertCAVX / "
+                   "decimateAVXRC / resampleAVXRR / filterAVXSymmetricRR / scaleAVX and the scalar kernels of the seam outputs are the "
+                   "reference's own C (oracle/_ref, -O2 -mavx2 -msse4), fmDemod and the Pipes' block bookkeeping (Haskell in the reference) "
+                   "come from the restatement; harmonic_sum_of_isolated_kernels = the five SIMD kernels alone on one cache-resident block "
+                   "(no seam outputs, no re-blocking, no data movement between stages), the ceiling of what the loop can reach"),
     }
 
 
@@ -211,12 +198,16 @@ def main():
                          "the default 20 steps keep the GPU busy for ~1 s and an outside utilisation sampler can see the run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the contract line (profiling runs)")
-    ap.add_argument("--cpu-worker", type=float, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker", type=float, default=None, help="only the compiled CPU receiver loop, single thread, for this many seconds")
     args = ap.parse_args()
 
     if args.cpu_worker is not None:
-        sps, kind = cpu_chain_worker(args.cpu_worker)
-        print(json.dumps({"sps": sps, "kind": kind}))
+        exe, taps = _cpu_harness()
+        try:
+            r = _cpu_run(exe, taps, args.cpu_worker, 1)
+        finally:
+            os.unlink(taps)
+        print(json.dumps({"sps": r["sps_total"], "kind": r["kind"]}))
         return
 
     if args.gpus < 1:
