@@ -658,7 +658,10 @@ def main():
     if rank == 0 and world == 1 and extras:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import host_stream_native as H
-        host = {"unit": "Msamples/s of input (PCIe inclusive)", "cpu_single_thread_chain": cpu["single_thread_value"] if cpu else None}
+        host = {"unit": "Msamples/s of input (PCIe inclusive)", "cpu_single_thread_chain": cpu["single_thread_value"] if cpu else None,
+                "note": "zero-copy lines: the source writes the library's pinned staging buffer itself (a radio's DMA target), so they carry "
+                        "no source-side copy; *_memcpy: the caller's block is copied in by the push, which is what the reference's host path "
+                        "(and cpu_single_thread_chain) includes"}
         for name, bpp, pushes, zc in (("fm_stream_1_block_per_push", 1, 4000, True), ("fm_stream_1_block_per_push_memcpy", 1, 4000, False),
                                       ("fm_stream_16_blocks_per_push", 16, 1000, True), ("fm_stream_4096_blocks_per_push_zero_copy", 4096, 12, True)):
             try:

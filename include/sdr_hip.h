@@ -425,7 +425,8 @@ int sdrhip_fm_stream_pop(sdrhip_fm_stream *st, float *out, int capacity);
 /* Checkpoint / resume.  Between two pushes the operator's state is the stream position, the last ~4k input samples and
  * the audio not yet popped (the reference keeps the equivalent in Pipe closures: overlap remainder, resampler phase, last
  * demod sample, output fill level -- Filter.hs:536-727, Demod.hs:21-38); everything else is a closed form of the position.
- * save: drains the operator (like flush) and writes the state (at most sdrhip_fm_stream_state_bytes, *used = its size);
+ * state_bytes: drains the operator (like flush) and returns the exact size the save that follows needs (0 = the drain failed);
+ * save: drains the operator and writes the state (*used = its size);
  * restore: into a freshly created stream over a chain of the same taps and block sizes; returns the number of audio blocks
  * ready to pop.  A restored stream fed the remaining samples yields the audio the uninterrupted stream would have. */
 size_t sdrhip_fm_stream_state_bytes(const sdrhip_fm_stream *st);
@@ -493,6 +494,7 @@ int sdrhip_pipe_pop(sdrhip_pipe *p, float *out, int capacity);
 /* Checkpoint / resume, as sdrhip_fm_stream_save / _restore: save drains the pipe (like flush) and writes its state -- position,
  * the last few input elements, the carried fmDemod sample / dcBlocker pair, the output not yet popped; restore loads it into a
  * freshly created pipe of the same kind over a descriptor of the same taps; returns the blocks ready to pop. */
+/* state_bytes drains the pipe (like flush) and returns the exact size the save that follows needs (0 = the drain failed). */
 size_t sdrhip_pipe_state_bytes(const sdrhip_pipe *p);
 int sdrhip_pipe_save(sdrhip_pipe *p, void *buf, size_t capacity, size_t *used);
 int sdrhip_pipe_restore(sdrhip_pipe *p, const void *buf, size_t bytes);

@@ -34,7 +34,9 @@ int sdrhip_bench_fm_stream(sdrhip_fm_chain* chain, int n_samples, int pushes, in
         if (zero_copy) {
             uint8_t* dst = sdrhip_fm_stream_input_buffer(st);
             if (!dst) return SDRHIP_ERR_STATE;
-            if ((i & 63) == 0) memcpy(dst, src.data(), src.size());       // the "radio": fresh data now and then, stale bytes otherwise
+            // the "radio" writes the lent buffer itself (DMA): the timed figure carries no source-side copy.  Two pushes in a row
+            // are filled now and then, so that BOTH staging slots hold real samples (consecutive pushes alternate slots)
+            if ((i & 63) < 2) memcpy(dst, src.data(), src.size());
             ready = sdrhip_fm_stream_push(st, dst, n_samples);
         } else {
             ready = sdrhip_fm_stream_push(st, src.data(), n_samples);
@@ -76,7 +78,7 @@ int sdrhip_bench_pipe(sdrhip_pipe* p, int n, int floats_per_element, int block_s
         if (zero_copy) {
             float* dst = sdrhip_pipe_input_buffer(p, n);
             if (!dst) return SDRHIP_ERR_STATE;
-            if ((i & 63) == 0) memcpy(dst, src.data(), src.size() * sizeof(float));
+            if ((i & 63) < 2) memcpy(dst, src.data(), src.size() * sizeof(float));      // both staging slots, as above
             ready = sdrhip_pipe_push(p, dst, n);
         } else {
             ready = sdrhip_pipe_push(p, src.data(), n);

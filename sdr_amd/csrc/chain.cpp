@@ -836,10 +836,13 @@ struct StreamStateHeader {
 constexpr uint32_t kStateMagic = 0x53444d46u;   // "FMDS"
 }  // namespace
 
-size_t sdrhip_fm_stream_state_bytes(const sdrhip_fm_stream* st)
+size_t sdrhip_fm_stream_state_bytes(const sdrhip_fm_stream* cst)
 {
-    if (st == nullptr) return 0;
-    return sizeof(StreamStateHeader) + (size_t)(2 * st->head_cap) + (st->fifo.size() - st->head + (size_t)st->capacity()) * sizeof(float);
+    if (cst == nullptr) return 0;
+    // exact: drains the operator exactly as sdrhip_fm_stream_save will (0 = the drain failed, sdrhip_last_error)
+    sdrhip_fm_stream* st = const_cast<sdrhip_fm_stream*>(cst);
+    if (sdrhip_fm_stream_flush(st) < 0) return 0;
+    return sizeof(StreamStateHeader) + (size_t)(2 * st->hist_n) + (st->fifo.size() - st->head) * sizeof(float);
 }
 
 int sdrhip_fm_stream_save(sdrhip_fm_stream* st, void* buf, size_t capacity, size_t* used)

@@ -10,7 +10,16 @@
 // that already holds a copy (PyTorch ships one under the same soname) the loader hands back that copy, so a process never
 // runs two RCCLs.  The reference has no multi-device code; there is nothing this file could have been translated from.
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// RCCL's development headers are absent: the library is bound at run time anyway, and these are the only declarations of
+// rccl.h this file uses (NCCL's ABI for them has not changed since 2.x)
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
+#endif
 #include <string.h>
 
 #include <mutex>
@@ -160,7 +169,15 @@ int sdrhip_comm_init_local(sdrhip_comm** comms, int ndev, const int* devices, in
         SDRHIP_CHECK_NCCL(rccl()->CommInitAll(nc.data(), ndev, devs.data()));
     }
     int prev = 0;
-    SDRHIP_CHECK_HIP(hipGetDevice(&prev));
+    {
+        const hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) {
+            set_error("sdrhip_comm_init_local: hipGetDevice: %s", hipGetErrorString(e));
+            for (ncclComm_t c : nc)                 // the communicators CommInitAll just made must not leak
+                if (c) (void)rccl()->CommDestroy(c);
+            return SDRHIP_ERR_HIP;
+        }
+    }
     for (int i = 0; i < ndev; i++) {
         sdrhip_comm* cm = new sdrhip_comm();
         cm->nranks = ndev;
@@ -264,6 +281,10 @@ int sdrhip_halo_exchange_all(sdrhip_comm* const* comms, int ndev, void* const* s
     // after this call may overwrite the head (with RCCL the send sits on the owner's own stream and orders itself)
     int prev = 0;
     SDRHIP_CHECK_HIP(hipGetDevice(&prev));
+    struct Restore {                       // the early returns of the checks below must not leave the caller on another device
+        int dev;
+        ~Restore() { (void)hipSetDevice(dev); }
+    } restore{prev};
     for (int i = 0; i < ndev; i++) {
         SDRHIP_CHECK_HIP(hipSetDevice(comms[i]->device));
         SDRHIP_CHECK_HIP(hipEventRecord(comms[i]->ev_head, (hipStream_t)streams[i]));
@@ -282,7 +303,6 @@ int sdrhip_halo_exchange_all(sdrhip_comm* const* comms, int ndev, void* const* s
         SDRHIP_CHECK_HIP(hipSetDevice(comms[right]->device));
         SDRHIP_CHECK_HIP(hipStreamWaitEvent((hipStream_t)streams[right], comms[i]->ev_pulled, 0));
     }
-    SDRHIP_CHECK_HIP(hipSetDevice(prev));
     return SDRHIP_OK;
 }
 

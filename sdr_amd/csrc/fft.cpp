@@ -7,7 +7,18 @@
 // summation tree from FFTW's: the contract is a tolerance (tests/test_gpu_fft.py: 1e-11 of the largest bin), not bit parity.
 // libhipfft.so is bound at run time like RCCL, so libsdr_hip.so keeps loading where it is absent.
 #include <dlfcn.h>
+#if __has_include(<hipfft/hipfft.h>)
 #include <hipfft/hipfft.h>
+#else
+// hipFFT's development headers are absent: the library is bound at run time anyway, and these are the only declarations of
+// hipfft.h this file uses
+typedef struct hipfftHandle_t* hipfftHandle;
+typedef enum { HIPFFT_SUCCESS = 0 } hipfftResult;
+typedef enum { HIPFFT_Z2Z = 0x69, HIPFFT_D2Z = 0x6a } hipfftType;
+typedef double2 hipfftDoubleComplex;
+typedef double hipfftDoubleReal;
+#define HIPFFT_FORWARD -1
+#endif
 #include <string.h>
 
 #include <mutex>

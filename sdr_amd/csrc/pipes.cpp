@@ -184,7 +184,13 @@ static int fir_submit(sdrhip_pipe* p, int n, int64_t uniform_seam)
     int64_t keep_from = p->in_offset(p->m_done);
     if (keep_from > E_prev) keep_from = E_prev;
     keep_from -= keep_from & 3;
-    if (E_prev - keep_from > p->hist_n) keep_from = E_prev - p->hist_n;      // stream start: nothing before element 0
+    if (E_prev - keep_from > p->hist_n) {
+        // the history always covers the carried tail (pipe_init_history sizes it for that); a state that says otherwise came
+        // from a corrupt or hand-built checkpoint, and running on would index in front of the staging buffer
+        set_error("pipe: the history holds %lld elements but pending output %lld needs %lld", (long long)p->hist_n,
+                  (long long)p->m_done, (long long)(E_prev - keep_from));
+        return SDRHIP_ERR_STATE;
+    }
     const int64_t tail = E_prev - keep_from;
     if (tail > p->head_cap) {
         set_error("pipe: carried tail of %lld elements exceeds the head room (%lld)", (long long)tail, (long long)p->head_cap);
@@ -553,13 +559,16 @@ struct PipeStateHeader {
 constexpr uint32_t kPipeMagic = 0x50504453u;   // "SDPP"
 }  // namespace
 
-size_t sdrhip_pipe_state_bytes(const sdrhip_pipe* p)
+size_t sdrhip_pipe_state_bytes(const sdrhip_pipe* cp)
 {
-    if (p == nullptr) return 0;
-    // + what the drain inside save may add: the outputs of the staged and in-flight blocks
-    const size_t slack = (size_t)(p->staged + 2 * (p->uniform_n > 0 ? p->uniform_n : 0) + 4 * p->block_out + 65536) * 2 * sizeof(float);
-    return sizeof(PipeStateHeader) + (size_t)p->head_cap * p->esz_in() * sizeof(float) + p->fifo_size() * sizeof(float) +
-           p->demod_blocks.size() * sizeof(int32_t) + slack;
+    if (cp == nullptr) return 0;
+    // Exact, not an estimate: the pipe is drained here exactly as sdrhip_pipe_save will drain it (what is staged goes out, both
+    // slots are harvested into the fifo), so the size returned is what the save that follows needs -- whatever the ratio of
+    // the stage and the size of the blocks in flight.  0 = the drain failed (sdrhip_last_error).
+    sdrhip_pipe* p = const_cast<sdrhip_pipe*>(cp);
+    if (sdrhip_pipe_flush(p) < 0) return 0;
+    return sizeof(PipeStateHeader) + (size_t)p->hist_n * p->esz_in() * sizeof(float) + p->fifo_size() * sizeof(float) +
+           p->demod_blocks.size() * sizeof(int32_t);
 }
 
 int sdrhip_pipe_save(sdrhip_pipe* p, void* buf, size_t capacity, size_t* used)
@@ -614,6 +623,17 @@ int sdrhip_pipe_restore(sdrhip_pipe* p, const void* buf, size_t bytes)
                    "sdrhip_pipe_restore: the state belongs to a pipe of another kind or geometry");
     SDRHIP_REQUIRE(h.hist_n >= 0 && h.hist_n <= h.head_cap && h.pending >= 0 && h.n_blocks >= 0 && h.E_prev >= h.hist_n && h.m_done >= 0,
                    "sdrhip_pipe_restore: inconsistent state");
+    if (p->kind == PK_FILTER || p->kind == PK_DECIMATOR || p->kind == PK_RESAMPLER) {
+        // the next pending output must start inside what the pipe has seen, every output computable from those elements must be
+        // done at most once, and the history must reach back to its first input (3 elements of alignment slack, fir_submit):
+        // otherwise the kernels would be sent in front of the staging buffer
+        const int64_t first_in = p->in_offset(h.m_done);
+        const int64_t m_max = (h.E_prev * p->I >= p->Lp) ? (h.E_prev * p->I - p->Lp) / p->D + 1 : 0;
+        int64_t keep_from = first_in < h.E_prev ? first_in : h.E_prev;
+        keep_from -= keep_from & 3;
+        SDRHIP_REQUIRE(h.m_done <= m_max && first_in <= h.E_prev + (p->Lp + p->D) / p->I + 1 && h.hist_n >= h.E_prev - keep_from,
+                       "sdrhip_pipe_restore: the position and the history of the state do not belong together");
+    }
     const size_t hist_bytes = (size_t)h.hist_n * p->esz_in() * sizeof(float);
     SDRHIP_REQUIRE(bytes >= sizeof h + hist_bytes + (size_t)h.pending * sizeof(float) + (size_t)h.n_blocks * sizeof(int32_t),
                    "sdrhip_pipe_restore: truncated state");

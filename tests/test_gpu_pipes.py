@@ -391,3 +391,44 @@ def test_pipes_save_and_restore(hip, oracle):
             _cmp(got, exp, f"{name}, saved after {cut} blocks")
     with pytest.raises(hip.SdrHipError):
         hip.fmDemod().restore(state)          # a dcBlockingFilter state into an fmDemod pipe
+
+
+def test_save_right_after_large_pushes_and_corrupt_states(hip, oracle):
+    """(a) sdrhip_pipe_state_bytes is exact (it drains the pipe as save will), so a save right after pushes of
+    blocks far larger than the old heuristic slack -- a map pipe (fmDemod) with 100k-sample blocks, a low-decimation filter --
+    succeeds at the first call; (b) a state whose history is shorter than the carried tail is refused by restore instead of
+    sending the kernels in front of the staging buffer."""
+    x = S.cfloat_block(3 * 100000)
+    blocks = _cut(x, 2, [100000, 100000, 100000])
+    exp = PM.fm_demod_pipe(oracle, blocks)
+    pipe = hip.fmDemod()
+    got = pipe.push(blocks[0]) + pipe.push(blocks[1])
+    state = pipe.save()                                   # both 100k-sample blocks may still be in flight here; what the drain
+                                                          # makes ready travels inside the state
+    fresh = hip.fmDemod()
+    got2 = fresh.restore(state, max_block=100000)
+    got2 += fresh.push(blocks[2]) + fresh.flush()
+    _cmp(got + got2, exp, "fmDemod pipe saved right after two 100k-sample pushes")
+
+    half = S.taps_audio_half64()
+    xr = S.real_block(3 * 70000)
+    rblocks = _cut(xr, 1, [70000, 70000, 70000])
+    expf, _ = PM.fir_filter_pipe(PM.FilterModel(oracle, half, PM.ORDER_AVX, sym=True), rblocks, 1024)
+    pf = hip.firFilter(hip.Filter(half, hip.ORDER_AVX, sym=True), 1024)
+    out = pf.push(rblocks[0]) + pf.push(rblocks[1])
+    st = pf.save()
+    pf2 = hip.firFilter(hip.Filter(half, hip.ORDER_AVX, sym=True), 1024)
+    out2 = pf2.restore(st)
+    out2 += pf2.push(rblocks[2]) + pf2.flush()
+    _cmp(out + out2, expf, "firFilter pipe saved right after two 70000-float pushes")
+
+    # (b) shrink the history recorded in the state: header = magic, version (u32), 10 x i32, then E_prev, m_done, head_cap, hist_n (i64)
+    import struct
+    bad = bytearray(st)
+    off_hist_n = 4 * 2 + 4 * 10 + 8 * 3
+    (hist_n,) = struct.unpack_from("<q", bad, off_hist_n)
+    assert hist_n >= 127
+    struct.pack_into("<q", bad, off_hist_n, 8)
+    pf3 = hip.firFilter(hip.Filter(half, hip.ORDER_AVX, sym=True), 1024)
+    with pytest.raises(hip.SdrHipError):
+        pf3.restore(bytes(bad))
