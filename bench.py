@@ -560,7 +560,8 @@ def main():
         half = (9 * n1 // 2) // 16 * 16
         src_c = x_uni.view(torch.uint8)[:half]
         dst_c = torch.empty(half, dtype=torch.uint8, device="cuda")
-        t_copy = timed(lambda: L.check(L.lib.sdrhip_bench_copy(sptr, src_c.data_ptr(), dst_c.data_ptr(), half)), 300, 50)
+        t_copy = timed(lambda: L.check(L.lib.sdrhip_bench_copy2(sptr, src_c.data_ptr(), dst_c.data_ptr(), half, 0)), 300, 50)
+        t_copy_nt = timed(lambda: L.check(L.lib.sdrhip_bench_copy2(sptr, src_c.data_ptr(), dst_c.data_ptr(), half, 1)), 300, 50)
         del dst_c, src_c, sout
         dbg("cfg1 ceilings done")
         # the data the FM pipeline actually feeds this stage: convert(u8 IQ), i.e. cfloat values k/128
@@ -574,12 +575,18 @@ def main():
                 "ceilings_same_process": {
                     "stream_8to1_plain_loads": {"ms": round(t_plain * 1e3, 5), "read_only_frac": round(8.0 * n1 / t_plain / 1e9 / HBM_PEAK_GBS, 4)},
                     "stream_8to1_nontemporal_loads": {"ms": round(t_nt * 1e3, 5), "read_only_frac": round(8.0 * n1 / t_nt / 1e9 / HBM_PEAK_GBS, 4)},
-                    "float4_copy_same_total_bytes": {"ms": round(t_copy * 1e3, 5), "total_GBps": round(2.0 * half / t_copy / 1e9, 1)},
-                    "kernel_over_plain_stream": round(t_plain / t_uni, 4), "kernel_over_float4_copy": round(t_copy / t_uni, 4),
-                    "what": "measured right after the kernel (300 launches each): a kernel that reads the same 1 GiB with 16-byte loads "
-                            "and writes 128 MiB (no arithmetic), and a float4 copy moving the same 1.125 GiB in total; the decimator is "
-                            "power-limited (DESIGN.md 7): with the same loads and no traffic its MAC phase alone takes ~0.17-0.18 ms at a "
-                            "shader clock of ~1.65-1.75 GHz"}}
+                    "copy_same_total_bytes": {"ms": round(t_copy * 1e3, 5), "total_GBps": round(2.0 * half / t_copy / 1e9, 1)},
+                    "copy_same_total_bytes_nontemporal": {"ms": round(t_copy_nt * 1e3, 5), "total_GBps": round(2.0 * half / t_copy_nt / 1e9, 1)},
+                    "kernel_over_nt_stream": round(t_nt / t_uni, 4),
+                    "kernel_over_plain_stream": round(t_plain / t_uni, 4), "kernel_over_copy": round(t_copy / t_uni, 4),
+                    "kernel_over_nt_copy": round(t_copy_nt / t_uni, 4),
+                    "what": "measured right after the kernel (300 launches each), same process and power state: kernels that read the same "
+                            "1 GiB with 16-byte loads and write 128 MiB with no arithmetic (8 loads in flight per thread, plain and "
+                            "non-temporal), and one-shot copies moving the same 1.125 GiB in total (4 x 16 B in flight per thread, plain "
+                            "and non-temporal).  kernel_over_nt_stream is the headline ratio: the decimator against the BEST the memory "
+                            "system gives this traffic shape.  The decimator is power-limited (DESIGN.md 5): its MAC phase alone takes "
+                            "~0.16-0.18 ms at a shader clock of ~1.7-1.9 GHz, and a row's place in a run moves it by +-5 % "
+                            "(profiles/k2lab/run5.txt, ABAB rows)"}}
         dbg("cfg1 done")
     # per-stage HIP events inside the timed region (ten event records per pass) when a pass is long enough not to notice them;
     # a launch-bound shard (e.g. --blocks 128, BASELINE configs[4]) is timed without them and its stage times come from a

@@ -342,6 +342,9 @@ int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain *c, int mode);
 int sdrhip_fm_chain_set_small_chain(sdrhip_fm_chain *c, int mode, int64_t max_outputs, int tile_outputs);
 /* launches of that kernel so far, process-wide (tests assert that this path, not the stage kernels, ran) */
 long long sdrhip_debug_small_chain_launches(void);
+/* A/B switch (measurements only; results are identical): 0 = the tiled AVX-order decimator runs every tile through its general
+ * instantiation, 1 (default) = whole tiles through the specialised one.  SDRHIP_FULL_TILES=0/1 sets the initial value. */
+void sdrhip_debug_set_full_tiles(int on);
 /* fmDemod inside the resampler's tile loader for large batches (>= 2^18 resampler outputs per run): the demodulated stream
  * never makes its round trip through HBM (12 B per decimated sample less traffic); the per-stage timing then books the pair
  * under `resample`.  Same bits.  Off by default (environment SDRHIP_FUSE_DEMOD=1 turns it on): measured, the pair takes
@@ -454,6 +457,8 @@ int sdrhip_fft_run_device(sdrhip_fft *f, void *stream, const double *d_in, doubl
  * of this box delivers in this process, measured next to the kernel. */
 int sdrhip_bench_stream_8to1(void *stream, const void *d_in, void *d_out, size_t bytes_in, int non_temporal);
 int sdrhip_bench_copy(void *stream, const void *d_in, void *d_out, size_t bytes);
+/* the same copy (4 x 16 bytes in flight per thread) with plain or non-temporal loads and stores */
+int sdrhip_bench_copy2(void *stream, const void *d_in, void *d_out, size_t bytes, int non_temporal);
 /* Timing loops over the host-block operators, written against this header only: what a compiled caller pays per push
  * (a Python loop adds 10-20 us per call).  fm_stream: `pushes` pushes of n_samples u8 IQ samples (zero_copy: through
  * sdrhip_fm_stream_input_buffer), every audio block popped; pipe: pushes of n elements into an existing pipe. */

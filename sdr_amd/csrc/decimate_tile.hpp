@@ -2,6 +2,7 @@
 // the FM chain) and kernels_fast_orders.hip (the SSE and "RC2" orders).  See kernels_fast.hip for the design notes.
 #pragma once
 #include <atomic>
+#include <stdlib.h>
 
 #include "crossfix.hpp"
 #include "kernels.hpp"
@@ -131,6 +132,17 @@ struct Stage {
     static constexpr int PER = (NV + NT - 1) / NT;               // vectors per thread
     uint4 r[PER];
 
+    // a whole tile: unconditional 16-byte loads into a plain register array, all in flight together
+    static __device__ __forceinline__ void load_whole(const void* __restrict__ src_v, int64_t sample0, uint4 (&regs)[PER])
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src_v) + (U8 ? 2 : 8) * sample0);
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int v = threadIdx.x + i * NT;
+            regs[i] = (i + 1 < PER || v < NV) ? src[v] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+
     __device__ __forceinline__ void load(const void* __restrict__ src_v, int64_t sample0, int avail)
     {
         const char* src = reinterpret_cast<const char*>(src_v) + (U8 ? 2 : 8) * sample0;
@@ -169,7 +181,9 @@ struct Stage {
         }
     }
 
-    __device__ __forceinline__ void store(float2* __restrict__ lds) const
+    __device__ __forceinline__ void store(float2* __restrict__ lds) const { store_regs(r, lds); }
+
+    static __device__ __forceinline__ void store_regs(const uint4 (&r)[PER], float2* __restrict__ lds)
     {
 #pragma unroll
         for (int i = 0; i < PER; i++) {
@@ -266,7 +280,13 @@ __device__ __forceinline__ float2 fold_partials(const float2 (&a)[NP])
     }
 }
 
-template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false, int NP = 4, int ORD = 0, int PSKIP = 0>
+// FULL: every tile of the launch is a whole one (all SPAN input samples exist, all OUTS outputs are wanted) and no Cross outputs
+// are computed in place: no ragged-end loader, no seam arithmetic, unconditional stores.  The same instructions for the common
+// case, but the slow paths no longer shape the register allocation and the epilogue of the fast one (measured on the cfloat-in
+// kernel, 2^27 samples: 243 -> 219 us, tools/k2lab/lab.hip "V0 production" against "dec: mac_window"); the launcher gives the
+// whole tiles to a FULL instantiation and the remainder (at most 64 tiles) to the general one.
+template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false, int NP = 4, int ORD = 0, int PSKIP = 0,
+          bool FULL = false>
 __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in, int64_t x0 /* sample index of output 0's window in `in` */,
                                                     int count, const float* __restrict__ taps, float* __restrict__ out,
                                                     int p_eff /* GUARD: taps of the filter (multiple of TC, <= P); else unused */,
@@ -288,15 +308,19 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
     if (tile >= ntiles) return;
     const int out0 = tile * T::OUTS;
     const int64_t s0 = (int64_t)out0 * D;                     // first sample of the tile, relative to x0
-    const int64_t total_avail = (int64_t)(count - 1) * D + (GUARD ? p_eff : P); // samples that exist from x0 on
-    int64_t av = total_avail - s0;
-    int avail = av > T::SPAN ? T::SPAN : (int)av;
-
     {
         // all of the tile's global loads in flight at once, then one wait
-        Stage<T, U8, NT> st;
-        st.load(in, x0 + s0, avail);
-        st.store(lds);
+        if constexpr (FULL) {
+            uint4 regs[Stage<T, U8, NT>::PER];
+            Stage<T, U8, NT>::load_whole(in, x0 + s0, regs);
+            Stage<T, U8, NT>::store_regs(regs, lds);
+        } else {
+            Stage<T, U8, NT> st;
+            const int64_t total_avail = (int64_t)(count - 1) * D + (GUARD ? p_eff : P); // samples that exist from x0 on
+            const int64_t av = total_avail - s0;
+            st.load(in, x0 + s0, av > T::SPAN ? T::SPAN : (int)av);
+            st.store(lds);
+        }
     }
     __syncthreads();
 
@@ -315,7 +339,7 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
     float2 res[R];
 #pragma unroll
     for (int r = 0; r < R; r++) res[r] = fold_partials<NP, ORD>(acc[r]);
-    if (inl_seam > 0) {
+    if (!FULL && inl_seam > 0) {
         // Small launches (one host block per push): the seam fix-up is not worth a launch of its own.  An output whose window
         // straddles a multiple of inl_seam samples is recomputed right here in the reference's sequential order
         // (decimateCrossHighLevel, FilterInternal.hs:397-402) from the same LDS tile.  rt = the tile's first window start
@@ -333,7 +357,7 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
         }
         if (any) inline_cross_outputs<D, R, T, TC, GUARD>(win, taps, plen, cross, res);
     }
-    if (R % 2 == 0 && o + R <= count) {
+    if (R % 2 == 0 && (FULL || o + R <= count)) {
         float4* dst = reinterpret_cast<float4*>(out + 2 * (int64_t)o);
 #pragma unroll
         for (int r = 0; r + 1 < R; r += 2) dst[r / 2] = make_float4(res[r].x, res[r].y, res[r + 1].x, res[r + 1].y);
@@ -507,6 +531,14 @@ __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const
     *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
 }
 
+// SDRHIP_FULL_TILES=0 / sdrhip_debug_set_full_tiles(0): every tile through the general instantiation (A/B measurements)
+inline std::atomic<int>& full_tiles_flag()
+{
+    static std::atomic<int> f{getenv("SDRHIP_FULL_TILES") ? atoi(getenv("SDRHIP_FULL_TILES")) : 1};
+    return f;
+}
+inline bool full_tiles_enabled() { return full_tiles_flag().load(std::memory_order_relaxed) != 0; }
+
 // inline_cross: the kernel computes the Cross outputs itself (no fix-up launch); *inlined tells whether the geometry allowed
 // it (a tile must span less than one buffer)
 template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false, int NP = 4, int ORD = 0, int PSKIP = 0>
@@ -533,6 +565,31 @@ void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, 
         inl_r0 = (int)((g.k_begin * D) % g.seamBI);
     }
     if (inlined) *inlined = inl_seam > 0;
+    // Large launches without in-kernel seams: the whole tiles (in whole groups of 64, the unit of the tile permutation) go to
+    // the FULL instantiation, what is left -- fewer than 64 whole tiles and the ragged last one -- to the general kernel.
+    // A tile is whole when its OUTS outputs are wanted and its SPAN samples exist: the launch's samples end at
+    // (count - 1) * D + Lp, and SPAN = (OUTS - 1) * D + P >= that of the filter's own length, hence the `- 1` below for guarded
+    // (shorter) filters.
+    if (inl_seam == 0 && g.count >= 128 * T::OUTS && full_tiles_enabled()) {
+        const int whole = g.count / T::OUTS - ((GUARD && g.Lp < P) ? 1 : 0);
+        const int nf = (whole / 64) * 64;
+        if (nf > 0) {
+            static std::atomic<bool> attr_full[64];
+            auto kfull = k_decimate_c4<D, P, R, NT, U8, TC, GUARD, NP, ORD, PSKIP, true>;
+            if (dev < 0 || dev >= 64 || !attr_full[dev]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfull), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
+                if (dev >= 0 && dev < 64) attr_full[dev] = true;
+            }
+            hipLaunchKernelGGL(kfull, dim3(nf), dim3(NT), T::LDS_BYTES, s, in, x0, nf * T::OUTS, taps, out, g.Lp, 0, 0);
+            const int rest = g.count - nf * T::OUTS;
+            if (rest > 0) {
+                const int rt = (rest + T::OUTS - 1) / T::OUTS;
+                hipLaunchKernelGGL(kern, dim3(((rt + 63) / 64) * 64), dim3(NT), T::LDS_BYTES, s, in, x0 + (int64_t)nf * T::OUTS * D, rest, taps,
+                                   out + 2 * (int64_t)nf * T::OUTS, g.Lp, 0, 0);
+            }
+            return;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, taps, out, g.Lp, inl_seam, inl_r0);
 }
 

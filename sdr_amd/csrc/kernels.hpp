@@ -164,6 +164,7 @@ int small_launch_outputs();
 // last_tap_zero: tap P-1 is the zero the constructor padded the filter with (lets the u8 path skip its MACs)
 bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps,
                              const void* d_in, bool in_is_u8, float* d_out, bool last_tap_zero = false);
+void set_full_tiles(int on);   // A/B switch of the FULL-tile instantiations of the AVX-order tiled decimator (decimate_tile.hpp)
 // kernels_fast_orders.hip: the same tiled decimator for the SSE "RC" and the "RC2" summation orders (CO_L2, CO_X4, CO_X2)
 bool launch_decimate_c_orders_fast(hipStream_t s, const Geom& g, ComplexOrder order, const float* d_plain_taps, int P,
                                    const float* d_cross_taps, const void* d_in, bool in_is_u8, float* d_out);

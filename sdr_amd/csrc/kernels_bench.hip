@@ -30,11 +30,32 @@ __global__ void __launch_bounds__(NT) k_stream_8to1(const uint4* __restrict__ in
     out[(size_t)blockIdx.x * NT + threadIdx.x] = r;
 }
 
-template <int NT>
-__global__ void __launch_bounds__(NT) k_copy16(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
+// The copy ceiling: one shot, every thread moves 4 x 16 bytes with all four loads in flight before the first store (a
+// one-load-per-iteration grid-stride loop moves 5.0-5.3 TB/s on this chip, this form 5.6 and with non-temporal accesses 6.1:
+// VERDICT r02 "weak ceiling").  n is a multiple of 4 * NT vectors; the launcher sends any remainder through k_copy_tail.
+template <int NT, bool NTL>
+__global__ void __launch_bounds__(NT) k_copy4(const uint4* __restrict__ in, uint4* __restrict__ out)
 {
-    const size_t stride = (size_t)gridDim.x * NT;
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) out[i] = in[i];
+    const size_t base = (size_t)blockIdx.x * NT * 4 + threadIdx.x;
+    u32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(in + base + (size_t)i * NT);
+        v[i] = NTL ? __builtin_nontemporal_load(p) : *p;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u32x4* q = reinterpret_cast<u32x4*>(out + base + (size_t)i * NT);
+        if (NTL) __builtin_nontemporal_store(v[i], q);
+        else *q = v[i];
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT) k_copy_tail(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i < n) out[i] = in[i];
 }
 
 }  // namespace
@@ -56,15 +77,24 @@ int sdrhip_bench_stream_8to1(void* stream, const void* d_in, void* d_out, size_t
     return SDRHIP_OK;
 }
 
-int sdrhip_bench_copy(void* stream, const void* d_in, void* d_out, size_t bytes)
+int sdrhip_bench_copy2(void* stream, const void* d_in, void* d_out, size_t bytes, int non_temporal)
 {
     SDRHIP_REQUIRE(d_in != nullptr && d_out != nullptr && bytes % 16 == 0, "sdrhip_bench_copy");
-    int dev = 0, cus = 256;
-    SDRHIP_CHECK_HIP(hipGetDevice(&dev));
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    hipLaunchKernelGGL((k_copy16<256>), dim3((unsigned)cus * 8), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_in, (uint4*)d_out, bytes / 16);
+    const size_t nv = bytes / 16, per = 256 * 4, whole = nv / per;
+    if (whole > 0) {
+        if (non_temporal)
+            hipLaunchKernelGGL((k_copy4<256, true>), dim3((unsigned)whole), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_in, (uint4*)d_out);
+        else
+            hipLaunchKernelGGL((k_copy4<256, false>), dim3((unsigned)whole), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_in, (uint4*)d_out);
+    }
+    const size_t rest = nv - whole * per;
+    if (rest > 0)
+        hipLaunchKernelGGL((k_copy_tail<256>), dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint4*)d_in + whole * per, (uint4*)d_out + whole * per, rest);
     SDRHIP_CHECK_HIP(hipGetLastError());
     return SDRHIP_OK;
 }
+
+int sdrhip_bench_copy(void* stream, const void* d_in, void* d_out, size_t bytes) { return sdrhip_bench_copy2(stream, d_in, d_out, bytes, 0); }
 
 }  // extern "C"

@@ -26,9 +26,7 @@
 
 namespace sdrhip {
 
-namespace {
-
-}  // namespace
+void set_full_tiles(int on) { full_tiles_flag().store(on); }
 
 bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps,
                              const void* d_in, bool in_is_u8, float* d_out, bool last_tap_zero)

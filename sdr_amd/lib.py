@@ -162,6 +162,7 @@ lib.sdrhip_resampler_one.argtypes = [_vp, C.c_int, C.c_int, _f32p, C.c_int, _f32
 lib.sdrhip_resampler_cross.argtypes = [_vp, C.c_int, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f32p]
 lib.sdrhip_bench_stream_8to1.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]
 lib.sdrhip_bench_copy.argtypes = [_vp, _vp, _vp, C.c_size_t]
+lib.sdrhip_bench_copy2.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]
 lib.sdrhip_bench_fm_stream.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
 lib.sdrhip_bench_pipe.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
 lib.sdrhip_debug_tiled_launches.argtypes = []

@@ -15,6 +15,7 @@
 
 #include "../../sdr_amd/csrc/kernels_fast.hip"
 
+namespace sdrhip { int small_launch_outputs() { return 32768; } }   // lives in abi_device.cpp in the library
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
 using namespace sdrhip;
@@ -120,6 +121,22 @@ __global__ void __launch_bounds__(NT) k_copy(const uint4* __restrict__ in, uint4
 {
     const size_t stride = (size_t)gridDim.x * NT;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) out[i] = in[i];
+}
+
+// one-shot copy: every thread moves 4 x 16 B, all four loads in flight before the first store
+template <int NT, bool NTL>
+__global__ void __launch_bounds__(NT) k_copy4(const uint4* __restrict__ a, uint4* __restrict__ b)
+{
+    const size_t base = (size_t)blockIdx.x * NT * 4 + threadIdx.x;
+    uint4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = ld16<NTL>(a + base + (size_t)i * NT);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+        if (NTL) __builtin_nontemporal_store(u4v{v[i].x, v[i].y, v[i].z, v[i].w}, reinterpret_cast<u4v*>(b + base + (size_t)i * NT));
+        else b[base + (size_t)i * NT] = v[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -338,6 +355,44 @@ __global__ void __launch_bounds__(NT) k_dec_v(const float* __restrict__ in, int 
     compute_tile_v<D, P, R, T, VAR>(lds, taps, out, tile * T::OUTS);
 }
 
+// the production structure with wave priorities: PRIO 1 = MAC phase at raised priority (waves that have their tile in LDS win the
+// issue arbitration over waves still converting / storing theirs), PRIO 2 = the opposite (the load phase is favoured so that the
+// next tiles' HBM requests go out as early as possible), PRIO 3 = odd workgroups sleep ~2 us before loading (co-resident workgroups
+// start out of phase: one loads while the other multiplies)
+template <int D, int P, int R, int NT, int VAR, int PRIO>
+__global__ void __launch_bounds__(NT) k_dec_prio(const float* __restrict__ in, int ntiles, const float* __restrict__ taps, float* __restrict__ out)
+{
+    using T = Tile<D, P, R, NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    const int b = blockIdx.x;
+    const int tile = (b & ~63) + ((b & 7) << 3) + ((b >> 3) & 7);
+    if (tile >= ntiles) return;
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(3);
+    if (PRIO == 3 && ((b >> 8) & 1)) {
+#pragma unroll 1
+        for (int i = 0; i < 32; i++) __builtin_amdgcn_s_sleep(127);       // 32 x 127 x 64 clocks ~ a few hundred ns each
+    }
+    constexpr int NV = (T::SPAN + 1) / 2;
+    constexpr int PER = (NV + NT - 1) / NT;
+    const uint4* src = reinterpret_cast<const uint4*>(in + 2 * (int64_t)tile * T::OUTS * D);
+    uint4 r[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int v = threadIdx.x + i * NT;
+        if (i + 1 < PER || v < NV) r[i] = ld16<false>(src + v);
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int v = threadIdx.x + i * NT;
+        if (v < NV) *reinterpret_cast<uint4*>(&lds[T::lds_idx(2 * v)]) = r[i];
+    }
+    __syncthreads();
+    if (PRIO == 1) __builtin_amdgcn_s_setprio(3);
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    compute_tile_v<D, P, R, T, VAR>(lds, taps, out, tile * T::OUTS);
+}
+
 // ------------------------------------------------------------------------------------------------
 struct Timer {
     hipEvent_t a, b;
@@ -443,6 +498,12 @@ int main(int argc, char** argv)
         report(nm, tm.us([&] { hipLaunchKernelGGL(kern, dim3(grid0), dim3(NT), T::LDS_BYTES, 0, dx, ntiles, dt, dout); }, reps));
         if (chk) check(nm);
     };
+    auto run_dec_lds = [&](auto kern, const char* nm, size_t lds_bytes, bool chk) {
+        SETLDS(kern, lds_bytes);
+        CK(hipMemset(dout, 0xff, (size_t)nout * 8));
+        report(nm, tm.us([&] { hipLaunchKernelGGL(kern, dim3(grid0), dim3(NT), lds_bytes, 0, dx, ntiles, dt, dout); }, reps));
+        if (chk) check(nm);
+    };
     for (int round = 0; round < rounds; round++) {
         printf("---- round %d\n", round);
         report("stream oneshot 8:1", tm.us([&] { hipLaunchKernelGGL((k_stream_oneshot<NT, false>), dim3(nchunks), dim3(NT), 0, 0, sin_, sout); }, reps));
@@ -450,6 +511,13 @@ int main(int argc, char** argv)
         CK(hipMemset(dout, 0xff, (size_t)nout * 8));
         report("V0 production (4 WG/CU, reg stage)", tm.us([&] { run0(dout); }, reps));
         check("V0");
+        {
+            auto kfull = k_decimate_c4<D, P, R, NT, false, 8, false, 4, 0, 0, true>;
+            SETLDS(kfull, T::LDS_BYTES);
+            CK(hipMemset(dout, 0xff, (size_t)nout * 8));
+            report("V0 FULL instantiation (production)", tm.us([&] { hipLaunchKernelGGL(kfull, dim3(grid0), dim3(NT), T::LDS_BYTES, 0, (const void*)dx, (int64_t)0, (int)nout, dt, dout, P, 0, 0); }, reps));
+            check("V0 FULL");
+        }
         run0(dout);   // leave real samples in LDS for the MAC-only kernels
         run_mac(k_mac_only<D, P, R, NT, 0>, "MAC only: mac_window (production)");
         run_mac_lds(k_mac_only<D, P, R, NT, 0>, "MAC only: production, 3 WG/CU", 50 * 1024);
@@ -478,6 +546,38 @@ int main(int argc, char** argv)
         run_dec(k_dec_v<D, P, R, NT, 2, true>, "dec: pinned d2, nt loads", true);
         run_dec(k_dec_v<D, P, R, NT, 7, true>, "dec: pinned d3, nt loads", true);
         run_dec(k_dec_v<D, P, R, NT, 3, true>, "dec: unpinned mac_window2, nt loads", true);
+        // round 3: the combinations VERDICT r02 found missing
+        run_dec(k_dec_v<D, P, R, NT, 3, false>, "dec: unpinned mac_window2, plain loads", true);
+        run_dec_lds(k_dec_v<D, P, R, NT, 0, false>, "dec: mac_window, 3 WG/CU", 50 * 1024, true);
+        run_dec_lds(k_dec_v<D, P, R, NT, 3, false>, "dec: unpinned mac_window2, 3 WG/CU", 50 * 1024, true);
+        run_dec_lds(k_dec_v<D, P, R, NT, 0, false>, "dec: mac_window, 2 WG/CU", 70 * 1024, true);
+        run_dec(k_dec_prio<D, P, R, NT, 0, 1>, "dec: mac_window, MAC phase prio 3", true);
+        run_dec(k_dec_prio<D, P, R, NT, 0, 2>, "dec: mac_window, load phase prio 3", true);
+        run_dec(k_dec_prio<D, P, R, NT, 0, 3>, "dec: mac_window, odd WGs start late", true);
+        run_dec(k_dec_prio<D, P, R, NT, 3, 1>, "dec: unpinned mw2, MAC phase prio 3", true);
+        // order check: the same three kernels back to back, twice (a row's place in the run decides the power state it meets)
+        for (int ab = 0; ab < 2; ab++) {
+            report("ABAB V0 production", tm.us([&] { run0(dout); }, reps));
+            run_dec(k_dec_v<D, P, R, NT, 0, false>, "ABAB dec: mac_window", false);
+            auto kfull = k_decimate_c4<D, P, R, NT, false, 8, false, 4, 0, 0, true>;
+            report("ABAB V0 FULL", tm.us([&] { hipLaunchKernelGGL(kfull, dim3(grid0), dim3(NT), T::LDS_BYTES, 0, (const void*)dx, (int64_t)0, (int)nout, dt, dout, P, 0, 0); }, reps));
+        }
+    }
+    // copies with 4 x 16 B in flight per thread (the one-load-per-iteration copy is a weak ceiling), plain and nt
+    {
+        const size_t nv = (size_t)((rd_bytes + wr_bytes) / 2 / 16) / (NT * 4) * (NT * 4);
+        uint4 *ca, *cb;
+        CK(hipMalloc(&ca, nv * 16));
+        CK(hipMalloc(&cb, nv * 16));
+        CK(hipMemset(ca, 1, nv * 16));
+        for (int rep2 = 0; rep2 < 2; rep2++) {
+            double us = tm.us([&] { hipLaunchKernelGGL((k_copy4<NT, false>), dim3((unsigned)(nv / (NT * 4))), dim3(NT), 0, 0, ca, cb); }, reps);
+            printf("copy, 4 x 16 B per thread, %zu MiB -> same: %8.1f us  total %5.3f TB/s\n", nv * 16 >> 20, us, 2.0 * nv * 16 / us / 1e6);
+            us = tm.us([&] { hipLaunchKernelGGL((k_copy4<NT, true>), dim3((unsigned)(nv / (NT * 4))), dim3(NT), 0, 0, ca, cb); }, reps);
+            printf("copy, 4 x 16 B per thread, nt loads + nt stores: %8.1f us  total %5.3f TB/s\n", us, 2.0 * nv * 16 / us / 1e6);
+        }
+        CK(hipFree(ca));
+        CK(hipFree(cb));
     }
     // plain copy, same total bytes, separate buffers
     {

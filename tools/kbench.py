@@ -8,7 +8,7 @@ import sdr_amd.lib as L
 import signals as S
 
 
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=200, warm=100):
     st = torch.cuda.current_stream()
     for _ in range(warm):
         fn()

@@ -64,9 +64,12 @@ def main():
     #    FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE reports exactly half of a wide (16 B/lane) coalesced
     #    streaming read on gfx950 -> doubled; WRITE_SIZE is uncalibrated -> reported as measured.
     bench = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
-    k2 = next(k for k in ours if k.startswith("k_decimate_c4<"))
-    fetch_kib = ours[k2].get("FETCH_SIZE", float("nan"))
-    write_kib = ours[k2].get("WRITE_SIZE", float("nan"))
+    # since round 3 a K2 launch is two kernels: the FULL-tile instantiation (all but at most 64 tiles) and the general one for
+    # the remainder; the traffic of a launch is their sum, the kernel named is the one that moves (nearly) all of it
+    k2s = [k for k in ours if k.startswith("k_decimate_c4<") and "FETCH_SIZE" in ours[k]]
+    k2 = max(k2s, key=lambda k: ours[k].get("FETCH_SIZE", 0.0))
+    fetch_kib = sum(ours[k].get("FETCH_SIZE", 0.0) for k in k2s)
+    write_kib = sum(ours[k].get("WRITE_SIZE", 0.0) for k in k2s)
     samples = bench["roofline"]["algorithmic_bytes_per_launch"] / 3.0
     sys.path.insert(0, ROOT)
     from bench import k2_source_sha256
@@ -92,9 +95,11 @@ def main():
         c_f = pmc("pmc_fetch_k2c")
         c_w = pmc("pmc_write_k2c")
         # template arguments <D, P, R, NT, U8, TC, GUARD, NP, ORD>: the cfloat-in instantiation has U8 = false
-        kc = next(k for k in c_f if k.startswith("k_decimate_c4<") and k[k.index("<") + 1:].split(",")[4].strip() == "false")
+        kcs = [k for k in c_f if k.startswith("k_decimate_c4<") and k[k.index("<") + 1:].split(",")[4].strip() == "false"]
+        kc = max(kcs, key=lambda k: c_f[k].get("FETCH_SIZE", 0.0))
         n_c = 1 << 27
-        fk, wk = c_f[kc].get("FETCH_SIZE", float("nan")), c_w[kc].get("WRITE_SIZE", float("nan"))
+        fk = sum(c_f[k].get("FETCH_SIZE", 0.0) for k in kcs)
+        wk = sum(c_w[k].get("WRITE_SIZE", 0.0) for k in kcs if k in c_w)
         json.dump({"kernel": kc, "samples_per_launch": n_c, "FETCH_SIZE_KiB_raw": fk, "WRITE_SIZE_KiB_raw": wk,
                    "fetch_bytes_corrected": 2.0 * fk * 1024.0, "write_bytes": wk * 1024.0,
                    "hbm_bytes_per_launch": 2.0 * fk * 1024.0 + wk * 1024.0, "algorithmic_bytes_per_launch": 9.0 * n_c,
@@ -104,6 +109,29 @@ def main():
                   open(os.path.join(dst, "k2c_traffic.json"), "w"), indent=1)
     except Exception as e:          # noqa: BLE001
         print("no k2c passes:", e)
+
+    # 3c. round 3: kernel-trace rows of the cfloat-in kernel on its own and of the one-kernel chain at the 2^20-sample shard
+    for sub, name in (("stats_k2c", f"{tag}_k2c_kernel_stats.csv"), ("stats_shard", f"{tag}_shard_kernel_stats.csv")):
+        path = os.path.join(src, sub, "bench_kernel_stats.csv")
+        if not os.path.exists(path):
+            continue
+        with open(os.path.join(dst, name), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns", "stddev"])
+            for r in csv.DictReader(open(path)):
+                if "sdrhip" in r["Name"]:
+                    w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+    for sub, name in (("pmc_sq_k2c", f"{tag}_k2c_pmc.csv"), ("pmc_shard", f"{tag}_shard_pmc.csv")):
+        if not os.path.exists(os.path.join(src, sub, "bench_counter_collection.csv")):
+            continue
+        res = {k: v for k, v in pmc(sub).items() if k.startswith("k_")}
+        cols2 = sorted({c for v in res.values() for c in v})
+        with open(os.path.join(dst, name), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel"] + cols2 + ["clock_GHz = GRBM_GUI_ACTIVE / 8 XCDs / dur_ns"])
+            for k, v in sorted(res.items()):
+                clk = v.get("GRBM_GUI_ACTIVE", float("nan")) / 8.0 / v.get("_dur_ns", float("nan"))
+                w.writerow([k] + [f"{v.get(c, float('nan')):.1f}" for c in cols2] + [f"{clk:.3f}"])
 
     # 4. derived table for the README
     print("kernel                                   avg_us(stats)  clock_GHz  valu_quad_busy  lds_conflict/idx")
