@@ -57,11 +57,12 @@ struct sdrhip_fm_chain {
     // SDRHIP_FUSED_TAIL=0/1/2.
     int fused_tail = getenv("SDRHIP_FUSED_TAIL") ? atoi(getenv("SDRHIP_FUSED_TAIL")) : 2;
     bool fuse_demod = getenv("SDRHIP_FUSE_DEMOD") ? atoi(getenv("SDRHIP_FUSE_DEMOD")) != 0 : false;   // fmDemod in the resampler's tile loader
+    bool tail_shape_any() const { return !resamp.cplx && resamp.lanes == 8 && !audio.cplx && audio.sym && audio.lanes == 8 && audio.factor == 1; }
     bool tail_shape_ok(int64_t n_out) const
     {
         // auto: runs of up to two source blocks (measured per push, in place: fused 27.3 / 29.1 / 36.6 us for 1 / 2 / 4 blocks,
         // the stage kernels on their one-launch routes 30.0 / 30.7 / 32.6 -- the single workgroup of a one-tile run is serial)
-        if (fused_tail == 0 || (fused_tail == 2 && n_out > kFusedTailAutoOutputs)) return false;
+        if (fused_tail == 0 || fused_tail == 3 || (fused_tail == 2 && n_out > kFusedTailAutoOutputs)) return false;
         return !resamp.cplx && resamp.lanes == 8 && !audio.cplx && audio.sym && audio.lanes == 8 && audio.factor == 1;
     }
     // The whole chain as one kernel for launch-bound runs (kernels_small.hip): 0 = never, 1 = whenever the configuration is the
@@ -419,6 +420,31 @@ int sdrhip_fm_chain_run(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
             }
             if (c->timing && c->ev_used > 0) c->ev_used--;      // the span's begin event goes back to the pool
         }
+        if (c->fused_tail == 3 && c->tail_shape_any()) {
+            // K3 as its own kernel, then resampler + filter (* gain) fused: z never reaches HBM, no fix-up launches (mode 3)
+            if ((rc = c->resamp.ensure_device()) != SDRHIP_OK || (rc = c->audio.ensure_device()) != SDRHIP_OK) return rc;
+            if ((rc = begin_span(1, st, &b)) != SDRHIP_OK) return rc;
+            launch_fm_demod_fast(st, d_d + 2 * (r.ky0 - r.kd0), d_y, r.ky1 - r.ky0, r.ky0 > r.kd0, 0.0f, 0.0f);
+            if ((rc = end_span(1, st, b)) != SDRHIP_OK) return rc;
+            if ((rc = begin_span(4, st, &b)) != SDRHIP_OK) return rc;
+            const bool took = launch_fm_tail_fused(st, d_d, r.kd0, r.kd1, r.ky0, r.ky1, d_audio + (r.q0 - q0), r.q0, r.q1, c->resamp.d_groups,
+                                                   c->resamp.row_stride, c->resamp.nloop, c->resamp.increments.data(), c->resamp.num_groups,
+                                                   c->resamp.I, c->resamp.D, c->resamp.Lp, c->resamp.d_plain, c->resamp.ntaps, c->audio.d_taps,
+                                                   c->audio.ntaps_kernel, c->audio.d_cross, c->gain, c->block, d_y);
+            if (took) {
+                if ((rc = end_span(4, st, b)) != SDRHIP_OK) return rc;
+                continue;
+            }
+            if (c->timing && c->ev_used > 0) c->ev_used--;
+            // not the FM receiver's shape: y is in place, the stage kernels finish the run
+            if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;
+            if ((rc = resamp_run(&c->resamp, st, d_y, r.ky0, d_z, r.m0, r.m1, c->block, c->block)) != SDRHIP_OK) return rc;
+            if ((rc = end_span(2, st, b)) != SDRHIP_OK) return rc;
+            if ((rc = begin_span(3, st, &b)) != SDRHIP_OK) return rc;
+            if ((rc = fir_run(&c->audio, st, d_z, false, r.m0, d_audio + (r.q0 - q0), r.q0, r.q1, c->block, c->gain)) != SDRHIP_OK) return rc;
+            if ((rc = end_span(3, st, b)) != SDRHIP_OK) return rc;
+            continue;
+        }
         if (c->fuse_demod) {
             // K3+K4: fmDemod inside the resampler's tile loader on large batches (y never reaches HBM), a stand-alone fmDemod
             // launch first otherwise; timed as the resample stage
@@ -509,7 +535,7 @@ int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain* c, int nsub)
 
 int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain* c, int enable)
 {
-    SDRHIP_REQUIRE(c != nullptr && enable >= 0 && enable <= 2, "sdrhip_fm_chain_set_fused_tail");
+    SDRHIP_REQUIRE(c != nullptr && enable >= 0 && enable <= 3, "sdrhip_fm_chain_set_fused_tail");
     c->fused_tail = enable;
     return SDRHIP_OK;
 }
@@ -585,9 +611,17 @@ struct sdrhip_fm_stream {
     sdrhip_fm_chain* c = nullptr;
     int max_block = 0;
     int block_out = 0;
-    hipStream_t compute = nullptr, compute2 = nullptr, up = nullptr, down = nullptr;   // compute2: odd slots of in-place pushes
-    DevBuf din[2];         // device input of the two slots (copy mode)
-    DevBuf ws, ws2;        // one workspace per compute stream
+    // Slots: submissions in flight.  Two for operators that take large pushes (upload of block i over compute of i-1 over
+    // download of i-2, each slot holding a pinned staging buffer of the largest push); FOUR for operators whose largest push
+    // runs in place (round 3): such a push is one small kernel, i.e. ~20 us of latency end to end over PCIe, and the host is
+    // done submitting it in ~6 -- the slots are what keeps the GPU fed.  Results then lag three pushes instead of one
+    // (sdrhip_fm_stream_flush drains; SDRHIP_STREAM_SLOTS=2 restores the short lag).
+    static constexpr int kMaxSlots = 4;
+    int nslots = 2;
+    hipStream_t compute[kMaxSlots] = {nullptr, nullptr, nullptr, nullptr};   // compute[0]: copy mode; compute[si]: in-place pushes of slot si
+    hipStream_t up = nullptr, down = nullptr;
+    DevBuf din[kMaxSlots];   // device input of the slots (copy mode)
+    DevBuf ws[kMaxSlots];    // one workspace per compute stream
     int64_t N = 0;         // samples received so far
     int64_t q_done = 0;    // audio outputs computed so far
     int64_t head_cap = 0;  // samples of room in front of the staged samples (for the carried tail), multiple of 8
@@ -604,8 +638,9 @@ struct sdrhip_fm_stream {
         int64_t n_out = 0;
         bool busy = false;
         bool direct = false;       // the last submission ran in place: `ev` also releases the staging buffer
-    } slot[2];
-    int64_t pushes = 0;        // submissions so far (slot = pushes & 1)
+    } slot[kMaxSlots];
+    int64_t pushes = 0;        // submissions so far (slot = pushes % nslots)
+    int cur() const { return (int)(pushes % nslots); }
     int staged = 0;            // samples copied into the current slot's staging buffer, not yet submitted
     int coalesce = 0;          // submit once this many samples are staged (0: every push)
     int capacity() const { return coalesce > max_block ? coalesce : max_block; }
@@ -614,12 +649,12 @@ struct sdrhip_fm_stream {
 
     ~sdrhip_fm_stream()
     {
-        for (hipStream_t st : {up, compute, compute2, down})
+        for (hipStream_t st : {up, compute[0], compute[1], compute[2], compute[3], down})
             if (st) (void)hipStreamSynchronize(st);
         for (auto& sl : slot)
             for (hipEvent_t e : {sl.ev, sl.ev_up, sl.ev_k})
                 if (e) (void)hipEventDestroy(e);
-        for (hipStream_t st : {up, compute, compute2, down})
+        for (hipStream_t st : {up, compute[0], compute[1], compute[2], compute[3], down})
             if (st) (void)hipStreamDestroy(st);
     }
     int ready() const { return (int)((fifo.size() - head) / (size_t)block_out); }
@@ -654,8 +689,16 @@ int sdrhip_fm_stream_create(sdrhip_fm_stream** out, sdrhip_fm_chain* chain, int 
     // the carried tail never exceeds the receptive field of one audio output (+ the 8-sample alignment of its start)
     st->head_cap = (sdrhip_fm_chain_max_halo(chain) + 8 + 15) / 8 * 8;
     st->hist.resize((size_t)(2 * st->head_cap));
-    hipError_t e = hipStreamCreateWithFlags(&st->compute, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->compute2, hipStreamNonBlocking);
+    // four slots when even the largest push runs in place (see the struct), else two
+    {
+        const char* env = getenv("SDRHIP_STREAM_SLOTS");
+        int want = (st->direct_ok && st->head_cap + (int64_t)max_block_samples <= st->direct_samples) ? sdrhip_fm_stream::kMaxSlots : 2;
+        if (env && atoi(env) >= 2 && atoi(env) <= sdrhip_fm_stream::kMaxSlots) want = atoi(env);
+        st->nslots = want;
+    }
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < st->nslots; i++)
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->compute[i], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->up, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->down, hipStreamNonBlocking);
     for (auto& sl : st->slot)
@@ -681,7 +724,7 @@ static int stream_submit(sdrhip_fm_stream* st)
     sdrhip_fm_chain* c = st->c;
     const int n = st->staged;
     if (n == 0) return SDRHIP_OK;
-    const int si = (int)(st->pushes & 1);
+    const int si = st->cur();
     sdrhip_fm_stream::Slot& sl = st->slot[si];
     int rc;
     // outputs whose receptive field is complete once these samples are in
@@ -714,8 +757,8 @@ static int stream_submit(sdrhip_fm_stream* st)
     // In-place pushes alternate between two compute streams (and workspaces): a push of one source block is a few small
     // kernels, i.e. latency, and nothing push i+1 computes depends on what push i left on the device (the carried tail
     // comes from the host-side history) -- so two consecutive pushes overlap on the GPU.
-    hipStream_t cs = (direct && (si & 1)) ? st->compute2 : st->compute;
-    DevBuf& wsb_buf = (direct && (si & 1)) ? st->ws2 : st->ws;
+    hipStream_t cs = direct ? st->compute[si] : st->compute[0];
+    DevBuf& wsb_buf = direct ? st->ws[si] : st->ws[0];
     if (n_out > 0) {
         const size_t wsb = sdrhip_fm_chain_workspace_bytes(c, tail + n);
         if (wsb > wsb_buf.cap) {
@@ -744,11 +787,11 @@ static int stream_submit(sdrhip_fm_stream* st)
         SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, st->up));
         sl.direct = false;
         if (n_out > 0) {
-            SDRHIP_CHECK_HIP(hipStreamWaitEvent(st->compute, sl.ev_up, 0));
+            SDRHIP_CHECK_HIP(hipStreamWaitEvent(st->compute[0], sl.ev_up, 0));
             if ((rc = sl.dout.ensure((size_t)n_out * 4)) != SDRHIP_OK) return rc;
-            if ((rc = sdrhip_fm_chain_run(c, (void*)st->compute, (const uint8_t*)dbuf.p, keep_from, tail + n, (float*)sl.dout.p,
-                                          st->q_done, q_new, st->ws.p, st->ws.cap)) != SDRHIP_OK) return rc;
-            SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, st->compute));
+            if ((rc = sdrhip_fm_chain_run(c, (void*)st->compute[0], (const uint8_t*)dbuf.p, keep_from, tail + n, (float*)sl.dout.p,
+                                          st->q_done, q_new, st->ws[0].p, st->ws[0].cap)) != SDRHIP_OK) return rc;
+            SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, st->compute[0]));
             SDRHIP_CHECK_HIP(hipStreamWaitEvent(st->down, sl.ev_k, 0));
             SDRHIP_CHECK_HIP(hipMemcpyAsync(sl.hout.p, sl.dout.p, (size_t)n_out * 4, hipMemcpyDeviceToHost, st->down));
             SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, st->down));
@@ -760,16 +803,16 @@ static int stream_submit(sdrhip_fm_stream* st)
     st->N = N1;
     st->pushes++;
     st->staged = 0;
-    return st->harvest(si ^ 1);
+    return st->harvest(st->cur());      // the oldest submission: its slot is the next to be filled
 }
 
 // make the current slot's staging buffer writable (its previous upload / in-place read and its download are over)
 static int stream_open_slot(sdrhip_fm_stream* st)
 {
-    sdrhip_fm_stream::Slot& sl = st->slot[st->pushes & 1];
+    sdrhip_fm_stream::Slot& sl = st->slot[st->cur()];
     int rc;
     if (st->staged == 0) {
-        if ((rc = st->harvest((int)(st->pushes & 1))) != SDRHIP_OK) return rc;
+        if ((rc = st->harvest(st->cur())) != SDRHIP_OK) return rc;
         SDRHIP_CHECK_HIP(hipEventSynchronize(sl.direct ? sl.ev : sl.ev_up));
     }
     return sl.hin.ensure((size_t)(st->head_cap + st->capacity()) * 2);
@@ -782,7 +825,8 @@ int sdrhip_fm_stream_set_coalesce(sdrhip_fm_stream* st, int samples)
     SDRHIP_REQUIRE(st != nullptr && samples >= 0, "sdrhip_fm_stream_set_coalesce");
     SDRHIP_REQUIRE(st->staged == 0, "sdrhip_fm_stream_set_coalesce: samples are staged (flush first)");
     SDRHIP_REQUIRE(st->c->block == 0 || samples % st->c->block == 0, "sdrhip_fm_stream_set_coalesce: whole source blocks only");
-    for (hipStream_t s : {st->up, st->compute, st->compute2, st->down}) SDRHIP_CHECK_HIP(hipStreamSynchronize(s));   // staging buffers may be reallocated
+    for (hipStream_t s : {st->up, st->compute[0], st->compute[1], st->compute[2], st->compute[3], st->down})
+        if (s) SDRHIP_CHECK_HIP(hipStreamSynchronize(s));   // staging buffers may be reallocated
     st->coalesce = samples;
     return SDRHIP_OK;
 }
@@ -793,7 +837,7 @@ uint8_t* sdrhip_fm_stream_input_buffer(sdrhip_fm_stream* st)
     // the caller may write up to max_block samples: make room for all of them behind what is already staged
     if (st->staged + st->max_block > st->capacity() && stream_submit(st) != SDRHIP_OK) return nullptr;
     if (stream_open_slot(st) != SDRHIP_OK) return nullptr;
-    return st->staged_base(st->slot[st->pushes & 1]) + (size_t)st->staged * 2;
+    return st->staged_base(st->slot[st->cur()]) + (size_t)st->staged * 2;
 }
 
 int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
@@ -804,7 +848,7 @@ int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
     int rc;
     if (st->staged + n > st->capacity() && (rc = stream_submit(st)) != SDRHIP_OK) return rc;
     if ((rc = stream_open_slot(st)) != SDRHIP_OK) return rc;
-    uint8_t* dst = st->staged_base(st->slot[st->pushes & 1]) + (size_t)st->staged * 2;
+    uint8_t* dst = st->staged_base(st->slot[st->cur()]) + (size_t)st->staged * 2;
     if (iq != dst) memcpy(dst, iq, (size_t)n * 2);   // else: the caller filled our staging buffer in place
     st->staged += n;
     if (st->staged >= st->coalesce && (rc = stream_submit(st)) != SDRHIP_OK) return rc;
@@ -816,9 +860,9 @@ int sdrhip_fm_stream_flush(sdrhip_fm_stream* st)
     SDRHIP_REQUIRE(st != nullptr, "sdrhip_fm_stream_flush");
     int rc;
     if ((rc = stream_submit(st)) != SDRHIP_OK) return rc;
-    const int first = (int)(st->pushes & 1);
-    if ((rc = st->harvest(first)) != SDRHIP_OK) return rc;
-    if ((rc = st->harvest(first ^ 1)) != SDRHIP_OK) return rc;
+    const int first = st->cur();        // oldest first: the audio goes into the fifo in push order
+    for (int k = 0; k < st->nslots; k++)
+        if ((rc = st->harvest((first + k) % st->nslots)) != SDRHIP_OK) return rc;
     return st->ready();
 }
 

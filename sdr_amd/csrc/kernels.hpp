@@ -149,7 +149,7 @@ constexpr int kTailTileOutputs = 2046;   // audio outputs one workgroup of the f
 bool launch_fm_tail_fused(hipStream_t s, const float* d_d, int64_t kd0, int64_t kd1, int64_t ky0, int64_t ky1, float* d_audio,
                           int64_t q0, int64_t q1, const float* d_groups, int row_stride, int nloop, const int* increments,
                           int ngroups, int I, int D, int rLp, const float* d_rplain, int ntaps, const float* d_fhalf, int nhalf,
-                          const float* d_fplain, float gain, int64_t seam);
+                          const float* d_fplain, float gain, int64_t seam, const float* d_y = nullptr);
 // kernels_small.hip: the WHOLE chain (u8 IQ -> /8 decimator -> fmDemod -> 3/10 resampler -> symmetric filter * gain) as one
 // kernel for launch-bound runs; d_in holds samples [s0, s0 + n_in).  tile_outputs: audio outputs per workgroup (0 = chosen
 // from the size of the run).  false = the configuration is not the FM chain's, nothing launched

@@ -343,6 +343,9 @@ def test_fused_tail_equals_stage_kernels(hip, oracle, block):
         ch.set_fused_tail(1)
         got = _run(hip, ch, d, 0, total, a, b)
         assert_bit_equal(got, ref, f"fused tail, block {block}, outputs [{a},{b})")
+        ch.set_fused_tail(3)              # fmDemod as its own kernel, resampler + filter fused
+        got = _run(hip, ch, d, 0, total, a, b)
+        assert_bit_equal(got, ref, f"fmDemod + fused resampler/filter, block {block}, outputs [{a},{b})")
     if block == B:
         exp = _model(oracle, u8, nblk)
         ch.set_fused_tail(1)
