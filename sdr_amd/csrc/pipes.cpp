@@ -40,13 +40,18 @@ struct sdrhip_pipe {
     bool cplx_in = false, cplx_out = false;
     int I = 1, D = 1, Lp = 1;
 
-    hipStream_t stream = nullptr;   // compute
-    hipStream_t stream2 = nullptr;  // compute, odd slots of in-place pushes (consecutive pushes overlap on the GPU)
+    // Slots = submissions in flight (round 3: four; SDRHIP_STREAM_SLOTS=2..4).  An in-place push of one host block is one
+    // small kernel, ~20 us of latency end to end over PCIe, and the host is done submitting it in ~6: the slots keep the GPU
+    // fed.  Results lag nslots - 1 pushes (sdrhip_pipe_flush drains).
+    static constexpr int kMaxSlots = 4;
+    int nslots = kMaxSlots;
+    hipStream_t stream = nullptr;   // compute (copy mode, map pipes)
+    hipStream_t cstream[kMaxSlots] = {nullptr, nullptr, nullptr, nullptr};   // compute of the in-place pushes of slot si (cstream[0] == stream)
     hipStream_t up = nullptr;       // H2D
     hipStream_t down = nullptr;     // D2H
-    // device input of the two slots (copy mode), each holding [tail | blocks]; map pipes alternate them by `cur`
-    DevBuf din[2];
-    int cur = 0;
+    // device input of the slots (copy mode), each holding [tail | blocks]
+    DevBuf din[kMaxSlots];
+    int cur_slot() const { return (int)(pushes % nslots); }
     // FIR-like pipes: room (elements) in front of the staged elements for the carried tail, and the host-side history
     // it is copied from: the stream's last hist_n elements
     int64_t head_cap = 0;
@@ -73,7 +78,7 @@ struct sdrhip_pipe {
         int64_t n_out = 0;   // elements produced by the in-flight work
         bool busy = false;
         bool direct = false; // the last submission ran in place: `ev` also releases the staging buffer
-    } slot[2];
+    } slot[kMaxSlots];
     int64_t pushes = 0;
 
     // produced output floats not yet popped: contiguous storage + read cursor (memcpy in/out)
@@ -91,12 +96,12 @@ struct sdrhip_pipe {
 
     ~sdrhip_pipe()
     {
-        for (hipStream_t st : {up, stream, stream2, down})
+        for (hipStream_t st : {up, stream, cstream[1], cstream[2], cstream[3], down})
             if (st) (void)hipStreamSynchronize(st);
         for (auto& s : slot)
             for (hipEvent_t e : {s.ev, s.ev_up, s.ev_k})
                 if (e) (void)hipEventDestroy(e);
-        for (hipStream_t st : {up, stream, stream2, down})
+        for (hipStream_t st : {up, stream, cstream[1], cstream[2], cstream[3], down})
             if (st) (void)hipStreamDestroy(st);
     }
 };
@@ -105,8 +110,12 @@ static int pipe_new(sdrhip_pipe** out, PipeKind kind)
 {
     sdrhip_pipe* p = new sdrhip_pipe();
     p->kind = kind;
+    if (const char* env = getenv("SDRHIP_STREAM_SLOTS"))
+        if (atoi(env) >= 2 && atoi(env) <= sdrhip_pipe::kMaxSlots) p->nslots = atoi(env);
     hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking);
+    p->cstream[0] = p->stream;
+    for (int i = 1; i < p->nslots; i++)
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->cstream[i], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking);
     for (auto& sl : p->slot)
@@ -162,7 +171,7 @@ static int ready_blocks(const sdrhip_pipe* p)
 // outputs straddling the boundary with the previous block first (all Cross), then the ones inside the new block (all One).
 static int fir_submit(sdrhip_pipe* p, int n, int64_t uniform_seam)
 {
-    const int si = (int)(p->pushes & 1);
+    const int si = p->cur_slot();
     sdrhip_pipe::Slot& sl = p->slot[si];
     int rc;
     const size_t ein = (size_t)p->esz_in() * 4, eout = (size_t)p->esz_out() * 4;
@@ -205,9 +214,9 @@ static int fir_submit(sdrhip_pipe* p, int n, int64_t uniform_seam)
         p->hist_n = keep;
     }
     const bool direct = p->direct_ok && (size_t)(tail + n) * ein <= sdrhip_pipe::kDirectBytes;
-    // in-place pushes alternate between two compute streams: nothing push i+1 computes depends on what push i left on the
+    // in-place pushes go to their slot's own compute stream: nothing push i+1 computes depends on what push i left on the
     // device (the carried tail comes from the host-side history), so consecutive pushes overlap on the GPU
-    hipStream_t cs = (direct && (si & 1)) ? p->stream2 : p->stream;
+    hipStream_t cs = direct ? p->cstream[si] : p->stream;
     const float* din = nullptr;
     if (direct) {
         din = (const float*)sl.hin.dev_ptr(first);
@@ -266,16 +275,16 @@ static int fir_submit(sdrhip_pipe* p, int n, int64_t uniform_seam)
     p->E_prev = E;
     p->pushes++;
     p->staged = 0;
-    return harvest(p, si ^ 1);
+    return harvest(p, p->cur_slot());     // the oldest submission: its slot is the next to be filled
 }
 
 // make the current slot's pinned staging buffer writable and big enough
 static int fir_open_slot(sdrhip_pipe* p, size_t elems)
 {
-    sdrhip_pipe::Slot& sl = p->slot[p->pushes & 1];
+    sdrhip_pipe::Slot& sl = p->slot[p->cur_slot()];
     int rc;
     if (p->staged == 0) {
-        if ((rc = harvest(p, (int)(p->pushes & 1))) != SDRHIP_OK) return rc;
+        if ((rc = harvest(p, p->cur_slot())) != SDRHIP_OK) return rc;
         SDRHIP_CHECK_HIP(hipEventSynchronize(sl.direct ? sl.ev : sl.ev_up));   // the slot's previous upload / in-place read has left the buffer
     }
     const size_t head_bytes = (size_t)p->head_cap * p->esz_in() * 4;
@@ -335,8 +344,8 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
     }
     // zero-copy push: `block` is the staging buffer's own write position (sdrhip_pipe_input_buffer); noted before the
     // buffer can be re-allocated below (growth keeps the lent region, so the data is then already in place)
-    const bool in_place = p->slot[p->pushes & 1].hin.p != nullptr &&
-                          block == p->staged_base(p->slot[p->pushes & 1]) + (size_t)p->staged * p->esz_in();
+    const bool in_place = p->slot[p->cur_slot()].hin.p != nullptr &&
+                          block == p->staged_base(p->slot[p->cur_slot()]) + (size_t)p->staged * p->esz_in();
     const uint64_t pushes_at_entry = (uint64_t)p->pushes;
     if (!coalescing && p->staged > 0) {
         // a block of another size ends the uniform run: what is staged goes out as one uniform batch first
@@ -353,7 +362,7 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
     p->all_uniform = all_uniform;
     const int64_t cap = coalescing ? (int64_t)p->coalesce * p->uniform_n : n;
     if ((rc = fir_open_slot(p, (size_t)(cap > p->staged + n ? cap : p->staged + n))) != SDRHIP_OK) return rc;
-    float* dst = p->staged_base(p->slot[p->pushes & 1]) + (size_t)p->staged * p->esz_in();
+    float* dst = p->staged_base(p->slot[p->cur_slot()]) + (size_t)p->staged * p->esz_in();
     if (!still_in_place) memcpy(dst, block, (size_t)n * ein);   // else: the caller filled the staging buffer in place
     p->lent = 0;
     p->staged += n;
@@ -448,10 +457,10 @@ int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
 {
     SDRHIP_REQUIRE(p != nullptr && block != nullptr && n > 0, "sdrhip_pipe_push");
     if (!p->is_map()) return fir_like_push(p, block, n);
-    const int si = (int)(p->pushes & 1);
+    const int si = p->cur_slot();
     sdrhip_pipe::Slot& sl = p->slot[si];
     int rc;
-    // slot si was last used by push i-2 and harvested during push i-1
+    // slot si was last used by push i - nslots and harvested during push i-1
     if ((rc = harvest(p, si)) != SDRHIP_OK) return rc;
 
     const size_t ein = (size_t)p->esz_in() * 4, eout = (size_t)p->esz_out() * 4;
@@ -460,7 +469,7 @@ int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
 
     if (p->is_map()) {
         // fmDemodVec last dat (Demod.hs:32-36,43-46) / dcBlockingFilter (Filter.hs:730-739): one output vector per input vector
-        DevBuf& d = p->din[p->cur];
+        DevBuf& d = p->din[si];              // last read by the kernels of push i - nslots, harvested above
         if ((rc = d.ensure((size_t)n * ein)) != SDRHIP_OK) return rc;
         if ((rc = sl.dout.ensure((size_t)n * eout)) != SDRHIP_OK) return rc;
         if ((rc = sl.hout.ensure((size_t)n * eout)) != SDRHIP_OK) return rc;
@@ -484,9 +493,8 @@ int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
         sl.n_out = n;
         sl.busy = true;
         p->demod_blocks.push_back(n);
-        p->cur ^= 1;  // the next push must not overwrite an input still being read
         p->pushes++;
-        if ((rc = harvest(p, si ^ 1)) != SDRHIP_OK) return rc;
+        if ((rc = harvest(p, p->cur_slot())) != SDRHIP_OK) return rc;
         return ready_blocks(p);
     }
 
@@ -517,7 +525,7 @@ float* sdrhip_pipe_input_buffer(sdrhip_pipe* p, int n)
     if (cap > (int64_t)1 << 30) { set_error("sdrhip_pipe_input_buffer: coalesced batch too large"); return nullptr; }
     if (fir_open_slot(p, (size_t)(cap > p->staged + n ? cap : p->staged + n)) != SDRHIP_OK) return nullptr;
     p->lent = n;
-    return p->staged_base(p->slot[p->pushes & 1]) + (size_t)p->staged * p->esz_in();
+    return p->staged_base(p->slot[p->cur_slot()]) + (size_t)p->staged * p->esz_in();
 }
 
 int sdrhip_pipe_flush(sdrhip_pipe* p)
@@ -526,9 +534,9 @@ int sdrhip_pipe_flush(sdrhip_pipe* p)
     int rc;
     if (p->staged > 0 && (rc = fir_submit(p, p->staged, p->uniform_n)) != SDRHIP_OK) return rc;
     // oldest first
-    int first = (int)(p->pushes & 1);
-    if ((rc = harvest(p, first)) != SDRHIP_OK) return rc;
-    if ((rc = harvest(p, first ^ 1)) != SDRHIP_OK) return rc;
+    const int first = p->cur_slot();
+    for (int k = 0; k < p->nslots; k++)
+        if ((rc = harvest(p, (first + k) % p->nslots)) != SDRHIP_OK) return rc;
     return ready_blocks(p);
 }
 
