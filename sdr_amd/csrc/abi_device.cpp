@@ -210,6 +210,9 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
         } else if (d->corder != CO_L4 && !d->sym && (!in_u8 || d->d_scaled) &&
                    launch_decimate_c_orders_fast(s, g, d->corder, in_u8 ? d->d_scaled : d->d_plain, d->Lp, d->d_cross, d_in, in_u8, d_out)) {
             // the same tiled kernel with the SSE / RC2 partial-sum layout took it
+        } else if (d->corder == CO_L4 && !in_u8 && !d->sym &&
+                   launch_filter_c4_tile(s, g, d->d_plain, d->Lp, d->d_cross, (const float*)d_in, d_out)) {
+            // complex filter of exactly 128 / 64 taps: the tiled decimator with D = 1, eight outputs per thread
         } else if (d->corder == CO_L4 && !in_u8 &&
                    launch_filter_cplx4_fast(s, g, d->d_taps, d->Lp, d->d_cross, (const float*)d_in, d_out)) {
             // LDS-tiled complex filter took it

@@ -55,12 +55,16 @@ template <int D, int P, int R, class T, int TC, bool GUARD, int NP = 4, int PSKI
 __device__ __forceinline__ void mac_window(const float2* __restrict__ win, const float* __restrict__ taps, float2 (&acc)[R][NP],
                                            int nch_eff)
 {
-    static_assert(P % TC == 0 && T::WIN % TC == 0 && D % TC == 0, "window and taps are walked in blocks of TC");
+    static_assert(P % TC == 0, "taps are walked in blocks of TC");
+    // the guarded walk pairs whole tap chunks with whole sample blocks: decimation a multiple of TC.  The exact-length walk
+    // takes any decimation, D = 1 (a FILTER: R consecutive outputs per thread, a sample meets up to R taps) included; its
+    // last sample block may then reach past the window (taps >= P are skipped, the reads stay inside the tile's padding)
+    static_assert(!GUARD || (T::WIN % TC == 0 && D % TC == 0), "the guarded walk pairs tap chunks with sample blocks");
     static_assert(TC % NP == 0 || NP % TC == 0, "partial of a tap = its index mod NP");
     static_assert(!GUARD || TC % NP == 0, "the guarded walk derives the partial from the index inside the chunk");
     constexpr int NCH = P / TC;
     const int nb_eff = GUARD ? nch_eff + (R - 1) * (D / TC) : 0;   // sample blocks that still meet a live tap
-    constexpr int NB = T::WIN / TC;             // sample blocks per thread
+    constexpr int NB = (T::WIN + TC - 1) / TC;  // sample blocks per thread
     typename TapVec<TC>::type tc[NCH];
     float4 buf[2][TC / 2];                      // LDS reads are double-buffered one block ahead
     tc[0] = load_tap_chunk<TC>(taps, 0);

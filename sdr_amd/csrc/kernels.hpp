@@ -135,6 +135,9 @@ bool launch_fir_real8_fast(hipStream_t s, const Geom& g, bool sym, const float* 
 // complex filter (D == 1), AVX "RC" order, duplicated taps (2P floats), P % 4 == 0
 bool launch_filter_cplx4_fast(hipStream_t s, const Geom& g, const float* d_dup_taps, int P, const float* d_cross_taps,
                               const float* d_in, float* d_out);
+// kernels_fast_filter.hip: complex filters of exactly 128 / 64 taps (AVX "RC" order, plain taps) on the tiled decimator with D = 1
+bool launch_filter_c4_tile(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps, const float* d_in,
+                           float* d_out);
 // kernels_cplx.hip: the same shape on complex data ("RC2" orders of resampleAVXRC / resampleSSERC)
 bool launch_resample3c_fast(hipStream_t s, const Geom& g, ComplexOrder order, const ResampTable& t, const int* increments, const float* d_groups,
                             const float* d_plain_taps, const float* d_in, float* d_out);

@@ -257,3 +257,21 @@ def test_decimator_by_8_any_length_up_to_128(hip, oracle, ntaps, factor, launch_
     assert_bit_equal(_run_ranges(dec, to_dev(u8), nblk * B, 2, K, B, [2048], u8=True), exp, "u8 in (convert fused)")
     assert_bit_equal(_run_ranges(dec, to_dev(u8), nblk * B, 2, K, 0, [], u8=True)[:64],
                      PM.FilterModel(oracle, taps, PM.ORDER_AVX, complex_=True, factor=factor).one(32, x), "u8 in, no seams")
+
+
+@pytest.mark.parametrize("ntaps", [128, 64, 127, 61])
+def test_complex_filter_on_the_tiled_kernel(hip, oracle, ntaps, launch_route):
+    """Complex filters of exactly 128 / 64 (padded) taps run on the tiled decimator with D = 1 (kernels_fast_filter.hip); 127 and
+    61 taps pad to 128 / 64 under mkFilterC's intended rule.  Large launches (the tile kernel takes >= 16384 outputs), with the
+    8192-sample seams of the Pipe and without, cut into launches at odd places."""
+    n = 6 * B
+    x = S.cfloat_block(n, seed=91)
+    taps = S.gauss_taps(ntaps, 300 + ntaps)
+    model = PM.FilterModel(oracle, taps, PM.ORDER_AVX, complex_=True, factor=1)
+    blocks, _ = PM.fir_filter_pipe(model, _split(x, 2, B), 4096)
+    exp = np.concatenate(blocks)
+    f = hip.Filter(taps, hip.ORDER_AVX, complex_=True)
+    got = _run_ranges(f, to_dev(x), n, 2, exp.size // 2, B, [])
+    assert_bit_equal(got, exp, f"complex filter {ntaps} taps, one launch")
+    got = _run_ranges(f, to_dev(x), n, 2, exp.size // 2, B, [3, 20000, 20001, 40000])
+    assert_bit_equal(got, exp, f"complex filter {ntaps} taps, cut into launches")
