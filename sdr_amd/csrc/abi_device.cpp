@@ -234,9 +234,9 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
         if (small) {
             launch_fir_real(s, g, d->lanes, d->sym, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out);
             if (gain != 1.0f) launch_scale(s, gain, d_out, d_out, g.count);
-        } else if (d->lanes == 8 &&
-            launch_fir_real8_fast(s, g, d->sym, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out, gain, gain != 1.0f)) {
-            // LDS-tiled kernel took it (gain fused)
+        } else if ((d->lanes == 8 || d->lanes == 4) &&
+            launch_fir_real8_fast(s, g, d->sym, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out, gain, gain != 1.0f, d->lanes)) {
+            // LDS-tiled kernel took it (gain fused): AVX order, and the SSE order when the tap count is a multiple of 8
         } else if (launch_fir_split(s, g, false, d->lanes, CO_SEQ, d->sym, d->sym ? d->d_taps : d->d_plain,
                                     d->sym ? d->ntaps_kernel : d->Lp, d->d_cross, (const float*)d_in, d_out, gain, gain != 1.0f)) {
             // lane-split tiled kernel took it (decimators, SSE order; gain fused)

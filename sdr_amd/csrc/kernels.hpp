@@ -130,8 +130,9 @@ long long split_launch_count();   // diagnostics: launches the lane-split kernel
 void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int64_t count, bool has_prev,
                           float last_re, float last_im);
 // real filters (D == 1), AVX order, nk taps walked (half-taps when sym), nk % 8 == 0
+// lanes: 8 = AVX order, 4 = SSE order (the same kernel with four lane partials per output)
 bool launch_fir_real8_fast(hipStream_t s, const Geom& g, bool sym, const float* d_taps, int nk, const float* d_cross_taps,
-                          const float* d_in, float* d_out, float gain, bool apply_gain);
+                          const float* d_in, float* d_out, float gain, bool apply_gain, int lanes = 8);
 // complex filter (D == 1), AVX "RC" order, duplicated taps (2P floats), P % 4 == 0
 bool launch_filter_cplx4_fast(hipStream_t s, const Geom& g, const float* d_dup_taps, int P, const float* d_cross_taps,
                               const float* d_in, float* d_out);

@@ -67,7 +67,10 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
 // iteration j (k = 8j..8j+7) needs the front samples w[8j .. 8j+R+6] and, for SYM, the back
 // samples w[2n-8-8j .. 2n-1-8j+R-1]: three 16-byte LDS reads each.
 // ---------------------------------------------------------------------------
-template <bool SYM, int R, int NT>
+// L = 8: the AVX order; L = 4: the SSE order (filterSSERR / filterSSESymmetricRR, filter.c:24-34,48-58 -> sse_dotprod_R /
+// sse_sym_dotprod_R, common.h:34-45,157-179: lane partial k & 3, tree (a0 + a1) + (a2 + a3)) -- the same walk, eight taps per
+// step, four accumulators per output instead of eight.
+template <bool SYM, int R, int NT, int L = 8>
 __global__ void __launch_bounds__(NT) k_fir_real8_fast(const float* __restrict__ in, int64_t x0, int count,
                                                         const float* __restrict__ taps, int nk, float* __restrict__ out,
                                                         float gain, int apply_gain, int aligned)
@@ -114,11 +117,12 @@ __global__ void __launch_bounds__(NT) k_fir_real8_fast(const float* __restrict__
 
     typedef float f8v __attribute__((ext_vector_type(8)));
     const float* win = lds + threadIdx.x * R;
-    float acc[R][8];
+    static_assert(L == 8 || L == 4, "AVX or SSE lane count");
+    float acc[R][L];
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
-        for (int l = 0; l < 8; l++) acc[r][l] = 0.0f;
+        for (int l = 0; l < L; l++) acc[r][l] = 0.0f;
 #pragma unroll 1
     for (int j = 0; j < nk / 8; j++) {
         const f8v c8 = *reinterpret_cast<const f8v*>(taps + 8 * j);      // wave-uniform: s_load_dwordx8
@@ -141,16 +145,18 @@ __global__ void __launch_bounds__(NT) k_fir_real8_fast(const float* __restrict__
         for (int kk = 0; kk < 8; kk++) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                // k = 8j+kk: front w[r+k] = fw[r+kk]; back w[r+2n-1-k] = bw[r + 7 - kk]; lane k&7 = kk
-                if constexpr (SYM) acc[r][kk] = acc[r][kk] + c8[kk] * (fw[r + kk] + bw[r + 7 - kk]);
-                else acc[r][kk] = acc[r][kk] + c8[kk] * fw[r + kk];
+                // k = 8j+kk: front w[r+k] = fw[r+kk]; back w[r+2n-1-k] = bw[r + 7 - kk]; lane k & (L-1) = kk & (L-1)
+                if constexpr (SYM) acc[r][kk % L] = acc[r][kk % L] + c8[kk] * (fw[r + kk] + bw[r + 7 - kk]);
+                else acc[r][kk % L] = acc[r][kk % L] + c8[kk] * fw[r + kk];
             }
         }
     }
     const int o = out0 + threadIdx.x * R;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        float res = ((acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3])) + ((acc[r][4] + acc[r][5]) + (acc[r][6] + acc[r][7]));
+        float res;
+        if constexpr (L == 8) res = ((acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3])) + ((acc[r][4] + acc[r][5]) + (acc[r][6] + acc[r][7]));
+        else res = (acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]);
         if (apply_gain) res = res * gain;
         if (o + r < count) out[o + r] = res;
     }
@@ -492,8 +498,9 @@ void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int
 }
 
 bool launch_fir_real8_fast(hipStream_t s, const Geom& g, bool sym, const float* d_taps, int nk, const float* d_cross_taps,
-                          const float* d_in, float* d_out, float gain, bool apply_gain)
+                          const float* d_in, float* d_out, float gain, bool apply_gain, int lanes)
 {
+    if (lanes != 8 && lanes != 4) return false;
     // filters only (D == 1), 8 lanes, tap count a multiple of 8 (the AVX constructors guarantee it)
     if (g.I != 1 || g.D != 1 || nk < 8 || nk % 8 != 0 || nk > 4096 || g.count <= 0 || g.seamBI < 0) return false;
     if (g.seamBI != 0 && d_cross_taps == nullptr) return false;
@@ -503,11 +510,17 @@ bool launch_fir_real8_fast(hipStream_t s, const Geom& g, bool sym, const float* 
     const int aligned = ((reinterpret_cast<uintptr_t>(d_in + x0) & 15) == 0) ? 1 : 0;
     const int tiles = (g.count + NT * R - 1) / (NT * R);
     const size_t lds_bytes = ((size_t)(NT * R + full - 1 + 3) / 4 * 4 + 16) * sizeof(float);
-    if (sym)
+    if (sym && lanes == 8)
         hipLaunchKernelGGL((k_fir_real8_fast<true, R, NT>), dim3(tiles), dim3(NT), lds_bytes, s, d_in, x0, g.count, d_taps, nk, d_out,
                            gain, apply_gain ? 1 : 0, aligned);
-    else
+    else if (lanes == 8)
         hipLaunchKernelGGL((k_fir_real8_fast<false, R, NT>), dim3(tiles), dim3(NT), lds_bytes, s, d_in, x0, g.count, d_taps, nk, d_out,
+                           gain, apply_gain ? 1 : 0, aligned);
+    else if (sym)
+        hipLaunchKernelGGL((k_fir_real8_fast<true, R, NT, 4>), dim3(tiles), dim3(NT), lds_bytes, s, d_in, x0, g.count, d_taps, nk, d_out,
+                           gain, apply_gain ? 1 : 0, aligned);
+    else
+        hipLaunchKernelGGL((k_fir_real8_fast<false, R, NT, 4>), dim3(tiles), dim3(NT), lds_bytes, s, d_in, x0, g.count, d_taps, nk, d_out,
                            gain, apply_gain ? 1 : 0, aligned);
     if (g.seamBI != 0) {
         int64_t first, last;
