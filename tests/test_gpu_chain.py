@@ -407,6 +407,7 @@ def test_small_chain_on_eight_shards_of_2_to_the_20(hip, oracle):
     stage kernels -- and, over the first blocks, to the restated Pipes."""
     S_len, nshards = 1 << 20, 8
     chain = _chain(hip)
+    chain.set_small_chain(2)                   # the default (auto) route, whatever the environment asks for
     halo_cap = chain.halo_samples()
     total = nshards * S_len + halo_cap
     u8 = S.iq_u8(total)

@@ -195,6 +195,7 @@ def test_chain_demod_fusion_is_invisible(hip, start_blocks):
     for block in (B, 0):
         chain = hip.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, block)
         chain.set_fused_tail(0)                                    # the stage kernels, whatever the environment asks for
+        chain.set_small_chain(0)
         ws = torch.empty(chain.workspace_bytes(n), dtype=torch.uint8, device="cuda")
         s0 = start_blocks * B
         q0, q1, _ = chain.plan(s0, s0 + n, s0 + n)
