@@ -162,3 +162,28 @@ def test_peer_copy_ring_of_several_ranks_on_one_device(hip, nranks):
     assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), "sharded chain over the exchanged halos vs the single stream"
     for c in comms:
         c.close()
+
+
+def test_bench_gpus_2_runs_two_ranks_on_this_box(hip):
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks (sharing this box's device when it has one), exchanges
+    the halo (host transport: RCCL refuses two ranks on one device) and reports n_gpus 2; the audio of every rank is the same
+    whether the exchange is overlapped with the halo-free outputs or not."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(BENCH_TRANSPORT="host", BENCH_CHECKSUM="1")
+    crcs = []
+    for no_overlap in ("0", "1"):
+        env["BENCH_NO_OVERLAP"] = no_overlap
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "512",
+                              "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        r = json.loads(lines[0])
+        assert r["n_gpus"] == 2 and r["value"] > 0 and r["scaling"] == "weak"
+        assert "host memory" in r["config"]["halo_transport"]
+        crcs.append(r["audio_crc32_per_rank"])
+    assert crcs[0] == crcs[1] and len(crcs[0]) == 2
