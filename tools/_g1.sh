@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_comm.py -m gpu -x -q 2>&1 | grep -v "^ROCm\|^Hostname\|^Librccl\|amdgpu.ids\|^RCCL\|^HIP version" | tail -5
+for i in 1 2 3; do for w in 0 1; do echo -n "NO_PREFETCH=$w: "; SDRHIP_FIR_NO_PREFETCH=$w python tools/stage_bench.py 26 2>&1 | grep -E "filter.*8192"; done; done
