@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do for w in 0 1; do echo -n "NO_PREFETCH=$w: "; SDRHIP_FIR_NO_PREFETCH=$w python tools/stage_bench.py 26 2>&1 | grep -E "filter.*8192"; done; done
+timeout 600 python -m pytest tests/test_gpu_stream.py tests/test_gpu_chain.py -m gpu -x -q 2>&1 | grep -v "^ROCm\|^Hostname\|^Librccl\|amdgpu.ids\|^RCCL\|^HIP version" | tail -2
+for i in 1 2 3; do for w in 1 0; do echo -n "TAP_PF=$w: "; SDRHIP_RESAMP_TAP_PF=$w python tools/stage_bench.py 26 2>&1 | grep -E "resample.*8192"; done; done
