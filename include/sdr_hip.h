@@ -402,9 +402,10 @@ int sdrhip_fm_chain_halo_exchange(const sdrhip_fm_chain *chain, sdrhip_comm *com
 /* Host-block streaming front end of the chain: u8 IQ source blocks in (host memory, `block` samples
  * each or a whole multiple), audio blocks of exactly block_size_out floats out -- the five middle
  * stages of examples/fm/fm.hs:34-41 as ONE operator with every intermediate resident in HBM.  Pinned
- * staging, two slots: results lag one push (flush drains).  Large pushes: H2D / compute / D2H on three HIP streams;
- * pushes of up to 33 source blocks: in place (the kernels read and write the pinned buffers over PCIe), two compute
- * streams in turn so that consecutive pushes overlap on the GPU.
+ * staging in slots = submissions in flight: two when max_block_samples is too large to run in place (results lag one push;
+ * H2D / compute / D2H on three HIP streams), four when even the largest push runs in place -- up to 33 source blocks: the
+ * kernels read and write the pinned buffers over PCIe, one compute stream per slot, a push of a few blocks is ONE kernel --
+ * and results lag three pushes (flush drains; SDRHIP_STREAM_SLOTS=2..4 overrides the count).
  * The chain must outlive the stream and must not be run concurrently by another caller. */
 typedef struct sdrhip_fm_stream sdrhip_fm_stream;
 int sdrhip_fm_stream_create(sdrhip_fm_stream **st, sdrhip_fm_chain *chain, int max_block_samples, int block_size_out);
@@ -420,10 +421,9 @@ uint8_t *sdrhip_fm_stream_input_buffer(sdrhip_fm_stream *st);
 int sdrhip_fm_stream_flush(sdrhip_fm_stream *st);
 /* Latency / throughput knob: stage pushes in the pinned buffer and submit them to the GPU together once
  * `samples` samples (a multiple of the chain's block; 0 = every push, the default) have accumulated, or on
- * flush.  One 8192-sample push costs ~19 us of launches and latency (two kernel launches, consecutive pushes
- * overlapping on two compute streams) whatever its size, so a caller that must keep the reference's block size
- * (fm.hs:17) gets ~10x the throughput from coalesce = 16 blocks, at 16 blocks of latency; the audio blocks are the
- * same.  Call with nothing staged. */
+ * flush.  One 8192-sample push costs ~8-9 us (one kernel launch, four pushes in flight) whatever its size, so a caller
+ * that must keep the reference's block size (fm.hs:17) gets ~6x the throughput from coalesce = 16 blocks, at 16 blocks
+ * of latency; the audio blocks are the same.  Call with nothing staged. */
 int sdrhip_fm_stream_set_coalesce(sdrhip_fm_stream *st, int samples);
 int sdrhip_fm_stream_pop(sdrhip_fm_stream *st, float *out, int capacity);
 /* Checkpoint / resume.  Between two pushes the operator's state is the stream position, the last ~4k input samples and
@@ -484,8 +484,8 @@ int sdrhip_pipe_dc_blocker(sdrhip_pipe **p);                                    
  * negative error.  A block shorter than numCoeffs is the reference's
  * `assert "filter 1"` failure -> SDRHIP_ERR_ARG. */
 int sdrhip_pipe_push(sdrhip_pipe *p, const float *block, int n);
-/* Transfers are double-buffered, so results lag one push behind: flush waits for
- * the in-flight block and returns the number of complete output blocks ready. */
+/* Up to four submissions are in flight (SDRHIP_STREAM_SLOTS=2..4), so results lag up to three pushes behind: flush waits
+ * for the in-flight blocks and returns the number of complete output blocks ready. */
 /* Throughput knobs of the filter / decimator / resampler pipes (results never depend on them):
  *  - set_coalesce(blocks): equal-sized pushes are staged in the pinned buffer and submitted `blocks` at a
  *    time (one upload, one run over the batch with its interior seams, one download); a push of another

@@ -603,9 +603,10 @@ int sdrhip_fm_chain_read_timing(sdrhip_fm_chain* c, double* ms_sum, int* runs)
 //     of i-1 over download of i-2;
 //   * small submissions (<= kDirectSamples): NO copies at all -- the decimator kernel reads the pinned
 //     host buffer directly over PCIe and the last kernel writes the audio straight into pinned host
-//     memory: two kernel launches (decimator with its seams, fused tail) and one event per push instead of ~15 API calls, which is what
-//     the reference's own block size (8192 samples) needs to beat one CPU thread.
-// Results lag one push (sdrhip_fm_stream_flush drains).
+//     memory: ONE kernel launch for a push of a few blocks (kernels_small.hip; two launches -- decimator with its seams,
+//     fused tail -- where the one-kernel chain does not apply) and one event per push instead of ~15 API calls, which is
+//     what the reference's own block size (8192 samples) needs to beat one CPU thread.
+// Results lag nslots - 1 pushes (sdrhip_fm_stream_flush drains).
 // ---------------------------------------------------------------------------
 struct sdrhip_fm_stream {
     sdrhip_fm_chain* c = nullptr;
