@@ -67,15 +67,10 @@ bool launch_filter_c4_tile(hipStream_t s, const Geom& g, const float* d_plain_ta
     const int64_t x0 = g.k_begin - g.in_base;
     if (((reinterpret_cast<uintptr_t>(d_in) + 8 * (uintptr_t)x0) & 15) != 0) return false;      // 16-byte aligned tile starts
     if ((reinterpret_cast<uintptr_t>(d_out) & 15) != 0) return false;
-    static const int r_env = getenv("SDRHIP_FILTER_TILE_R") ? atoi(getenv("SDRHIP_FILTER_TILE_R")) : 4;     // 0 = off, 8 = eight outputs per thread (A/B)
-    if (r_env == 0) return false;
-    if (r_env == 4) {
-        if (P == 128) launch_c4<1, 128, 4, 256, false>(s, g, d_plain_taps, d_in, d_out);
-        else launch_c4<1, 64, 4, 256, false>(s, g, d_plain_taps, d_in, d_out);
-    } else {
-        if (P == 128) launch_c4<1, 128, 8, 256, false>(s, g, d_plain_taps, d_in, d_out);
-        else launch_c4<1, 64, 8, 256, false>(s, g, d_plain_taps, d_in, d_out);
-    }
+    static const bool off = getenv("SDRHIP_FILTER_TILE") != nullptr && atoi(getenv("SDRHIP_FILTER_TILE")) == 0;     // A/B: the rolled kernel
+    if (off) return false;
+    if (P == 128) launch_c4<1, 128, 4, 256, false>(s, g, d_plain_taps, d_in, d_out);
+    else launch_c4<1, 64, 4, 256, false>(s, g, d_plain_taps, d_in, d_out);
     if (g.seamBI != 0) {
         // Cross outputs: sequential order over the plain taps (filterCrossHighLevel, FilterInternal.hs:404-408)
         const int64_t v_lo = g.k_begin, v_hi = g.k_begin + g.count - 1 + g.Lp;

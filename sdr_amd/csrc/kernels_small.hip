@@ -186,12 +186,12 @@ __device__ __forceinline__ float2 seq_one(const float2* __restrict__ tile, int i
 }
 
 // dtaps: the decimator's 128 plain taps pre-scaled by 1/128 (FirDesc::d_scaled); groups: 3 rows of row_stride floats;
-// rplain: the resampler's plain taps; fhalf / fplain: the audio filter's 64 half-taps / 128 plain taps
+// rplain: the resampler's plain taps; fplain: the audio filter's 128 plain taps (coeffs ++ reverse coeffs: its first 64 are the half-taps)
 template <int PSKIP>
 __global__ void __launch_bounds__(SM_NT, 2) k_fm_chain_small(const uint8_t* __restrict__ in, float* __restrict__ audio,
                                                              const float* __restrict__ dtaps, const float* __restrict__ groups,
-                                                             const float* __restrict__ rplain, const float* __restrict__ fhalf,
-                                                             const float* __restrict__ fplain, SmallParams p
+                                                             const float* __restrict__ rplain, const float* __restrict__ fplain,
+                                                             SmallParams p
 #ifdef SDRHIP_SMALL_PROBE
                                                              , SmallProbe* pr
 #endif
@@ -508,7 +508,7 @@ bool launch_fm_chain_small(hipStream_t s, const uint8_t* d_in, int64_t s0, int64
     // resampler with 64-float groups, 64 half-tap symmetric filter
     if (!(dD == 8 && dP == 128 && d_dscaled != nullptr)) return false;
     if (!(ngroups == 3 && nloop == SM_NL && I == 3 && D == 10 && increments[0] == 4 && increments[1] == 3 && increments[2] == 3)) return false;
-    if (!(nhalf == SM_LF / 2 && rLp <= 3 * SM_NL && ntaps <= rLp)) return false;
+    if (!(nhalf == SM_LF / 2 && d_fhalf != nullptr && rLp <= 3 * SM_NL && ntaps <= rLp)) return false;
     if (seam != 0 && (seam < 192 || seam > (1 << 26))) return false;       // 32-bit seam arithmetic; a stage's window meets one boundary at most
     if ((reinterpret_cast<uintptr_t>(d_in) & 15) != 0 || (s0 & 7) != 0) return false;   // 16-byte aligned tile loads
     if (q1 <= q0) return true;
@@ -530,11 +530,10 @@ bool launch_fm_chain_small(hipStream_t s, const uint8_t* d_in, int64_t s0, int64
             if (dev >= 0 && dev < 64) attr_set[which][dev] = true;
         }
 #ifdef SDRHIP_SMALL_PROBE
-        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(SM_NT), SmT::LDS_BYTES, s, d_in, d_audio, d_dscaled, d_groups, d_rplain, d_fhalf,
-                           d_fplain, p, g_small_probe);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(SM_NT), SmT::LDS_BYTES, s, d_in, d_audio, d_dscaled, d_groups, d_rplain, d_fplain, p,
+                           g_small_probe);
 #else
-        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(SM_NT), SmT::LDS_BYTES, s, d_in, d_audio, d_dscaled, d_groups, d_rplain, d_fhalf,
-                           d_fplain, p);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(SM_NT), SmT::LDS_BYTES, s, d_in, d_audio, d_dscaled, d_groups, d_rplain, d_fplain, p);
 #endif
     };
     if (last_tap_zero) launch(k_fm_chain_small<1>, 1);
