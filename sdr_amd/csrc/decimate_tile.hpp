@@ -284,32 +284,18 @@ __device__ __forceinline__ float2 fold_partials(const float2 (&a)[NP])
     }
 }
 
-// FULL: every tile of the launch is a whole one (all SPAN input samples exist, all OUTS outputs are wanted) and no Cross outputs
-// are computed in place: no ragged-end loader, no seam arithmetic, unconditional stores.  The same instructions for the common
-// case, but the slow paths no longer shape the register allocation and the epilogue of the fast one (measured on the cfloat-in
-// kernel, 2^27 samples: 243 -> 219 us, tools/k2lab/lab.hip "V0 production" against "dec: mac_window"); the launcher gives the
-// whole tiles to a FULL instantiation and the remainder (at most 64 tiles) to the general one.
-template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false, int NP = 4, int ORD = 0, int PSKIP = 0,
-          bool FULL = false>
-__global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in, int64_t x0 /* sample index of output 0's window in `in` */,
-                                                    int count, const float* __restrict__ taps, float* __restrict__ out,
-                                                    int p_eff /* GUARD: taps of the filter (multiple of TC, <= P); else unused */,
-                                                    int inl_seam /* > 0: compute the Cross outputs of buffers this long HERE */,
-                                                    int inl_r0 /* window start of output 0 inside its buffer */)
+// FULL: the tile is a whole one (all SPAN input samples exist, all OUTS outputs are wanted) and no Cross outputs are computed
+// in place: no ragged-end loader, no seam arithmetic, unconditional stores.  The same instructions for the common case, but
+// the slow paths no longer shape the register allocation and the epilogue of the fast one (alternating A/B inside one process,
+// tools/full_tiles_ab.py: decimate stage -1.8 %).
+template <int D, int P, int R, int NT, bool U8, int TC, bool GUARD, int NP, int ORD, int PSKIP, bool FULL>
+__device__ __forceinline__ void decimate_c4_tile(int tile, const void* __restrict__ in, int64_t x0, int count, const float* __restrict__ taps,
+                                                 float* __restrict__ out, int p_eff, int inl_seam, int inl_r0)
 {
     using T = Tile<D, P, R, NT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
 
-    // XCD-aware tile order: workgroup b runs on XCD b % 8 (each XCD has its own L2).  Within every group
-    // of 64 consecutive tiles XCD x takes the 8 consecutive tiles [8x, 8x+8), so 7 of 8 tile-to-tile
-    // overlaps (120 samples each) hit in the SAME L2, while all XCDs still stream through the same
-    // ~2 MB neighbourhood of HBM (giving every XCD its own far-apart eighth of the buffer measured
-    // 20 % slower: DRAM locality matters more than the 3 % of re-reads).
-    const int ntiles = (count + T::OUTS - 1) / T::OUTS;
-    const int b = blockIdx.x;
-    const int tile = (b & ~63) + ((b & 7) << 3) + ((b >> 3) & 7);
-    if (tile >= ntiles) return;
     const int out0 = tile * T::OUTS;
     const int64_t s0 = (int64_t)out0 * D;                     // first sample of the tile, relative to x0
     {
@@ -370,6 +356,37 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
         for (int r = 0; r < R; r++)
             if (o + r < count) *reinterpret_cast<float2*>(out + 2 * (int64_t)(o + r)) = res[r];
     }
+}
+
+// MIXED = false: every tile through the general body.  MIXED = true: tiles [0, nfull) -- whole ones, in a launch without in-place
+// Cross outputs -- take the FULL body, the remainder (the ragged end) the general one, in the SAME launch (a second launch for the
+// last tile or two costs 9-10 us of pure latency behind a 0.2-0.7 ms kernel).
+template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false, int NP = 4, int ORD = 0, int PSKIP = 0,
+          bool MIXED = false>
+__global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in, int64_t x0 /* sample index of output 0's window in `in` */,
+                                                    int count, const float* __restrict__ taps, float* __restrict__ out,
+                                                    int p_eff /* GUARD: taps of the filter (multiple of TC, <= P); else unused */,
+                                                    int inl_seam /* > 0: compute the Cross outputs of buffers this long HERE */,
+                                                    int inl_r0 /* window start of output 0 inside its buffer */,
+                                                    int nfull /* MIXED: tiles [0, nfull) are whole */)
+{
+    using T = Tile<D, P, R, NT>;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (each XCD has its own L2).  Within every group
+    // of 64 consecutive tiles XCD x takes the 8 consecutive tiles [8x, 8x+8), so 7 of 8 tile-to-tile
+    // overlaps (120 samples each) hit in the SAME L2, while all XCDs still stream through the same
+    // ~2 MB neighbourhood of HBM (giving every XCD its own far-apart eighth of the buffer measured
+    // 20 % slower: DRAM locality matters more than the 3 % of re-reads).
+    const int ntiles = (count + T::OUTS - 1) / T::OUTS;
+    const int b = blockIdx.x;
+    const int tile = (b & ~63) + ((b & 7) << 3) + ((b >> 3) & 7);
+    if (tile >= ntiles) return;
+    if constexpr (MIXED) {
+        if (tile < nfull) {
+            decimate_c4_tile<D, P, R, NT, U8, TC, GUARD, NP, ORD, PSKIP, true>(tile, in, x0, count, taps, out, p_eff, 0, 0);
+            return;
+        }
+    }
+    decimate_c4_tile<D, P, R, NT, U8, TC, GUARD, NP, ORD, PSKIP, false>(tile, in, x0, count, taps, out, p_eff, inl_seam, inl_r0);
 }
 
 // Cross outputs: sequential order over the Lp plain taps (decimateCrossHighLevel,
@@ -569,32 +586,21 @@ void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, 
         inl_r0 = (int)((g.k_begin * D) % g.seamBI);
     }
     if (inlined) *inlined = inl_seam > 0;
-    // Large launches without in-kernel seams: the whole tiles (in whole groups of 64, the unit of the tile permutation) go to
-    // the FULL instantiation, what is left -- fewer than 64 whole tiles and the ragged last one -- to the general kernel.
-    // A tile is whole when its OUTS outputs are wanted and its SPAN samples exist: the launch's samples end at
-    // (count - 1) * D + Lp, and SPAN = (OUTS - 1) * D + P >= that of the filter's own length, hence the `- 1` below for guarded
-    // (shorter) filters.
+    // Large launches without in-kernel seams: whole tiles take the FULL body inside the same launch (MIXED kernel).  A tile is
+    // whole when its OUTS outputs are wanted and its SPAN samples exist: the launch's samples end at (count - 1) * D + Lp, and
+    // SPAN = (OUTS - 1) * D + P reaches past that of a shorter (guarded) filter's own length, hence one tile less there.
     if (inl_seam == 0 && g.count >= 128 * T::OUTS && full_tiles_enabled()) {
-        const int whole = g.count / T::OUTS - ((GUARD && g.Lp < P) ? 1 : 0);
-        const int nf = (whole / 64) * 64;
-        if (nf > 0) {
-            static std::atomic<bool> attr_full[64];
-            auto kfull = k_decimate_c4<D, P, R, NT, U8, TC, GUARD, NP, ORD, PSKIP, true>;
-            if (dev < 0 || dev >= 64 || !attr_full[dev]) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfull), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
-                if (dev >= 0 && dev < 64) attr_full[dev] = true;
-            }
-            hipLaunchKernelGGL(kfull, dim3(nf), dim3(NT), T::LDS_BYTES, s, in, x0, nf * T::OUTS, taps, out, g.Lp, 0, 0);
-            const int rest = g.count - nf * T::OUTS;
-            if (rest > 0) {
-                const int rt = (rest + T::OUTS - 1) / T::OUTS;
-                hipLaunchKernelGGL(kern, dim3(((rt + 63) / 64) * 64), dim3(NT), T::LDS_BYTES, s, in, x0 + (int64_t)nf * T::OUTS * D, rest, taps,
-                                   out + 2 * (int64_t)nf * T::OUTS, g.Lp, 0, 0);
-            }
-            return;
+        const int nfull = g.count / T::OUTS - ((GUARD && g.Lp < P) ? 1 : 0);
+        static std::atomic<bool> attr_full[64];
+        auto kmixed = k_decimate_c4<D, P, R, NT, U8, TC, GUARD, NP, ORD, PSKIP, true>;
+        if (dev < 0 || dev >= 64 || !attr_full[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kmixed), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
+            if (dev >= 0 && dev < 64) attr_full[dev] = true;
         }
+        hipLaunchKernelGGL(kmixed, dim3(grid), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, taps, out, g.Lp, 0, 0, nfull);
+        return;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, taps, out, g.Lp, inl_seam, inl_r0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), T::LDS_BYTES, s, in, x0, g.count, taps, out, g.Lp, inl_seam, inl_r0, 0);
 }
 
 

@@ -451,7 +451,7 @@ int main(int argc, char** argv)
     auto k0 = k_decimate_c4<D, P, R, NT, false>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES));
     const int grid0 = ((ntiles + 63) / 64) * 64;
-    auto run0 = [&](float* o) { hipLaunchKernelGGL(k0, dim3(grid0), dim3(NT), T::LDS_BYTES, 0, (const void*)dx, (int64_t)0, (int)nout, dt, o, P, 0, 0); };
+    auto run0 = [&](float* o) { hipLaunchKernelGGL(k0, dim3(grid0), dim3(NT), T::LDS_BYTES, 0, (const void*)dx, (int64_t)0, (int)nout, dt, o, P, 0, 0, 0); };
     run0(dref);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(href.data(), dref, (size_t)nout * 8, hipMemcpyDeviceToHost));
@@ -515,7 +515,7 @@ int main(int argc, char** argv)
             auto kfull = k_decimate_c4<D, P, R, NT, false, 8, false, 4, 0, 0, true>;
             SETLDS(kfull, T::LDS_BYTES);
             CK(hipMemset(dout, 0xff, (size_t)nout * 8));
-            report("V0 FULL instantiation (production)", tm.us([&] { hipLaunchKernelGGL(kfull, dim3(grid0), dim3(NT), T::LDS_BYTES, 0, (const void*)dx, (int64_t)0, (int)nout, dt, dout, P, 0, 0); }, reps));
+            report("V0 FULL instantiation (production)", tm.us([&] { hipLaunchKernelGGL(kfull, dim3(grid0), dim3(NT), T::LDS_BYTES, 0, (const void*)dx, (int64_t)0, (int)nout, dt, dout, P, 0, 0, ntiles); }, reps));
             check("V0 FULL");
         }
         run0(dout);   // leave real samples in LDS for the MAC-only kernels
@@ -560,7 +560,7 @@ int main(int argc, char** argv)
             report("ABAB V0 production", tm.us([&] { run0(dout); }, reps));
             run_dec(k_dec_v<D, P, R, NT, 0, false>, "ABAB dec: mac_window", false);
             auto kfull = k_decimate_c4<D, P, R, NT, false, 8, false, 4, 0, 0, true>;
-            report("ABAB V0 FULL", tm.us([&] { hipLaunchKernelGGL(kfull, dim3(grid0), dim3(NT), T::LDS_BYTES, 0, (const void*)dx, (int64_t)0, (int)nout, dt, dout, P, 0, 0); }, reps));
+            report("ABAB V0 FULL", tm.us([&] { hipLaunchKernelGGL(kfull, dim3(grid0), dim3(NT), T::LDS_BYTES, 0, (const void*)dx, (int64_t)0, (int)nout, dt, dout, P, 0, 0, ntiles); }, reps));
         }
     }
     // copies with 4 x 16 B in flight per thread (the one-load-per-iteration copy is a weak ceiling), plain and nt

@@ -288,8 +288,8 @@ int main(int argc, char** argv)
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k0u), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T0::LDS_BYTES));
     const int nt0 = (int)(nout / T0::OUTS), grid0 = ((nt0 + 63) / 64) * 64;
     auto run0 = [&](const void* in, bool u8, float* o) {
-        if (u8) hipLaunchKernelGGL(k0u, dim3(grid0), dim3(256), T0::LDS_BYTES, 0, in, (int64_t)0, (int)nout, g_dt, o, P, 0, 0);
-        else hipLaunchKernelGGL(k0, dim3(grid0), dim3(256), T0::LDS_BYTES, 0, in, (int64_t)0, (int)nout, g_dt, o, P, 0, 0);
+        if (u8) hipLaunchKernelGGL(k0u, dim3(grid0), dim3(256), T0::LDS_BYTES, 0, in, (int64_t)0, (int)nout, g_dt, o, P, 0, 0, 0);
+        else hipLaunchKernelGGL(k0, dim3(grid0), dim3(256), T0::LDS_BYTES, 0, in, (int64_t)0, (int)nout, g_dt, o, P, 0, 0, 0);
     };
     auto set_ref = [&](const void* in, bool u8) {
         run0(in, u8, g_dref);
