@@ -343,6 +343,9 @@ int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain *c, int mode);
 int sdrhip_fm_chain_set_small_chain(sdrhip_fm_chain *c, int mode, int64_t max_outputs, int tile_outputs);
 /* launches of that kernel so far, process-wide (tests assert that this path, not the stage kernels, ran) */
 long long sdrhip_debug_small_chain_launches(void);
+/* launches of the thread-per-polyphase-cycle resampler (real I/D with an odd decimation: 2/3, 5/7, ...; any filter length),
+ * process-wide (tests assert that this kernel, not the lane-split one, served those ratios) */
+long long sdrhip_debug_resample_cycle_launches(void);
 /* A/B switch (measurements only; results are identical): 0 = the tiled AVX-order decimator runs every tile through its general
  * instantiation, 1 (default) = whole tiles through the specialised one.  SDRHIP_FULL_TILES=0/1 sets the initial value. */
 void sdrhip_debug_set_full_tiles(int on);

@@ -377,6 +377,8 @@ int resamp_run_demod(const ResampDesc* r, hipStream_t s, const float* d_iq, bool
         launch_resample_real(s, g, r->lanes, t, r->d_groups, r->d_plain, d_in, d_out);
     } else if (r->lanes == 8 && launch_resample_3_10_fast(s, g, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
         // specialised 3-group kernel took it
+    } else if (launch_resample_cycle_fast(s, g, r->lanes, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
+        // thread-per-cycle kernel took it (odd decimations)
     } else if (launch_resample_split(s, g, false, r->lanes, r->corder, t, r->d_groups, r->d_plain, d_in, d_out)) {
         // lane-split tiled kernel took it (any I/D, SSE order)
     } else launch_resample_real(s, g, r->lanes, t, r->d_groups, r->d_plain, d_in, d_out);

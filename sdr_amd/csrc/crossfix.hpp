@@ -110,5 +110,64 @@ inline void seam_range(const Geom& g, int64_t& first, int64_t& last)
     last = (v_hi - 1) / g.seamBI;
 }
 
+// Cross outputs of the real resampler (resampleCrossHighLevel, FilterInternal.hs:410-423):
+// taps = stride I (drop filterOffset coeffs) over the UNPADDED taps, sequential.  A group of LPG
+// (32 or 64) lanes serves one seam: its <= PER straddlers read a union of <= UNI consecutive inputs, staged in LDS.
+template <int PER, int UNI, int LPG = 32>
+__global__ void __launch_bounds__(256) k_resample_real_crossfix(Geom g, const float* __restrict__ plain, int ntaps,
+                                                                 const float* __restrict__ in, float* __restrict__ out,
+                                                                 int64_t first_seam, int nseams, int64_t in_avail)
+{
+    static_assert((LPG == 32 || LPG == 64) && PER <= LPG, "one group of LPG lanes per seam");
+    constexpr int SPW = 256 / LPG;                                       // seams per workgroup
+    __shared__ float lds[SPW][UNI];
+    __shared__ float tl[256];
+    const int tid = threadIdx.x, sl = tid / LPG, ci = tid % LPG;
+    const int si = blockIdx.x * SPW + sl;
+    const bool live = si < nseams;
+    int64_t edge = 0, m_lo = 0, p_lo = 0;
+    if (live) {
+        edge = (first_seam + si) * g.seamBI;                     // in upsampled units
+        const int64_t m_hi = (edge + g.D - 1) / g.D - 1;         // last output starting before the edge
+        m_lo = m_hi - (PER - 1);
+        if (m_lo < 0) m_lo = 0;
+        p_lo = (m_lo * g.D + g.I - 1) / g.I;                     // inOff(m_lo): first input of the union
+        // branch-free (clamped index + select): the five loads of a lane are in flight together
+        constexpr int NE = (UNI + LPG - 1) / LPG;
+        float ve[NE];
+#pragma unroll
+        for (int k = 0; k < NE; k++) {
+            const int64_t idx = p_lo + (ci + LPG * k) - g.in_base;
+            const bool ok = idx >= 0 && idx < in_avail;
+            const float x = in[ok ? idx : 0];
+            ve[k] = ok ? x : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NE; k++)
+            if (ci + LPG * k < UNI) lds[sl][ci + LPG * k] = ve[k];
+    }
+    // the unpadded taps, once per workgroup (the sequential loop below would otherwise wait for a global load per tap)
+    const bool taps_in_lds = ntaps <= 256;
+    if (taps_in_lds) tl[tid] = tid < ntaps ? plain[tid] : 0.0f;
+    __syncthreads();
+    if (!live || ci >= PER) return;
+    const int64_t m = m_lo + ci;
+    if (m < g.k_begin || m >= g.k_begin + g.count) return;
+    const int64_t v = m * g.D;
+    if (!(v < edge && v + g.Lp > edge)) return;
+    if (!seam_has_crossover(edge, g.I, g.D, g.Lp)) return;       // the Pipe goes straight to the next buffer here
+    if (late_output_is_one(m, edge, g.I, g.D, g.outB)) return;   // first output of an output block, first input beyond the seam
+    const int64_t pos = (v + g.I - 1) / g.I;                     // inOff(m)
+    const int fo = (int)(pos * g.I - v);
+    const float* x = lds[sl] + (pos - p_lo);
+    float r = 0.0f;
+    if (taps_in_lds) {
+        for (int l = 0, j = fo; j < ntaps; l++, j += g.I) r = r + x[l] * tl[j];
+    } else {
+        for (int l = 0, j = fo; j < ntaps; l++, j += g.I) r = r + x[l] * plain[j];
+    }
+    out[m - g.k_begin] = r;
+}
+
 }  // namespace
 }  // namespace sdrhip

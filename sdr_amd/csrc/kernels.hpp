@@ -124,6 +124,13 @@ bool launch_resample_split(hipStream_t s, const Geom& g, bool cplx, int lanes, C
 
 long long split_launch_count();   // diagnostics: launches the lane-split kernels have taken so far
 
+// kernels_resample_cycle.hip: real resamplers I/D with an odd decimation (I <= 6, D in {3,5,7}), any filter length up to
+// 1024 taps per group, AVX / SSE lane order: one thread per polyphase cycle, rolled walk with taps from LDS.  False = not
+// this kernel's shape (the caller falls through to the split / generic kernels).
+bool launch_resample_cycle_fast(hipStream_t s, const Geom& g, int lanes, const ResampTable& t, const int* increments, const float* d_groups,
+                                const float* d_plain_taps, const float* d_in, float* d_out);
+long long resample_cycle_launch_count();
+
 // Fast paths (kernels_fast.hip).  Return false when the configuration is not one
 // they are specialised for; the caller then uses the generic kernel.
 // kernels_chain.hip: fast paths of the low-rate stages

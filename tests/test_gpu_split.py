@@ -153,13 +153,50 @@ def test_resampler_families(hip, oracle, order, complex_, I, D, ntaps):
     r = hip.Resampler(I, D, taps, order, complex_)
     # 3/10 with 64-tap groups has specialised kernels: real AVX (k_resample3_fast), complex AVX / SSE (k_resample3c_fast)
     is_special = (I, D) == (3, 10) and 185 <= ntaps <= 192 and (order == PM.ORDER_AVX or (complex_ and order == PM.ORDER_SSE))
-    before = _tiled(hip)
+    # real I/D with an odd decimation 3 / 5 / 7 has the thread-per-cycle kernel (kernels_resample_cycle.hip), both lane orders
+    is_cycle = not complex_ and D in (3, 5, 7)
+    before, before_cycle = _tiled(hip), hip.lib.sdrhip_debug_resample_cycle_launches()
     got = _run(r, to_dev(x), w, K, B, out_block=512)
-    if not is_special:
+    if is_cycle:
+        assert hip.lib.sdrhip_debug_resample_cycle_launches() > before_cycle, "the thread-per-cycle kernel did not take this launch"
+    elif not is_special:
         assert _tiled(hip) > before, "the tiled kernel did not take this launch"
     assert_bit_equal(got, exp, "one launch")
     got = _run(r, to_dev(x), w, K, B, cuts=[4099, 4099 + 4097, K - 5000], out_block=512)
     assert_bit_equal(got, exp, "cut into launches (every starting group)")
+
+
+@pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE])
+@pytest.mark.parametrize("I,D", [(1, 3), (2, 3), (1, 5), (2, 5), (3, 5), (4, 5), (2, 7), (3, 7), (4, 7), (5, 7), (6, 7)])
+@pytest.mark.parametrize("ntaps", [37, 150, 700])
+def test_cycle_resampler(hip, oracle, order, I, D, ntaps):
+    """Every instantiation of the thread-per-cycle kernel (kernels_resample_cycle.hip): short / medium / long filters (a
+    single step of the rolled walk, an odd and an even number of steps, the SSE half step), launches cut at every
+    starting group, against the restated Pipe (resample.c:52-87 for One outputs, FilterInternal.hs:410-423 at seams)."""
+    x = S.real_block(NBLK * B)
+    taps = S.gauss_taps(ntaps, 100 * I + D + ntaps)
+    model = PM.ResamplerModel(oracle, I, D, taps, order)
+    blocks, _ = PM.fir_resampler_pipe(model, _split(x, 1, B), 512)
+    exp = np.concatenate(blocks)
+    K = exp.size
+    r = hip.Resampler(I, D, taps, order)
+    before = hip.lib.sdrhip_debug_resample_cycle_launches()
+    got = _run(r, to_dev(x), 1, K, B, out_block=512)
+    groups_taps = -(-ntaps // I)
+    lanes = 8 if order == PM.ORDER_AVX else 4
+    if -(-groups_taps // lanes) * lanes >= 8:
+        assert hip.lib.sdrhip_debug_resample_cycle_launches() > before, "the thread-per-cycle kernel did not take this launch"
+    assert_bit_equal(got, exp, f"{I}/{D}, {ntaps} taps: one launch")
+    cuts = [4099 + q for q in range(I)]
+    cuts = [c + 4100 * q for q, c in enumerate(cuts)] + [K - 4500]
+    got = _run(r, to_dev(x), 1, K, B, cuts=[c for c in cuts if 0 < c < K], out_block=512)
+    assert_bit_equal(got, exp, f"{I}/{D}, {ntaps} taps: cut into launches")
+    # no seams (one contiguous buffer)
+    model1 = PM.ResamplerModel(oracle, I, D, taps, order)
+    blocks1, _ = PM.fir_resampler_pipe(model1, [x], 512)
+    exp1 = np.concatenate(blocks1)
+    got1 = _run(r, to_dev(x), 1, exp1.size, 0, out_block=512)
+    assert_bit_equal(got1, exp1, f"{I}/{D}, {ntaps} taps: no seams")
 
 
 @pytest.mark.parametrize("complex_", [False, True])
