@@ -375,7 +375,8 @@ int resamp_run_demod(const ResampDesc* r, hipStream_t s, const float* d_iq, bool
             launch_resample_cplx(s, g, r->corder, t, r->d_groups, r->d_plain, d_in, d_out);
     } else if (g.seamBI > 0 && g.count <= small_generic_r) {
         launch_resample_real(s, g, r->lanes, t, r->d_groups, r->d_plain, d_in, d_out);
-    } else if (r->lanes == 8 && launch_resample_3_10_fast(s, g, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
+    } else if ((r->lanes == 8 || r->lanes == 4) &&
+               launch_resample_3_10_fast(s, g, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out, nullptr, false, 0, r->lanes)) {
         // specialised 3-group kernel took it
     } else if (launch_resample_cycle_fast(s, g, r->lanes, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
         // thread-per-cycle kernel took it (odd decimations)

@@ -150,10 +150,11 @@ bool launch_filter_c4_tile(hipStream_t s, const Geom& g, const float* d_plain_ta
 bool launch_resample3c_fast(hipStream_t s, const Geom& g, ComplexOrder order, const ResampTable& t, const int* increments, const float* d_groups,
                             const float* d_plain_taps, const float* d_in, float* d_out);
 // d_iq != nullptr: fmDemod fused into the loader (d_iq = decimator output at input 0 of the launch, y_count inputs; d_in is
-// then the y buffer, filled only where the lead / tail / seam kernels read it); false = not this shape, nothing launched
+// then the y buffer, filled only where the lead / tail / seam kernels read it); false = not this shape, nothing launched.
+// lanes = 8: AVX order; 4: SSE order (64-float groups, no fused demodulator)
 bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& t, const int* increments,
                                const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out,
-                               const float* d_iq = nullptr, bool iq_has_prev = false, int64_t y_count = 0);
+                               const float* d_iq = nullptr, bool iq_has_prev = false, int64_t y_count = 0, int lanes = 8);
 // kernels_tail.hip: fmDemod -> 3/10 resampler -> symmetric filter (* gain) as one kernel (y and z never leave LDS); false = the
 // configuration is not the FM chain's tail (3 groups of 64, increments {4,3,3}, 64 half-taps, buffers longer than a tile)
 constexpr int kTailTileOutputs = 2046;   // audio outputs one workgroup of the fused tail kernel produces

@@ -317,7 +317,7 @@ struct DemodSide {
     int yseam, ykeep;      // yseam = 0: nothing to keep
 };
 
-template <int NG, int NLOOP, int INC0, int INC1, int INC2, int NT, bool DEMOD = false>
+template <int NG, int NLOOP, int INC0, int INC1, int INC2, int NT, bool DEMOD = false, int L = 8>
 __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restrict__ in, int64_t pos0, int ncycles,
                                                         int64_t avail_total, const float* __restrict__ groups,
                                                         int row_stride, float* __restrict__ out, DemodSide dm)
@@ -423,12 +423,14 @@ __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restric
 #pragma unroll
     for (int g = 0; g < 3; g++) {
         const float* c = groups + g * row_stride;
-        float acc[8];
+        // L = 8: the AVX order; L = 4: the SSE order (resampleSSERR, resample.c:52-68 -> sse_dotprod_R, common.h:34-50)
+        float acc[L];
 #pragma unroll
-        for (int l = 0; l < 8; l++) acc[l] = 0.0f;
+        for (int l = 0; l < L; l++) acc[l] = 0.0f;
 #pragma unroll
-        for (int j = 0; j < NLOOP; j++) acc[j & 7] = acc[j & 7] + c[j] * w[PRE[g] + j];
-        res[g] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        for (int j = 0; j < NLOOP; j++) acc[j % L] = acc[j % L] + c[j] * w[PRE[g] + j];
+        if constexpr (L == 8) res[g] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        else res[g] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
     // one 12-byte store per thread: the wave writes 768 contiguous bytes
     struct __attribute__((packed, aligned(4))) f3 { float a, b, c; };
@@ -528,8 +530,9 @@ bool launch_filter_cplx4_fast(hipStream_t s, const Geom& g, const float* d_dup_t
 // first / after the last whole polyphase cycle) and the neighbourhood of every seam (written by the tile kernel).
 bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& t, const int* increments,
                                const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out,
-                               const float* d_iq, bool iq_has_prev, int64_t y_count)
+                               const float* d_iq, bool iq_has_prev, int64_t y_count, int lanes)
 {
+    if (!(lanes == 8 || (lanes == 4 && d_iq == nullptr && t.nloop == 64))) return false;
     constexpr int kEdge = 256, kKeep = 160;
     if (d_iq != nullptr) {
         // the fused form serves the FM chain's shape only; anything else: the caller demodulates first
@@ -561,7 +564,7 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
     if (lead > 0) {
         Geom gl = gs;
         gl.count = lead;
-        launch_resample_real(s, gl, 8, t, d_groups, d_plain_taps, d_in, d_out);
+        launch_resample_real(s, gl, lanes, t, d_groups, d_plain_taps, d_in, d_out);
     }
     if (ncycles > 0) {
         // position of the first group-0 output relative to d_in
@@ -577,7 +580,10 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
             dm.ykeep = kKeep;
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, true>), dim3(blocks), dim3(NT), 0, s, d_iq, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);
-        } else if (t.nloop == 64)
+        } else if (lanes == 4)
+            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, false, 4>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
+                               d_groups, t.row_stride, d_out + lead, dm);
+        else if (t.nloop == 64)
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);
         else
@@ -593,7 +599,7 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
         tt.group0 = 0;
         tt.pos0 = t.pos0 + (lead > 0 ? t.pre[lead - 1] + increments[(t.group0 + lead - 1) % 3] : 0) + (int64_t)ncycles * 10;
         tt.pre[0] = 0; tt.pre[1] = 4; tt.pre[2] = 7;
-        launch_resample_real(s, gt, 8, tt, d_groups, d_plain_taps, d_in, d_out + done);
+        launch_resample_real(s, gt, lanes, tt, d_groups, d_plain_taps, d_in, d_out + done);
     }
     if (g.seamBI != 0) {
         int64_t first, last;

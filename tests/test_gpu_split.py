@@ -151,8 +151,8 @@ def test_resampler_families(hip, oracle, order, complex_, I, D, ntaps):
     K = exp.size // w
     assert K >= 4096
     r = hip.Resampler(I, D, taps, order, complex_)
-    # 3/10 with 64-tap groups has specialised kernels: real AVX (k_resample3_fast), complex AVX / SSE (k_resample3c_fast)
-    is_special = (I, D) == (3, 10) and 185 <= ntaps <= 192 and (order == PM.ORDER_AVX or (complex_ and order == PM.ORDER_SSE))
+    # 3/10 with 64-tap groups has specialised kernels: real AVX / SSE (k_resample3_fast), complex AVX / SSE (k_resample3c_fast)
+    is_special = (I, D) == (3, 10) and 185 <= ntaps <= 192
     # real I/D with an odd decimation 3 / 5 / 7 has the thread-per-cycle kernel (kernels_resample_cycle.hip), both lane orders
     is_cycle = not complex_ and D in (3, 5, 7)
     before, before_cycle = _tiled(hip), hip.lib.sdrhip_debug_resample_cycle_launches()
