@@ -346,6 +346,8 @@ long long sdrhip_debug_small_chain_launches(void);
 /* launches of the thread-per-polyphase-cycle resampler (real I/D with an odd decimation: 2/3, 5/7, ...; any filter length),
  * process-wide (tests assert that this kernel, not the lane-split one, served those ratios) */
 long long sdrhip_debug_resample_cycle_launches(void);
+/* launches of the real decimator kernel for factors 2 / 4 / 8 / 16 (kernels_decimate_real.hip), process-wide */
+long long sdrhip_debug_decimate_real16_launches(void);
 /* A/B switch (measurements only; results are identical): 0 = the tiled AVX-order decimator runs every tile through its general
  * instantiation, 1 (default) = whole tiles through the specialised one.  SDRHIP_FULL_TILES=0/1 sets the initial value. */
 void sdrhip_debug_set_full_tiles(int on);

@@ -551,6 +551,7 @@ int sdrhip_fm_chain_set_small_chain(sdrhip_fm_chain* c, int mode, int64_t max_ou
 
 long long sdrhip_debug_small_chain_launches(void) { return fm_chain_small_launch_count(); }
 long long sdrhip_debug_resample_cycle_launches(void) { return resample_cycle_launch_count(); }
+long long sdrhip_debug_decimate_real16_launches(void) { return decimate_real16_launch_count(); }
 void sdrhip_debug_set_full_tiles(int on) { set_full_tiles(on); }
 
 int sdrhip_fm_chain_set_demod_fusion(sdrhip_fm_chain* c, int enable)

@@ -111,12 +111,14 @@ inline void seam_range(const Geom& g, int64_t& first, int64_t& last)
 }
 
 // Cross outputs of the real resampler (resampleCrossHighLevel, FilterInternal.hs:410-423):
-// taps = stride I (drop filterOffset coeffs) over the UNPADDED taps, sequential.  A group of LPG
+// taps = stride I (drop filterOffset coeffs) over the UNPADDED taps, sequential -- and with I = 1 the Cross outputs of a real
+// decimator / filter (decimateCrossHighLevel / filterCrossHighLevel, FilterInternal.hs:397-408).  A group of LPG
 // (32 or 64) lanes serves one seam: its <= PER straddlers read a union of <= UNI consecutive inputs, staged in LDS.
 template <int PER, int UNI, int LPG = 32>
 __global__ void __launch_bounds__(256) k_resample_real_crossfix(Geom g, const float* __restrict__ plain, int ntaps,
                                                                  const float* __restrict__ in, float* __restrict__ out,
-                                                                 int64_t first_seam, int nseams, int64_t in_avail)
+                                                                 int64_t first_seam, int nseams, int64_t in_avail, float gain = 1.0f,
+                                                                 int apply_gain = 0)
 {
     static_assert((LPG == 32 || LPG == 64) && PER <= LPG, "one group of LPG lanes per seam");
     constexpr int SPW = 256 / LPG;                                       // seams per workgroup
@@ -161,11 +163,24 @@ __global__ void __launch_bounds__(256) k_resample_real_crossfix(Geom g, const fl
     const int fo = (int)(pos * g.I - v);
     const float* x = lds[sl] + (pos - p_lo);
     float r = 0.0f;
-    if (taps_in_lds) {
+    if (taps_in_lds && g.I == 1) {
+        // decimators / filters: unit stride, so the reads of eight taps ahead are issued together (the chain of dependent
+        // additions is the sequential order itself; what can be hidden is the LDS latency in front of each of them)
+        int j = 0;
+        for (; j + 8 <= ntaps; j += 8) {
+            float xv[8], tv[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { xv[i] = x[j + i]; tv[i] = tl[j + i]; }
+#pragma unroll
+            for (int i = 0; i < 8; i++) r = r + xv[i] * tv[i];
+        }
+        for (; j < ntaps; j++) r = r + x[j] * tl[j];
+    } else if (taps_in_lds) {
         for (int l = 0, j = fo; j < ntaps; l++, j += g.I) r = r + x[l] * tl[j];
     } else {
         for (int l = 0, j = fo; j < ntaps; l++, j += g.I) r = r + x[l] * plain[j];
     }
+    if (apply_gain) r = r * gain;
     out[m - g.k_begin] = r;
 }
 

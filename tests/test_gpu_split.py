@@ -77,9 +77,13 @@ def test_decimator_families(hip, oracle, order, complex_, factor, ntaps):
     # the SSE order through kernels_fast_orders.hip)
     special = (factor in (4, 8, 16) and order in (PM.ORDER_AVX, PM.ORDER_SSE) and complex_ and d.num_coeffs % 4 == 0
                and factor < d.num_coeffs <= (128 if factor == 4 else 256))
-    before = _tiled(hip)
+    # real decimators by 2 / 4 / 8 / 16: kernels_decimate_real.hip
+    real16 = not complex_ and factor in (2, 4, 8, 16)
+    before, before16 = _tiled(hip), hip.lib.sdrhip_debug_decimate_real16_launches()
     got = _run(d, to_dev(x), w, K, B)
-    if _fits(d.num_coeffs, order, complex_) and not special:
+    if real16:
+        assert hip.lib.sdrhip_debug_decimate_real16_launches() > before16, "the real decimator's own kernel did not take this launch"
+    elif _fits(d.num_coeffs, order, complex_) and not special:
         assert _tiled(hip) > before, "the tiled kernel did not take this launch"
     assert_bit_equal(got, exp, "one launch")
     got = _run(d, to_dev(x), w, K, B, cuts=[4097, K - 4099])
@@ -88,6 +92,37 @@ def test_decimator_families(hip, oracle, order, complex_, factor, ntaps):
     got0 = _run(d, to_dev(x), w, K, 0)
     seq = PM.FilterModel(oracle, taps, order, complex_=complex_, factor=factor)
     assert_bit_equal(got0[: w * 16], seq.one(16, x), "contiguous (all One)")
+
+
+@pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE])
+@pytest.mark.parametrize("factor", [2, 4, 8, 16])
+@pytest.mark.parametrize("ntaps", [20, 28, 37, 128, 300, 1000])
+def test_real_decimator16(hip, oracle, order, factor, ntaps):
+    """Every instantiation of kernels_decimate_real.hip: filters shorter than one 16-tap step, with every remainder of the
+    rolled walk (SSE: 4 / 8 / 12 taps, AVX: 8), launches cut at odd outputs (a thread owns 16 / factor consecutive ones) and
+    at float offsets that are not 16-byte aligned, with and without seams (decimate.c:36-66 for One outputs,
+    FilterInternal.hs:397-402 at seams)."""
+    x = S.real_block(NBLK * B)
+    taps = S.gauss_taps(ntaps, 7 * factor + ntaps)
+    model = PM.FilterModel(oracle, taps, order, factor=factor)
+    blocks, _ = PM.fir_decimator_pipe(model, _split(x, 1, B), 1024)
+    exp = np.concatenate(blocks)
+    K = exp.size
+    d = hip.Decimator(factor, taps, order)
+    before = hip.lib.sdrhip_debug_decimate_real16_launches()
+    got = _run(d, to_dev(x), 1, K, B)
+    if d.num_coeffs >= 8:
+        assert hip.lib.sdrhip_debug_decimate_real16_launches() > before, "the real decimator's own kernel did not take this launch"
+    assert_bit_equal(got, exp, f"/{factor}, {ntaps} taps: one launch")
+    got = _run(d, to_dev(x), 1, K, B, cuts=[4097, 4097 + 4099, 4097 + 4099 + 4101, K - 4103])
+    assert_bit_equal(got, exp, f"/{factor}, {ntaps} taps: cut into launches")
+    # one contiguous buffer (no seams), read from a float offset that is not 16-byte aligned
+    model1 = PM.FilterModel(oracle, taps, order, factor=factor)
+    exp1 = model1.one((x.size - 3 - d.num_coeffs) // factor + 1, x[3:])
+    dx = to_dev(x)
+    out = dev_empty_f32(exp1.size)
+    d.run(ptr(dx) + 12, 0, ptr(out), 0, exp1.size, 0)
+    assert_bit_equal(to_host(out), exp1, f"/{factor}, {ntaps} taps: no seams, unaligned input")
 
 
 @pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE])
