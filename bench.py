@@ -669,10 +669,14 @@ def main():
                 "note": "zero-copy lines: the source writes the library's pinned staging buffer itself (a radio's DMA target), so they carry "
                         "no source-side copy; *_memcpy: the caller's block is copied in by the push, which is what the reference's host path "
                         "(and cpu_single_thread_chain) includes"}
-        for name, bpp, pushes, zc in (("fm_stream_1_block_per_push", 1, 4000, True), ("fm_stream_1_block_per_push_memcpy", 1, 4000, False),
-                                      ("fm_stream_16_blocks_per_push", 16, 1000, True), ("fm_stream_4096_blocks_per_push_zero_copy", 4096, 12, True)):
+        host["note_adaptive"] = ("pushes are submitted at once while the GPU keeps up and pile up in the pinned staging buffer while it is busy "
+                                 "(sdrhip_fm_stream_set_adaptive, on by default): *_every_push_its_own_launch is the same run with that off")
+        for name, bpp, pushes, zc, co in (("fm_stream_1_block_per_push", 1, 20000, True, 0), ("fm_stream_1_block_per_push_memcpy", 1, 20000, False, 0),
+                                          ("fm_stream_1_block_per_push_memcpy_every_push_its_own_launch", 1, 4000, False, 1),
+                                          ("fm_stream_16_blocks_per_push", 16, 1000, True, 0),
+                                          ("fm_stream_4096_blocks_per_push_zero_copy", 4096, 12, True, 0)):
             try:
-                sps, _ = H.fm_stream_rate(L, chain, bpp * BLOCK, pushes, zc)
+                sps, _ = H.fm_stream_rate(L, chain, bpp * BLOCK, pushes, zc, co)
                 host[name] = round(sps / 1e6, 1)
                 dbg(f"host {name} done")
             except Exception as e:                      # noqa: BLE001
@@ -680,10 +684,10 @@ def main():
         try:
             res = L.Resampler(3, 10, S.taps_resamp191(), L.ORDER_AVX)
             pp = L.Pipe("resampler", res, BLOCK)
-            host["config3_firResampler_pipe_65536_float_blocks_Melements_per_s"] = round(H.pipe_rate(L, pp.h, 65536, 1, BLOCK, 2000, True) / 1e6, 1)
+            host["config3_firResampler_pipe_65536_float_blocks_Melements_per_s"] = round(H.pipe_rate(L, pp.h, 65536, 1, BLOCK, 4000, True) / 1e6, 1)
             dec8 = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
             pd = L.Pipe("decimator", dec8, BLOCK)
-            host["config1_firDecimator_pipe_8192_cfloat_blocks_Melements_per_s"] = round(H.pipe_rate(L, pd.h, BLOCK, 2, BLOCK, 2000, True) / 1e6, 1)
+            host["config1_firDecimator_pipe_8192_cfloat_blocks_Melements_per_s"] = round(H.pipe_rate(L, pd.h, BLOCK, 2, BLOCK, 20000, True) / 1e6, 1)
         except Exception as e:                          # noqa: BLE001
             host["pipes"] = f"failed: {e!r}"
 

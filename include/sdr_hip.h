@@ -430,6 +430,12 @@ int sdrhip_fm_stream_flush(sdrhip_fm_stream *st);
  * that must keep the reference's block size (fm.hs:17) gets ~6x the throughput from coalesce = 16 blocks, at 16 blocks
  * of latency; the audio blocks are the same.  Call with nothing staged. */
 int sdrhip_fm_stream_set_coalesce(sdrhip_fm_stream *st, int samples);
+/* The same knob turned by the GPU itself: with max_samples > 0 (a multiple of the chain's block, at least two pushes) a push
+ * is submitted at once while the slot its submission would move on to is free, and staged behind the earlier ones while that
+ * slot is still running -- up to max_samples, then the push waits.  A source slower than the GPU (a radio) sees every push
+ * go out immediately; a faster one (file replay) sees its pushes leave as fewer, larger launches.  Which push returns which
+ * audio block then depends on timing; the blocks themselves do not.  0 switches it off.  Call with nothing staged. */
+int sdrhip_fm_stream_set_adaptive(sdrhip_fm_stream *st, int max_samples);
 int sdrhip_fm_stream_pop(sdrhip_fm_stream *st, float *out, int capacity);
 /* Checkpoint / resume.  Between two pushes the operator's state is the stream position, the last ~4k input samples and
  * the audio not yet popped (the reference keeps the equivalent in Pipe closures: overlap remainder, resampler phase, last
@@ -467,7 +473,9 @@ int sdrhip_bench_copy(void *stream, const void *d_in, void *d_out, size_t bytes)
 int sdrhip_bench_copy2(void *stream, const void *d_in, void *d_out, size_t bytes, int non_temporal);
 /* Timing loops over the host-block operators, written against this header only: what a compiled caller pays per push
  * (a Python loop adds 10-20 us per call).  fm_stream: `pushes` pushes of n_samples u8 IQ samples (zero_copy: through
- * sdrhip_fm_stream_input_buffer), every audio block popped; pipe: pushes of n elements into an existing pipe. */
+ * sdrhip_fm_stream_input_buffer), every audio block popped, coalesce_samples < 0 = adaptive submission with that cap, 1 = adaptive
+ * submission off (every push its own launch), 0 = the stream's default; pipe:
+ * pushes of n elements into an existing pipe. */
 struct sdrhip_pipe;
 int sdrhip_bench_fm_stream(sdrhip_fm_chain *chain, int n_samples, int pushes, int zero_copy, int coalesce_samples,
                            double *samples_per_s, long long *audio_blocks);
@@ -495,9 +503,14 @@ int sdrhip_pipe_push(sdrhip_pipe *p, const float *block, int n);
  *  - set_coalesce(blocks): equal-sized pushes are staged in the pinned buffer and submitted `blocks` at a
  *    time (one upload, one run over the batch with its interior seams, one download); a push of another
  *    size ends the uniform run.  0 / 1 = every push on its own.
+ *  - set_adaptive(max_blocks): the same, decided by the GPU: a push is submitted at once while the slot its submission would
+ *    move on to is free, and staged behind the earlier ones while that slot is still running (up to max_blocks, and never more
+ *    than is read in place over PCIe: 512 KiB); a source slower than the GPU sees every push go out immediately, a faster
+ *    one sees fewer, larger launches.  Which push returns which block then depends on timing.  0 = off.
  *  - input_buffer(n): the pinned staging memory the next push of n elements will be uploaded from; fill it
  *    and push that pointer to skip the host-side copy. */
 int sdrhip_pipe_set_coalesce(sdrhip_pipe *p, int blocks);
+int sdrhip_pipe_set_adaptive(sdrhip_pipe *p, int max_blocks);
 float *sdrhip_pipe_input_buffer(sdrhip_pipe *p, int n);
 int sdrhip_pipe_flush(sdrhip_pipe *p);
 /* Pop one ready block into out (capacity in elements); returns its length, 0 if none. */

@@ -23,7 +23,10 @@ int sdrhip_bench_fm_stream(sdrhip_fm_chain* chain, int n_samples, int pushes, in
     sdrhip_fm_stream* st = nullptr;
     int rc = sdrhip_fm_stream_create(&st, chain, n_samples, 8192);
     if (rc != SDRHIP_OK) return rc;
-    if (coalesce_samples > 0 && (rc = sdrhip_fm_stream_set_coalesce(st, coalesce_samples)) != SDRHIP_OK) { sdrhip_fm_stream_destroy(st); return rc; }
+    if (coalesce_samples == 1) rc = sdrhip_fm_stream_set_adaptive(st, 0);        // every push on its own
+    else if (coalesce_samples < 0) rc = sdrhip_fm_stream_set_adaptive(st, -coalesce_samples);
+    else if (coalesce_samples > 0) rc = sdrhip_fm_stream_set_coalesce(st, coalesce_samples);
+    if (rc != SDRHIP_OK) { sdrhip_fm_stream_destroy(st); return rc; }
     std::vector<uint8_t> src((size_t)2 * n_samples);
     uint32_t s = 12345u;
     for (auto& b : src) { s = s * 1664525u + 1013904223u; b = (uint8_t)(s >> 24); }

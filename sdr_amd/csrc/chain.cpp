@@ -646,7 +646,14 @@ struct sdrhip_fm_stream {
     int cur() const { return (int)(pushes % nslots); }
     int staged = 0;            // samples copied into the current slot's staging buffer, not yet submitted
     int coalesce = 0;          // submit once this many samples are staged (0: every push)
-    int capacity() const { return coalesce > max_block ? coalesce : max_block; }
+    int adaptive = 0;          // > 0: submit when the next slot is free, else keep staging up to this many samples
+    int capacity() const
+    {
+        int c = coalesce > max_block ? coalesce : max_block;
+        return adaptive > c ? adaptive : c;
+    }
+    // is slot si's last submission still running on the GPU?
+    bool in_flight(int si) const { return slot[si].busy && hipEventQuery(slot[si].ev) == hipErrorNotReady; }
     std::vector<float> fifo;
     size_t head = 0;
 
@@ -698,6 +705,16 @@ int sdrhip_fm_stream_create(sdrhip_fm_stream** out, sdrhip_fm_chain* chain, int 
         int want = (st->direct_ok && st->head_cap + (int64_t)max_block_samples <= st->direct_samples) ? sdrhip_fm_stream::kMaxSlots : 2;
         if (env && atoi(env) >= 2 && atoi(env) <= sdrhip_fm_stream::kMaxSlots) want = atoi(env);
         st->nslots = want;
+    }
+    // adaptive submission by default for operators that run in place (sdrhip_fm_stream_set_adaptive; SDRHIP_STREAM_ADAPTIVE=0
+    // switches the default off, =n caps it at n source blocks): up to what is still read in place over PCIe
+    if (st->nslots == sdrhip_fm_stream::kMaxSlots) {
+        const char* env = getenv("SDRHIP_STREAM_ADAPTIVE");
+        const int64_t unit = chain->block > 0 ? chain->block : 8;
+        int64_t cap = (st->direct_samples - st->head_cap) / unit;
+        if (env && atoll(env) < cap) cap = atoll(env);
+        cap *= unit;
+        if (cap >= 2 * (int64_t)max_block_samples && cap <= (1 << 30)) st->adaptive = (int)cap;
     }
     hipError_t e = hipSuccess;
     for (int i = 0; i < st->nslots; i++)
@@ -834,6 +851,18 @@ int sdrhip_fm_stream_set_coalesce(sdrhip_fm_stream* st, int samples)
     return SDRHIP_OK;
 }
 
+int sdrhip_fm_stream_set_adaptive(sdrhip_fm_stream* st, int max_samples)
+{
+    SDRHIP_REQUIRE(st != nullptr && max_samples >= 0, "sdrhip_fm_stream_set_adaptive");
+    SDRHIP_REQUIRE(st->staged == 0, "sdrhip_fm_stream_set_adaptive: samples are staged (flush first)");
+    SDRHIP_REQUIRE(st->c->block == 0 || max_samples % st->c->block == 0, "sdrhip_fm_stream_set_adaptive: whole source blocks only");
+    SDRHIP_REQUIRE(max_samples == 0 || max_samples >= 2 * st->max_block, "sdrhip_fm_stream_set_adaptive: room for at least two pushes");
+    for (hipStream_t s : {st->up, st->compute[0], st->compute[1], st->compute[2], st->compute[3], st->down})
+        if (s) SDRHIP_CHECK_HIP(hipStreamSynchronize(s));   // staging buffers may be reallocated
+    st->adaptive = max_samples;
+    return SDRHIP_OK;
+}
+
 uint8_t* sdrhip_fm_stream_input_buffer(sdrhip_fm_stream* st)
 {
     if (st == nullptr) { set_error("sdrhip_fm_stream_input_buffer: null stream"); return nullptr; }
@@ -854,7 +883,14 @@ int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
     uint8_t* dst = st->staged_base(st->slot[st->cur()]) + (size_t)st->staged * 2;
     if (iq != dst) memcpy(dst, iq, (size_t)n * 2);   // else: the caller filled our staging buffer in place
     st->staged += n;
-    if (st->staged >= st->coalesce && (rc = stream_submit(st)) != SDRHIP_OK) return rc;
+    bool submit = st->staged >= st->coalesce;
+    if (st->adaptive > 0 && submit) {
+        // a GPU that keeps up gets every push at once (lowest latency); one that is still busy with the slot this submission
+        // would move on to lets the pushes pile up in the staging buffer and takes them as ONE launch when it frees up
+        const bool room = st->staged + st->max_block <= st->capacity();
+        submit = !room || !st->in_flight((st->cur() + 1) % st->nslots);
+    }
+    if (submit && (rc = stream_submit(st)) != SDRHIP_OK) return rc;
     return st->ready();
 }
 

@@ -59,12 +59,32 @@ struct sdrhip_pipe {
     int64_t hist_n = 0;
     bool direct_ok = getenv("SDRHIP_NO_DIRECT_STREAM") == nullptr;
     static constexpr size_t kDirectBytes = 512 << 10;     // [tail | staged] up to this size is read in place over PCIe
+    static constexpr size_t kAdaptiveBytes = 4 << 20;     // adaptive submission stages at most this much
     int64_t E_prev = 0;     // global end of the previous block
     int64_t m_done = 0;     // outputs computed so far
     float last_re = 0.0f, last_im = 0.0f;  // fmDemod carry (Demod.hs:41,46)
     // coalescing of equal-sized pushes (FIR-like stages): samples staged in the current slot, not yet submitted
     int staged = 0;
     int coalesce = 0;          // blocks per submission (0/1: every push)
+    // > 1: submit when the next slot is free, else keep staging up to this many blocks.  On by default (SDRHIP_STREAM_ADAPTIVE=0
+    // or sdrhip_pipe_set_adaptive(p, 0) switch it off): a source that is slower than the GPU never notices, a faster one
+    // gets the throughput of coalesced pushes at the reference's own block size
+    int adaptive = getenv("SDRHIP_STREAM_ADAPTIVE") ? atoi(getenv("SDRHIP_STREAM_ADAPTIVE")) : kAdaptiveBlocks;
+    static constexpr int kAdaptiveBlocks = 32;
+    // blocks per submission in force for blocks of `uni` elements: the adaptive cap stays inside what is read in place
+    int coalesce_eff(int uni) const
+    {
+        if (adaptive > 1 && uni > 0) {
+            const int64_t esz = (int64_t)(cplx_in ? 2 : 1) * 4;
+            // (measured, 8192-sample cfloat blocks into firDecimator: batches of up to 0.5 / 1 / 4 / 16 MiB -> 2.7 / 2.3-3.0 /
+            // 3.0-4.9 / 3.7-4.8 G elements/s; batches past kDirectBytes go through the copy engines)
+            static const int64_t bytes = getenv("SDRHIP_ADAPTIVE_BYTES") ? atoll(getenv("SDRHIP_ADAPTIVE_BYTES")) : (int64_t)kAdaptiveBytes;
+            const int64_t fit = bytes / ((int64_t)uni * esz);
+            const int64_t b = adaptive < fit ? adaptive : fit;
+            if (b >= 2) return (int)b;
+        }
+        return coalesce;
+    }
     int uniform_n = 0;         // size of the first block; all_uniform: every block so far had it
     bool all_uniform = true;
     int lent = 0;              // elements behind `staged` the caller may have filled through sdrhip_pipe_input_buffer
@@ -80,6 +100,8 @@ struct sdrhip_pipe {
         bool direct = false; // the last submission ran in place: `ev` also releases the staging buffer
     } slot[kMaxSlots];
     int64_t pushes = 0;
+    // is slot si's last submission still running on the GPU?
+    bool in_flight(int si) const { return slot[si].busy && hipEventQuery(slot[si].ev) == hipErrorNotReady; }
 
     // produced output floats not yet popped: contiguous storage + read cursor (memcpy in/out)
     std::vector<float> fifo;
@@ -337,9 +359,10 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
     // the size of the first ACCEPTED block is the uniform size: a block the checks below refuse must not latch it
     const int uni = p->uniform_n == 0 ? n : p->uniform_n;
     const bool all_uniform = p->all_uniform && n == uni;
-    const bool coalescing = p->coalesce > 1 && all_uniform;
-    if ((int64_t)p->coalesce * uni > (int64_t)1 << 30) {
-        set_error("pipe: %d coalesced blocks of %d elements exceed the staging limit", p->coalesce, uni);
+    const int ce = p->coalesce_eff(uni);
+    const bool coalescing = ce > 1 && all_uniform;
+    if ((int64_t)ce * uni > (int64_t)1 << 30) {
+        set_error("pipe: %d coalesced blocks of %d elements exceed the staging limit", ce, uni);
         return SDRHIP_ERR_ARG;
     }
     // zero-copy push: `block` is the staging buffer's own write position (sdrhip_pipe_input_buffer); noted before the
@@ -360,7 +383,7 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
     if ((rc = fir_check_block(p, p->E_prev + p->staged, m_pending, n)) != SDRHIP_OK) return rc;
     p->uniform_n = uni;
     p->all_uniform = all_uniform;
-    const int64_t cap = coalescing ? (int64_t)p->coalesce * p->uniform_n : n;
+    const int64_t cap = coalescing ? (int64_t)ce * p->uniform_n : n;
     if ((rc = fir_open_slot(p, (size_t)(cap > p->staged + n ? cap : p->staged + n))) != SDRHIP_OK) return rc;
     float* dst = p->staged_base(p->slot[p->cur_slot()]) + (size_t)p->staged * p->esz_in();
     if (!still_in_place) memcpy(dst, block, (size_t)n * ein);   // else: the caller filled the staging buffer in place
@@ -370,7 +393,10 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
         // equal-sized blocks from the start: the seams are the multiples of that size and one run covers Cross and One
         // outputs alike; otherwise (ragged blocks) the two-part submission
         if ((rc = fir_submit(p, p->staged, p->all_uniform ? p->uniform_n : 0)) != SDRHIP_OK) return rc;
-    } else if (p->staged >= (int64_t)p->coalesce * p->uniform_n) {
+    } else if (p->staged >= (int64_t)ce * p->uniform_n ||
+               (p->adaptive > 1 && !p->in_flight((p->cur_slot() + 1) % p->nslots))) {
+        // (adaptive: a GPU that keeps up gets every push at once; one still busy with the slot this submission would move on
+        // to lets the blocks pile up in the staging buffer and takes them as one launch when it frees up)
         if ((rc = fir_submit(p, p->staged, p->uniform_n)) != SDRHIP_OK) return rc;
     }
     return ready_blocks(p);
@@ -514,14 +540,24 @@ int sdrhip_pipe_set_coalesce(sdrhip_pipe* p, int blocks)
     return SDRHIP_OK;
 }
 
+int sdrhip_pipe_set_adaptive(sdrhip_pipe* p, int max_blocks)
+{
+    SDRHIP_REQUIRE(p != nullptr && max_blocks >= 0 && max_blocks != 1, "sdrhip_pipe_set_adaptive: 0 (off) or at least two blocks");
+    SDRHIP_REQUIRE(!p->is_map(), "sdrhip_pipe_set_adaptive: filter / decimator / resampler pipes only");
+    SDRHIP_REQUIRE(p->staged == 0, "sdrhip_pipe_set_adaptive: blocks are staged (flush first)");
+    p->adaptive = max_blocks;
+    return SDRHIP_OK;
+}
+
 float* sdrhip_pipe_input_buffer(sdrhip_pipe* p, int n)
 {
     if (p == nullptr || n <= 0 || p->is_map()) { set_error("sdrhip_pipe_input_buffer: filter / decimator / resampler pipes, n > 0"); return nullptr; }
-    const bool coalescing = p->coalesce > 1 && p->all_uniform && (p->uniform_n == 0 || p->uniform_n == n);
+    const int ce = p->coalesce_eff(p->uniform_n ? p->uniform_n : n);
+    const bool coalescing = ce > 1 && p->all_uniform && (p->uniform_n == 0 || p->uniform_n == n);
     if (!coalescing && p->staged > 0 && fir_submit(p, p->staged, p->uniform_n) != SDRHIP_OK) return nullptr;
     // a fresh pipe has no uniform size yet: the block about to be pushed defines it, so size the buffer for a whole
     // coalesced batch of such blocks now (growing it at the push would move the block the caller is about to fill)
-    const int64_t cap = coalescing ? (int64_t)p->coalesce * (p->uniform_n ? p->uniform_n : n) : n;
+    const int64_t cap = coalescing ? (int64_t)ce * (p->uniform_n ? p->uniform_n : n) : n;
     if (cap > (int64_t)1 << 30) { set_error("sdrhip_pipe_input_buffer: coalesced batch too large"); return nullptr; }
     if (fir_open_slot(p, (size_t)(cap > p->staged + n ? cap : p->staged + n)) != SDRHIP_OK) return nullptr;
     p->lent = n;

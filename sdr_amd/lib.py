@@ -179,6 +179,7 @@ lib.sdrhip_fm_stream_destroy.restype = None
 lib.sdrhip_fm_stream_push.argtypes = [_vp, _u8p, C.c_int]
 lib.sdrhip_fm_stream_flush.argtypes = [_vp]
 lib.sdrhip_fm_stream_set_coalesce.argtypes = [_vp, C.c_int]
+lib.sdrhip_fm_stream_set_adaptive.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_stream_input_buffer.argtypes = [_vp]
 lib.sdrhip_fm_stream_input_buffer.restype = _vp
 lib.sdrhip_fm_stream_pop.argtypes = [_vp, _f32p, C.c_int]
@@ -189,6 +190,7 @@ lib.sdrhip_pipe_fir_resampler.argtypes = [C.POINTER(_vp), _vp, C.c_int]
 lib.sdrhip_pipe_fm_demod.argtypes = [C.POINTER(_vp)]
 lib.sdrhip_pipe_dc_blocker.argtypes = [C.POINTER(_vp)]
 lib.sdrhip_pipe_set_coalesce.argtypes = [_vp, C.c_int]
+lib.sdrhip_pipe_set_adaptive.argtypes = [_vp, C.c_int]
 lib.sdrhip_pipe_input_buffer.argtypes = [_vp, C.c_int]
 lib.sdrhip_pipe_input_buffer.restype = _vp
 lib.sdrhip_pipe_push.argtypes = [_vp, _f32p, C.c_int]
@@ -578,6 +580,9 @@ class FmStream(_Handle):
     def set_coalesce(self, samples):
         check(lib.sdrhip_fm_stream_set_coalesce(self.h, samples), "sdrhip_fm_stream_set_coalesce")
 
+    def set_adaptive(self, max_samples):
+        check(lib.sdrhip_fm_stream_set_adaptive(self.h, max_samples), "sdrhip_fm_stream_set_adaptive")
+
     def _pop(self, ready):
         outs = []
         for _ in range(ready):
@@ -654,6 +659,9 @@ class Pipe(_Handle):
 
     def set_coalesce(self, blocks):
         check(lib.sdrhip_pipe_set_coalesce(self.h, blocks), "sdrhip_pipe_set_coalesce")
+
+    def set_adaptive(self, max_blocks):
+        check(lib.sdrhip_pipe_set_adaptive(self.h, max_blocks), "sdrhip_pipe_set_adaptive")
 
     def input_buffer(self, n):
         """numpy view (n elements; interleaved pairs for complex stages) of the pinned staging memory of the next push."""

@@ -222,6 +222,44 @@ def test_fm_stream_coalesce(hip, oracle, coalesce_blocks):
         st.set_coalesce(2 * B)                     # samples staged: refuse
 
 
+@pytest.mark.parametrize("cap_blocks", [2, 8, 32])
+def test_fm_stream_adaptive(hip, oracle, cap_blocks):
+    """Adaptive submission (pushes are staged while the slot ahead is still running and leave as one launch when it frees up):
+    how the pushes are grouped depends on timing, the audio does not -- fast pushes, pushes with pauses, lent buffers."""
+    import time
+    nblk = 300
+    u8 = S.iq_u8_fm(nblk * B)
+    exp = _model(oracle, u8, nblk)
+    chain = _chain(hip)
+    st = hip.FmStream(chain, B, B)
+    st.set_adaptive(cap_blocks * B)
+    got = []
+    for i in range(nblk):
+        if i % 3 == 0:
+            view = st.input_buffer(B)
+            view[:] = u8[2 * i * B: 2 * (i + 1) * B]
+            got += st.push_inplace(view)
+        else:
+            got += st.push(u8[2 * i * B: 2 * (i + 1) * B])
+        if i % 50 == 49:
+            time.sleep(0.002)                      # the GPU catches up: the next pushes go out one by one again
+    got += st.flush()
+    got = np.concatenate(got)
+    assert got.size >= exp.size
+    assert_bit_equal(got[: exp.size], exp, "adaptive stream")
+    st.set_adaptive(0)
+    with pytest.raises(hip.SdrHipError):
+        st.set_adaptive(B)                         # less than two pushes
+    with pytest.raises(hip.SdrHipError):
+        st.push(u8[: 2 * B])
+        st.flush()
+        st.push(u8[: 2 * B])
+        st.set_adaptive(4 * B)                     # samples may be staged / in flight: only refused while staged
+        st.set_coalesce(4 * B)
+        st.push(u8[: 2 * B])
+        st.set_adaptive(4 * B)                     # staged now: refuse
+
+
 def test_chain_random_sweep(hip, oracle):
     """Seeded random receivers (decimation, tap counts, resampling ratio, gain, source block size, SIMD order): the
     device-resident chain in one launch, the same chain sharded in three, and the host-block stream operator all give the

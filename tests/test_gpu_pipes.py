@@ -291,6 +291,19 @@ def test_uniform_block_pipes_coalesced_sweep(hip, oracle):
                 got += pipe.push(b)
         got += pipe.flush()
         _cmp(got, exp, label + " (coalesced, zero-copy every third push)")
+        # adaptive submission: how the pushes are grouped depends on how busy the GPU is, the blocks do not
+        pipe = mk()
+        pipe.set_adaptive(int(rng.integers(2, 40)))
+        got = []
+        for i, b in enumerate(blocks):
+            if i % 4 == 2:
+                view = pipe.input_buffer(b.size // w)
+                view[:] = b
+                got += pipe.push(view)
+            else:
+                got += pipe.push(b)
+        got += pipe.flush()
+        _cmp(got, exp, label + " (adaptive submission, zero-copy every fourth push)")
         ran += 1
     assert ran >= 20
 

@@ -24,11 +24,21 @@ def main():
     import signals as S
     B = 8192
     chain = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, B)
-    for bpp, pushes in ((1, 4000), (2, 3000), (4, 2000), (16, 1000), (256, 100), (4096, 12)):
+    # default = adaptive submission (sdrhip_fm_stream_set_adaptive): pushes pile up in the staging buffer while the GPU is busy
+    for bpp, pushes in ((1, 20000), (2, 10000), (4, 5000), (16, 2000), (256, 100), (4096, 12)):
         for zc in (False, True):
             sps, blocks = fm_stream_rate(L, chain, bpp * B, pushes, zc)
             print(f"sdrhip_fm_stream {bpp:5d} block(s)/push, {'zero-copy' if zc else 'memcpy   '}: {sps / 1e6:9.1f} Msamples/s "
-                  f"({bpp * B / sps * 1e6:7.1f} us/push, {blocks} audio blocks)")
+                  f"({bpp * B / sps * 1e6:7.2f} us/push, {blocks} audio blocks)")
+    for bpp, pushes in ((1, 4000), (2, 3000), (4, 2000), (16, 1000)):
+        for zc in (False, True):
+            sps, blocks = fm_stream_rate(L, chain, bpp * B, pushes, zc, coalesce=1)
+            print(f"sdrhip_fm_stream {bpp:5d} block(s)/push, {'zero-copy' if zc else 'memcpy   '}, every push its own launch: {sps / 1e6:9.1f} Msamples/s "
+                  f"({bpp * B / sps * 1e6:7.2f} us/push, {blocks} audio blocks)")
+    for zc in (False, True):
+        sps, blocks = fm_stream_rate(L, chain, B, 20000, zc, coalesce=-8 * B)
+        print(f"sdrhip_fm_stream     1 block(s)/push, {'zero-copy' if zc else 'memcpy   '}, adaptive <=  8 blocks: {sps / 1e6:9.1f} Msamples/s "
+              f"({B / sps * 1e6:7.2f} us/push, {blocks} audio blocks)")
     dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
     res = L.Resampler(3, 10, S.taps_resamp191(), L.ORDER_AVX)
     fil = L.Filter(S.taps_audio_half64(), L.ORDER_AVX, sym=True)
@@ -37,8 +47,13 @@ def main():
                              ("firFilter 64 half-taps sym, 8192-float blocks", lambda: L.Pipe("filter", fil, B), B, 1)):
         for zc in (False, True):
             p = mk()
+            r = pipe_rate(L, p.h, n, fpe, B, 20000 if n <= B else 4000, zc)
+            print(f"{name}, {'zero-copy' if zc else 'memcpy   '}: {r / 1e6:8.1f} M elements/s ({n / r * 1e6:6.2f} us/push)")
+        for zc in (False, True):
+            p = mk()
+            p.set_adaptive(0)
             r = pipe_rate(L, p.h, n, fpe, B, 2000, zc)
-            print(f"{name}, {'zero-copy' if zc else 'memcpy   '}: {r / 1e6:8.1f} M elements/s ({n / r * 1e6:6.1f} us/push)")
+            print(f"{name}, {'zero-copy' if zc else 'memcpy   '}, every push its own launch: {r / 1e6:8.1f} M elements/s ({n / r * 1e6:6.2f} us/push)")
 
 
 if __name__ == "__main__":
