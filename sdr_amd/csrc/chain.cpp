@@ -608,7 +608,8 @@ int sdrhip_fm_chain_read_timing(sdrhip_fm_chain* c, double* ms_sum, int* runs)
 //     memory: ONE kernel launch for a push of a few blocks (kernels_small.hip; two launches -- decimator with its seams,
 //     fused tail -- where the one-kernel chain does not apply) and one event per push instead of ~15 API calls, which is
 //     what the reference's own block size (8192 samples) needs to beat one CPU thread.
-// Results lag nslots - 1 pushes (sdrhip_fm_stream_flush drains).
+// Results lag at most nslots - 1 submissions (sdrhip_fm_stream_flush drains); with adaptive submission (the default for
+// operators that run in place) a push that finds the next slot still busy is staged behind the earlier ones and leaves with them.
 // ---------------------------------------------------------------------------
 struct sdrhip_fm_stream {
     sdrhip_fm_chain* c = nullptr;
