@@ -78,6 +78,9 @@ foreign import ccall safe "sdrhip_pipe_dc_blocker"     c_pipe_dc_blocker   :: Pt
 -- throughput knob: stage equal-sized pushes and submit them n at a time (same output blocks, n blocks of latency)
 foreign import ccall safe "sdrhip_pipe_set_coalesce"   c_pipe_set_coalesce :: Ptr SdrPipe -> CInt -> IO CInt
 foreign import ccall safe "sdrhip_fm_stream_set_coalesce" c_stream_set_coalesce :: Ptr SdrStream -> CInt -> IO CInt
+-- adaptive submission (on by default: pushes that arrive while the GPU is busy share a launch); 0 switches it off
+foreign import ccall safe "sdrhip_pipe_set_adaptive"   c_pipe_set_adaptive :: Ptr SdrPipe -> CInt -> IO CInt
+foreign import ccall safe "sdrhip_fm_stream_set_adaptive" c_stream_set_adaptive :: Ptr SdrStream -> CInt -> IO CInt
 foreign import ccall safe "sdrhip_fm_chain_create"     c_chain_create      :: Ptr (Ptr SdrChain) -> CInt -> CInt -> Ptr CFloat -> CInt -> CInt -> CInt -> Ptr CFloat -> CInt -> Ptr CFloat -> CInt -> CFloat -> Int64 -> IO CInt
 foreign import ccall safe "sdrhip_fm_stream_create"    c_stream_create     :: Ptr (Ptr SdrStream) -> Ptr SdrChain -> CInt -> CInt -> IO CInt
 foreign import ccall safe "sdrhip_fm_stream_push"      c_stream_push       :: Ptr SdrStream -> Ptr CUChar -> CInt -> IO CInt
