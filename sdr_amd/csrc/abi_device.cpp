@@ -380,6 +380,9 @@ int resamp_run_demod(const ResampDesc* r, hipStream_t s, const float* d_iq, bool
     } else if ((r->lanes == 8 || r->lanes == 4) &&
                launch_resample_3_10_fast(s, g, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out, nullptr, false, 0, r->lanes)) {
         // specialised 3-group kernel took it
+    } else if (g.I == 1 && t.ext == nullptr && t.group0 == 0 &&
+               launch_decimate_real16_fast(s, g, r->lanes, r->d_groups, t.nloop, r->d_plain, d_in, d_out, 1.0f, false, t.ntaps_plain)) {
+        // interpolation 1: a decimator by 2 / 4 / 8 / 16 in the resampler's clothes (one group, the same lane order)
     } else if (launch_resample_cycle_fast(s, g, r->lanes, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
         // thread-per-cycle kernel took it (odd decimations)
     } else if (launch_resample_split(s, g, false, r->lanes, r->corder, t, r->d_groups, r->d_plain, d_in, d_out)) {

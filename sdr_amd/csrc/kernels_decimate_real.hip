@@ -204,8 +204,9 @@ bool launch_dr(hipStream_t s, const Geom& g, const float* d_taps, int nk, const 
 long long decimate_real16_launch_count() { return g_decreal_launches.load(); }
 
 bool launch_decimate_real16_fast(hipStream_t s, const Geom& g, int lanes, const float* d_taps, int nk, const float* d_cross_taps, const float* d_in,
-                                 float* d_out, float gain, bool apply_gain)
+                                 float* d_out, float gain, bool apply_gain, int ncross)
 {
+    if (ncross <= 0) ncross = g.Lp;              // taps the sequential (Cross) outputs walk: a resampler's are the unpadded ones
     static const bool off = getenv("SDRHIP_DECIM_REAL16") != nullptr && atoi(getenv("SDRHIP_DECIM_REAL16")) == 0;     // A/B: the split kernel
     if (off || g.I != 1 || g.seamBI < 0 || g.count < 4096) return false;
     if (!(lanes == 8 || lanes == 4) || nk < 8 || nk % lanes != 0 || nk > 2048 || nk != g.Lp) return false;
@@ -236,15 +237,20 @@ bool launch_decimate_real16_fast(hipStream_t s, const Geom& g, int lanes, const 
             const int ga = apply_gain ? 1 : 0;
             auto uni = [&](int PER) { return g.Lp + PER * g.D + 4; };
             if (per <= 16 && uni(16) <= 416)
-                hipLaunchKernelGGL((k_resample_real_crossfix<16, 416, 32>), dim3((nseams + 7) / 8), dim3(256), 0, s, g, d_cross_taps, g.Lp, d_in, d_out,
+                hipLaunchKernelGGL((k_resample_real_crossfix<16, 416, 32>), dim3((nseams + 7) / 8), dim3(256), 0, s, g, d_cross_taps, ncross, d_in, d_out,
                                    first, nseams, in_avail, gain, ga);
             else if (per <= 32 && uni(32) <= 416)
-                hipLaunchKernelGGL((k_resample_real_crossfix<32, 416, 32>), dim3((nseams + 7) / 8), dim3(256), 0, s, g, d_cross_taps, g.Lp, d_in, d_out,
+                hipLaunchKernelGGL((k_resample_real_crossfix<32, 416, 32>), dim3((nseams + 7) / 8), dim3(256), 0, s, g, d_cross_taps, ncross, d_in, d_out,
                                    first, nseams, in_avail, gain, ga);
             else if (per <= 64 && uni(64) <= 1152)
-                hipLaunchKernelGGL((k_resample_real_crossfix<64, 1152, 64>), dim3((nseams + 3) / 4), dim3(256), 0, s, g, d_cross_taps, g.Lp, d_in, d_out,
+                hipLaunchKernelGGL((k_resample_real_crossfix<64, 1152, 64>), dim3((nseams + 3) / 4), dim3(256), 0, s, g, d_cross_taps, ncross, d_in, d_out,
                                    first, nseams, in_avail, gain, ga);
-            else {
+            else if (ncross != g.Lp) {
+                // a resampler with interpolation 1 whose seams do not fit the LDS kernel: its own generic fix-up (unpadded taps)
+                const int64_t total = (int64_t)nseams * per;
+                hipLaunchKernelGGL(k_resample_crossfix<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, d_cross_taps, ncross, d_in, d_out,
+                                   first, nseams, per);
+            } else {
                 const int64_t total = (int64_t)nseams * per;
                 hipLaunchKernelGGL(k_fir_real_crossfix, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, d_cross_taps, d_in, d_out, first, nseams,
                                    per, gain, ga);

@@ -173,7 +173,7 @@ def test_filter_sse_orders(hip, oracle, order, complex_):
 
 @pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE])
 @pytest.mark.parametrize("complex_", [False, True])
-@pytest.mark.parametrize("I,D,ntaps", [(3, 10, 191), (2, 3, 150), (5, 7, 191), (7, 11, 100), (3, 23, 150), (1, 4, 64), (4, 6, 90)])
+@pytest.mark.parametrize("I,D,ntaps", [(3, 10, 191), (2, 3, 150), (5, 7, 191), (7, 11, 100), (3, 23, 150), (1, 4, 64), (1, 8, 120), (1, 2, 45), (4, 6, 90)])
 def test_resampler_families(hip, oracle, order, complex_, I, D, ntaps):
     w = 2 if complex_ else 1
     x = S.cfloat_block(NBLK * B) if complex_ else S.real_block(NBLK * B)
@@ -190,9 +190,13 @@ def test_resampler_families(hip, oracle, order, complex_, I, D, ntaps):
     is_special = (I, D) == (3, 10) and 185 <= ntaps <= 192
     # real I/D with an odd decimation 3 / 5 / 7 has the thread-per-cycle kernel (kernels_resample_cycle.hip), both lane orders
     is_cycle = not complex_ and D in (3, 5, 7)
-    before, before_cycle = _tiled(hip), hip.lib.sdrhip_debug_resample_cycle_launches()
+    # interpolation 1 and decimation 2 / 4 / 8 / 16: the real decimator's kernel (one polyphase group, the same lane order)
+    is_decim = not complex_ and I == 1 and D in (2, 4, 8, 16)
+    before, before_cycle, before16 = _tiled(hip), hip.lib.sdrhip_debug_resample_cycle_launches(), hip.lib.sdrhip_debug_decimate_real16_launches()
     got = _run(r, to_dev(x), w, K, B, out_block=512)
-    if is_cycle:
+    if is_decim:
+        assert hip.lib.sdrhip_debug_decimate_real16_launches() > before16, "the real decimator's kernel did not take this launch"
+    elif is_cycle:
         assert hip.lib.sdrhip_debug_resample_cycle_launches() > before_cycle, "the thread-per-cycle kernel did not take this launch"
     elif not is_special:
         assert _tiled(hip) > before, "the tiled kernel did not take this launch"
