@@ -237,7 +237,8 @@ int fir_run(const FirDesc* d, hipStream_t s, const void* d_in, bool in_u8, int64
         } else if ((d->lanes == 8 || d->lanes == 4) &&
             launch_fir_real8_fast(s, g, d->sym, d->d_taps, d->ntaps_kernel, d->d_cross, (const float*)d_in, d_out, gain, gain != 1.0f, d->lanes)) {
             // LDS-tiled kernel took it (gain fused): AVX order, and the SSE order when the tap count is a multiple of 8
-        } else if (!d->sym && launch_decimate_real16_fast(s, g, d->lanes, d->d_plain, d->Lp, d->d_cross, (const float*)d_in, d_out, gain, gain != 1.0f)) {
+        } else if (launch_decimate_real16_fast(s, g, d->lanes, d->sym ? d->d_taps : d->d_plain, d->sym ? d->ntaps_kernel : d->Lp, d->d_cross,
+                                               (const float*)d_in, d_out, gain, gain != 1.0f, 0, d->sym)) {
             // real decimator by 2 / 4 / 8 / 16: 16 / D outputs per thread, scalar-loaded taps (gain fused)
         } else if (launch_fir_split(s, g, false, d->lanes, CO_SEQ, d->sym, d->sym ? d->d_taps : d->d_plain,
                                     d->sym ? d->ntaps_kernel : d->Lp, d->d_cross, (const float*)d_in, d_out, gain, gain != 1.0f)) {

@@ -124,11 +124,12 @@ bool launch_resample_split(hipStream_t s, const Geom& g, bool cplx, int lanes, C
 
 long long split_launch_count();   // diagnostics: launches the lane-split kernels have taken so far
 
-// kernels_decimate_real.hip: real decimators by 2 / 4 / 8 / 16 (not symmetric), AVX / SSE lane order, up to 2048 taps: 16 / D
+// kernels_decimate_real.hip: real decimators by 2 / 4 / 8 / 16, AVX / SSE lane order, up to 2048 taps (sym: d_taps = nk half-taps,
+// a multiple of 8, g.Lp = 2 nk): 16 / D
 // outputs per thread, scalar-loaded taps, rolled walk.  False = not this kernel's shape.
 // ncross: taps of the sequential (Cross) outputs when they are not the g.Lp padded ones (a resampler with interpolation 1)
 bool launch_decimate_real16_fast(hipStream_t s, const Geom& g, int lanes, const float* d_taps, int nk, const float* d_cross_taps, const float* d_in,
-                                 float* d_out, float gain, bool apply_gain, int ncross = 0);
+                                 float* d_out, float gain, bool apply_gain, int ncross = 0, bool sym = false);
 long long decimate_real16_launch_count();
 // kernels_resample_cycle.hip: real resamplers I/D with an odd decimation (I <= 6, D in {3,5,7}), any filter length up to
 // 1024 taps per group, AVX / SSE lane order: one thread per polyphase cycle, rolled walk with taps from LDS.  False = not

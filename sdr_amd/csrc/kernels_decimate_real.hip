@@ -28,6 +28,35 @@ struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
 // LDS position of float k of a window / of the tile: four floats of padding after every 16
 __host__ __device__ constexpr int dr_idx(int k) { return k + 4 * (k / 16); }
 
+// stage span4 16-byte vectors from src (4-byte aligned; `avail` floats exist) into the padded tile: all of a thread's global loads
+// in flight before the first wait
+__device__ __forceinline__ void dr_stage_tile(const float* __restrict__ src, int64_t avail, int span4, int tid, float* __restrict__ dr_lds)
+{
+    float4 val[DR_NV];
+#pragma unroll
+    for (int i = 0; i < DR_NV; i++) {
+        const int v = tid + i * DR_NT;
+        float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (v < span4) {
+            const int64_t s = 4 * (int64_t)v;
+            if (s + 3 < avail) {
+                const f4u u = *reinterpret_cast<const f4u*>(src + s);
+                q = make_float4(u.x, u.y, u.z, u.w);
+            } else {
+                if (s + 0 < avail) q.x = src[s + 0];
+                if (s + 1 < avail) q.y = src[s + 1];
+                if (s + 2 < avail) q.z = src[s + 2];
+            }
+        }
+        val[i] = q;
+    }
+#pragma unroll
+    for (int i = 0; i < DR_NV; i++) {
+        const int v = tid + i * DR_NT;
+        if (v < span4) *reinterpret_cast<float4*>(&dr_lds[4 * v + 4 * (v / 4)]) = val[i];
+    }
+}
+
 template <int D, int L, bool RINGED>
 __global__ void __launch_bounds__(DR_NT) k_decimate_real16(const float* __restrict__ in, int64_t pos0, int count, int64_t avail_total,
                                                             const float* __restrict__ taps, int nloop, float gain, int apply_gain,
@@ -42,33 +71,7 @@ __global__ void __launch_bounds__(DR_NT) k_decimate_real16(const float* __restri
     const int t0 = blockIdx.x * DR_NT;                                // first thread-chunk of the tile
     const int span = (DR_NT - 1) * 16 + A + nloop + 16;               // floats the tile reads (the window runs one step ahead)
     const int span4 = (span + 3) / 4;
-    const float* src = in + pos0 + (int64_t)t0 * 16;
-    const int64_t avail = avail_total - (int64_t)t0 * 16;             // floats that exist from src on
-    {
-        float4 val[DR_NV];
-#pragma unroll
-        for (int i = 0; i < DR_NV; i++) {
-            const int v = tid + i * DR_NT;
-            float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (v < span4) {
-                const int64_t s = 4 * (int64_t)v;
-                if (s + 3 < avail) {
-                    const f4u u = *reinterpret_cast<const f4u*>(src + s);
-                    q = make_float4(u.x, u.y, u.z, u.w);
-                } else {
-                    if (s + 0 < avail) q.x = src[s + 0];
-                    if (s + 1 < avail) q.y = src[s + 1];
-                    if (s + 2 < avail) q.z = src[s + 2];
-                }
-            }
-            val[i] = q;
-        }
-#pragma unroll
-        for (int i = 0; i < DR_NV; i++) {
-            const int v = tid + i * DR_NT;
-            if (v < span4) *reinterpret_cast<float4*>(&dr_lds[4 * v + 4 * (v / 4)]) = val[i];
-        }
-    }
+    dr_stage_tile(in + pos0 + (int64_t)t0 * 16, avail_total - (int64_t)t0 * 16, span4, tid, dr_lds);
     __syncthreads();
     const int64_t m0 = (int64_t)(t0 + tid) * R;                       // first output of the thread, relative to the launch
     if (m0 >= count) return;
@@ -179,6 +182,103 @@ __global__ void __launch_bounds__(DR_NT) k_decimate_real16(const float* __restri
         if (m0 + r < count) o[r] = res[r];
 }
 
+
+// The symmetric form (decimateAVXSymmetricRR / decimateSSESymmetricRR, decimate.c:53-83 -> avx_sym_dotprod_R, common.h:58-72):
+// half-tap j multiplies x[j] + x[2N-1-j] -- the pair is added first, then multiplied, then accumulated in lane j % L.  A second
+// register window slides DOWN from the far end of the thread's window; nhalf a multiple of 8, so that it starts on a 16-float
+// granule and the tile's padding sits at fixed offsets for it as well.
+template <int D, int L>
+__global__ void __launch_bounds__(DR_NT) k_decimate_real16_sym(const float* __restrict__ in, int64_t pos0, int count, int64_t avail_total,
+                                                                const float* __restrict__ taps, int nhalf, float gain, int apply_gain,
+                                                                float* __restrict__ out)
+{
+    static_assert(D == 2 || D == 4 || D == 8 || D == 16, "a thread's outputs span 16 inputs");
+    static_assert(L == 8 || L == 4, "AVX or SSE lane count");
+    constexpr int R = 16 / D, PM = (R - 1) * D;
+    constexpr int A = (PM + 3) / 4 * 4 + 16;
+    extern __shared__ __attribute__((aligned(16))) float dr_lds[];
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * DR_NT;
+    const int span = (DR_NT - 1) * 16 + A + 2 * nhalf + 16;
+    const int span4 = (span + 3) / 4;
+    dr_stage_tile(in + pos0 + (int64_t)t0 * 16, avail_total - (int64_t)t0 * 16, span4, tid, dr_lds);
+    __syncthreads();
+    const int64_t m0 = (int64_t)(t0 + tid) * R;
+    if (m0 >= count) return;
+    const float* wp = dr_lds + tid * 20;
+    float acc[R][L];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int l = 0; l < L; l++) acc[r][l] = 0.0f;
+    // forward window: w[k] = x[j0 + k]; backward window: wb[16 + k] = x[kb + k], kb = 2 nhalf - 16 - j0 (wb[0 .. 16): the next
+    // step's, sixteen floats further down)
+    float w[A + 16], wb[A + 16];
+    const float* wbp = wp + 20 * ((2 * nhalf - 16) >> 4);             // (2 nhalf - 16 is a multiple of 16)
+#pragma unroll
+    for (int q = 0; q < A / 4; q++) {
+        const float4 v = *reinterpret_cast<const float4*>(wp + dr_idx(4 * q));
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        const float4 u = *reinterpret_cast<const float4*>(wbp + dr_idx(4 * q));
+        wb[16 + 4 * q] = u.x; wb[16 + 4 * q + 1] = u.y; wb[16 + 4 * q + 2] = u.z; wb[16 + 4 * q + 3] = u.w;
+    }
+    float c[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) c[i] = 0.0f;
+    if (nhalf >= 16) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) c[i] = taps[i];
+    }
+    int j0 = 0;
+#pragma unroll 1
+    for (; j0 + 16 <= nhalf; j0 += 16) {
+        const float* wn = wp + 20 * (j0 >> 4);
+        const float* wbn = wbp - 20 * ((j0 >> 4) + 1);               // sixteen floats below the backward window (>= the thread's
+                                                                    // own window start: j0 + 16 <= nhalf)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v = *reinterpret_cast<const float4*>(wn + dr_idx(A + 4 * q));
+            w[A + 4 * q] = v.x; w[A + 4 * q + 1] = v.y; w[A + 4 * q + 2] = v.z; w[A + 4 * q + 3] = v.w;
+            const float4 u = *reinterpret_cast<const float4*>(wbn + 4 * q);
+            wb[4 * q] = u.x; wb[4 * q + 1] = u.y; wb[4 * q + 2] = u.z; wb[4 * q + 3] = u.w;
+        }
+        float cn[16];
+        const float* tn = taps + (j0 + 32 <= nhalf ? j0 + 16 : j0);
+#pragma unroll
+        for (int i = 0; i < 16; i++) cn[i] = tn[i];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[r][i % L] = acc[r][i % L] + (w[r * D + i] + wb[16 + r * D + 15 - i]) * c[i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) c[i] = cn[i];
+#pragma unroll
+        for (int k = 0; k < A; k++) w[k] = w[k + 16];
+#pragma unroll
+        for (int k = A + 15; k >= 16; k--) wb[k] = wb[k - 16];
+    }
+    // the last 8 half-taps (nhalf is a multiple of 8, 16 need not divide it)
+#pragma unroll
+    for (int q = 0; q < 16; q += L) {
+        if (j0 + q < nhalf) {
+            const float* tq = taps + j0 + q;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int i = 0; i < L; i++) acc[r][i] = acc[r][i] + (w[r * D + q + i] + wb[16 + r * D + 15 - (q + i)]) * tq[i];
+        }
+    }
+    float* o = out + m0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        float res;
+        if constexpr (L == 8) res = ((acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3])) + ((acc[r][4] + acc[r][5]) + (acc[r][6] + acc[r][7]));
+        else res = (acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]);
+        if (apply_gain) res = res * gain;
+        if (m0 + r < count) o[r] = res;
+    }
+}
+
 std::atomic<long long> g_decreal_launches{0};
 
 template <int D, int L, bool RINGED>
@@ -199,17 +299,37 @@ bool launch_dr(hipStream_t s, const Geom& g, const float* d_taps, int nk, const 
     return true;
 }
 
+
+template <int D, int L>
+bool launch_dr_sym(hipStream_t s, const Geom& g, const float* d_half, int nhalf, const float* d_in, float* d_out, float gain, bool apply_gain)
+{
+    constexpr int R = 16 / D, PM = (R - 1) * D, A = (PM + 3) / 4 * 4 + 16;
+    const int span = (DR_NT - 1) * 16 + A + 2 * nhalf + 16;
+    const int span4 = (span + 3) / 4;
+    if (span4 > DR_NV * DR_NT) return false;
+    const size_t lds_bytes = (size_t)(4 * span4 + 4 * (span4 / 4) + 8) * sizeof(float);
+    if (lds_bytes > 60 * 1024) return false;
+    const int64_t pos0 = g.k_begin * g.D - g.in_base;
+    const int64_t avail_total = (int64_t)(g.count - 1) * D + 2 * nhalf;
+    const int threads = (g.count + R - 1) / R;
+    hipLaunchKernelGGL((k_decimate_real16_sym<D, L>), dim3((threads + DR_NT - 1) / DR_NT), dim3(DR_NT), lds_bytes, s, d_in, pos0, g.count, avail_total,
+                       d_half, nhalf, gain, apply_gain ? 1 : 0, d_out);
+    g_decreal_launches++;
+    return true;
+}
+
 }  // namespace
 
 long long decimate_real16_launch_count() { return g_decreal_launches.load(); }
 
 bool launch_decimate_real16_fast(hipStream_t s, const Geom& g, int lanes, const float* d_taps, int nk, const float* d_cross_taps, const float* d_in,
-                                 float* d_out, float gain, bool apply_gain, int ncross)
+                                 float* d_out, float gain, bool apply_gain, int ncross, bool sym)
 {
     if (ncross <= 0) ncross = g.Lp;              // taps the sequential (Cross) outputs walk: a resampler's are the unpadded ones
     static const bool off = getenv("SDRHIP_DECIM_REAL16") != nullptr && atoi(getenv("SDRHIP_DECIM_REAL16")) == 0;     // A/B: the split kernel
     if (off || g.I != 1 || g.seamBI < 0 || g.count < 4096) return false;
-    if (!(lanes == 8 || lanes == 4) || nk < 8 || nk % lanes != 0 || nk > 2048 || nk != g.Lp) return false;
+    if (!(lanes == 8 || lanes == 4) || nk < 8 || nk > 2048) return false;
+    if (sym ? (nk % 8 != 0 || 2 * nk != g.Lp) : (nk % lanes != 0 || nk != g.Lp)) return false;     // sym: nk = half-taps
     if (g.seamBI != 0 && d_cross_taps == nullptr) return false;
     bool took = false;
     static const int ring_env = getenv("SDRHIP_DR_RING") ? atoi(getenv("SDRHIP_DR_RING")) : -1;                     // A/B: -1 = the default per shape
@@ -221,7 +341,11 @@ bool launch_decimate_real16_fast(hipStream_t s, const Geom& g, int lanes, const 
         else took = ring ? launch_dr<DV, 4, true>(s, g, d_taps, nk, d_in, d_out, gain, apply_gain)                  \
                          : launch_dr<DV, 4, false>(s, g, d_taps, nk, d_in, d_out, gain, apply_gain);                \
     }
-    DR(2, false); DR(4, false); DR(8, false); DR(16, true);
+#define DRS(DV) if (g.D == DV) took = lanes == 8 ? launch_dr_sym<DV, 8>(s, g, d_taps, nk, d_in, d_out, gain, apply_gain) \
+                                                : launch_dr_sym<DV, 4>(s, g, d_taps, nk, d_in, d_out, gain, apply_gain)
+    if (sym) { DRS(2); DRS(4); DRS(8); DRS(16); }
+    else { DR(2, false); DR(4, false); DR(8, false); DR(16, true); }
+#undef DRS
 #undef DR
     if (!took) return false;
     if (g.seamBI != 0) {

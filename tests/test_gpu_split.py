@@ -126,11 +126,43 @@ def test_real_decimator16(hip, oracle, order, factor, ntaps):
 
 
 @pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE])
+@pytest.mark.parametrize("factor", [2, 4, 8, 16])
+@pytest.mark.parametrize("nhalf", [8, 16, 24, 64, 200])
+def test_real_decimator16_symmetric(hip, oracle, order, factor, nhalf):
+    """The symmetric form of kernels_decimate_real.hip (decimateAVXSymmetricRR / decimateSSESymmetricRR, decimate.c:53-83): the
+    pair x[j] + x[2N-1-j] is added first; filters of one half step, whole steps and steps + 8, launches cut at odd outputs,
+    with and without seams, unaligned input."""
+    if 2 * nhalf <= factor:
+        pytest.skip("the reference's Pipe asserts on a filter no longer than the decimation")
+    x = S.real_block(NBLK * B)
+    half = S.gauss_taps(nhalf, 11 * factor + nhalf)
+    model = PM.FilterModel(oracle, half, order, sym=True, factor=factor)
+    blocks, _ = PM.fir_decimator_pipe(model, _split(x, 1, B), 1024)
+    exp = np.concatenate(blocks)
+    K = exp.size
+    d = hip.Decimator(factor, half, order, sym=True)
+    before = hip.lib.sdrhip_debug_decimate_real16_launches()
+    got = _run(d, to_dev(x), 1, K, B)
+    assert hip.lib.sdrhip_debug_decimate_real16_launches() > before, "the real decimator's own kernel did not take this launch"
+    assert_bit_equal(got, exp, f"sym /{factor}, {nhalf} half-taps: one launch")
+    got = _run(d, to_dev(x), 1, K, B, cuts=[4097, 4097 + 4099, 4097 + 4099 + 4101, K - 4103])
+    assert_bit_equal(got, exp, f"sym /{factor}, {nhalf} half-taps: cut into launches")
+    model1 = PM.FilterModel(oracle, half, order, sym=True, factor=factor)
+    exp1 = model1.one((x.size - 3 - 2 * nhalf) // factor + 1, x[3:])
+    dx = to_dev(x)
+    out = dev_empty_f32(exp1.size)
+    d.run(ptr(dx) + 12, 0, ptr(out), 0, exp1.size, 0)
+    assert_bit_equal(to_host(out), exp1, f"sym /{factor}, {nhalf} half-taps: no seams, unaligned input")
+
+
+@pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE])
 @pytest.mark.parametrize("factor,nhalf", [(1, 32), (2, 64), (4, 24), (8, 64)])
 def test_symmetric_real_families(hip, oracle, order, factor, nhalf):
     # symmetric FILTERS with a multiple of 8 half-taps have their own kernel (k_fir_real8_fast: AVX order, and since round 3 the
     # SSE order with four lane partials); they are still compared here, only the "general tiled kernel ran" assertion is dropped
     own_kernel = factor == 1 and nhalf % 8 == 0
+    # symmetric DECIMATORS by 2 / 4 / 8 / 16 with a multiple of 8 half-taps: kernels_decimate_real.hip (round 3)
+    own_kernel = own_kernel or (factor in (2, 4, 8, 16) and nhalf % 8 == 0)
     if order == PM.ORDER_AVX and factor == 1:
         pytest.skip("the AVX symmetric filter has its own kernel (k_fir_real8_fast)")
     x = S.real_block(NBLK * B)

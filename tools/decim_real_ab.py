@@ -29,5 +29,23 @@ def main():
                   f"{m / t / 1e9:7.1f} G inputs/s  {K * d.num_coeffs / t / 1e12:6.2f} T MAC/s  {'own kernel' if took else 'other kernel'}")
 
 
+def sym():
+    st = torch.cuda.current_stream().cuda_stream
+    n = 1 << 26
+    xr = torch.rand(n + 4096, device="cuda") * 2 - 1
+    out = torch.empty(n // 2 + 4096, device="cuda")
+    for D, nh, order in ((2, 64, L.ORDER_AVX), (2, 64, L.ORDER_SSE), (4, 64, L.ORDER_AVX), (8, 64, L.ORDER_AVX), (8, 200, L.ORDER_AVX), (16, 64, L.ORDER_AVX)):
+        m = n if D >= 8 else n // 4
+        d = L.Decimator(D, S.gauss_taps(nh, nh + D), order, sym=True)
+        K = (m - 2 * nh) // D + 1
+        for seam in (8192, 0):
+            c0 = L.lib.sdrhip_debug_decimate_real16_launches()
+            t = timeit(lambda: d.run(xr.data_ptr(), 0, out.data_ptr(), 0, K, seam, stream=st))
+            took = L.lib.sdrhip_debug_decimate_real16_launches() > c0
+            print(f"decimate /{D} {nh} half-taps symmetric real [{'AVX' if order == L.ORDER_AVX else 'SSE'}] seam {seam:5d}: "
+                  f"{m / t / 1e9:7.1f} G inputs/s  {K * nh / t / 1e12:6.2f} T sym-MAC/s  {'own kernel' if took else 'other kernel'}")
+
+
 if __name__ == "__main__":
+    sym()
     main()
