@@ -81,6 +81,10 @@ foreign import ccall safe "sdrhip_fm_stream_set_coalesce" c_stream_set_coalesce 
 -- adaptive submission (on by default: pushes that arrive while the GPU is busy share a launch); 0 switches it off
 foreign import ccall safe "sdrhip_pipe_set_adaptive"   c_pipe_set_adaptive :: Ptr SdrPipe -> CInt -> IO CInt
 foreign import ccall safe "sdrhip_fm_stream_set_adaptive" c_stream_set_adaptive :: Ptr SdrStream -> CInt -> IO CInt
+-- blocks ready to pop after collecting (without waiting) what the GPU has finished: for consumers that want the audio of the
+-- block they just pushed before the next one arrives
+foreign import ccall unsafe "sdrhip_pipe_poll"      c_pipe_poll   :: Ptr SdrPipe -> IO CInt
+foreign import ccall unsafe "sdrhip_fm_stream_poll" c_stream_poll :: Ptr SdrStream -> IO CInt
 foreign import ccall safe "sdrhip_fm_chain_create"     c_chain_create      :: Ptr (Ptr SdrChain) -> CInt -> CInt -> Ptr CFloat -> CInt -> CInt -> CInt -> Ptr CFloat -> CInt -> Ptr CFloat -> CInt -> CFloat -> Int64 -> IO CInt
 foreign import ccall safe "sdrhip_fm_stream_create"    c_stream_create     :: Ptr (Ptr SdrStream) -> Ptr SdrChain -> CInt -> CInt -> IO CInt
 foreign import ccall safe "sdrhip_fm_stream_push"      c_stream_push       :: Ptr SdrStream -> Ptr CUChar -> CInt -> IO CInt

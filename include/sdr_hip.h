@@ -424,6 +424,10 @@ int sdrhip_fm_stream_push(sdrhip_fm_stream *st, const uint8_t *iq, int n_samples
  * max_block_samples more.) */
 uint8_t *sdrhip_fm_stream_input_buffer(sdrhip_fm_stream *st);
 int sdrhip_fm_stream_flush(sdrhip_fm_stream *st);
+/* Audio blocks ready to pop, after collecting (without waiting) every in-flight submission the GPU has finished: lets a
+ * real-time caller fetch the audio of the push it just made some tens of microseconds later instead of at its next push
+ * (pushes themselves collect finished work too; flush waits for all of it). */
+int sdrhip_fm_stream_poll(sdrhip_fm_stream *st);
 /* Latency / throughput knob: stage pushes in the pinned buffer and submit them to the GPU together once
  * `samples` samples (a multiple of the chain's block; 0 = every push, the default) have accumulated, or on
  * flush.  One 8192-sample push costs ~8-9 us (one kernel launch, four pushes in flight) whatever its size, so a caller
@@ -513,6 +517,8 @@ int sdrhip_pipe_set_coalesce(sdrhip_pipe *p, int blocks);
 int sdrhip_pipe_set_adaptive(sdrhip_pipe *p, int max_blocks);
 float *sdrhip_pipe_input_buffer(sdrhip_pipe *p, int n);
 int sdrhip_pipe_flush(sdrhip_pipe *p);
+/* output blocks ready to pop, after collecting (without waiting) every in-flight submission the GPU has finished */
+int sdrhip_pipe_poll(sdrhip_pipe *p);
 /* Pop one ready block into out (capacity in elements); returns its length, 0 if none. */
 int sdrhip_pipe_pop(sdrhip_pipe *p, float *out, int capacity);
 /* Checkpoint / resume, as sdrhip_fm_stream_save / _restore: save drains the pipe (like flush) and writes its state -- position,

@@ -669,6 +669,19 @@ struct sdrhip_fm_stream {
             if (st) (void)hipStreamDestroy(st);
     }
     int ready() const { return (int)((fifo.size() - head) / (size_t)block_out); }
+    // harvest, oldest first, every in-flight submission the GPU has finished (never waits)
+    int harvest_done()
+    {
+        for (int64_t k = pushes - (nslots - 1); k < pushes; k++) {
+            if (k < 0) continue;
+            const int si = (int)(k % nslots);
+            if (!slot[si].busy) continue;
+            if (hipEventQuery(slot[si].ev) != hipSuccess) break;     // still running (an error surfaces in the blocking harvest)
+            int rc = harvest(si);
+            if (rc != SDRHIP_OK) return rc;
+        }
+        return SDRHIP_OK;
+    }
     uint8_t* staged_base(Slot& sl) const { return (uint8_t*)sl.hin.p + 2 * head_cap; }    // where staged sample 0 lives
     int harvest(int si)
     {
@@ -891,7 +904,20 @@ int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
         const bool room = st->staged + st->max_block <= st->capacity();
         submit = !room || !st->in_flight((st->cur() + 1) % st->nslots);
     }
-    if (submit && (rc = stream_submit(st)) != SDRHIP_OK) return rc;
+    if (submit) {
+        if ((rc = stream_submit(st)) != SDRHIP_OK) return rc;
+        // a push that went out also collects whatever the GPU has finished meanwhile: a source slower than the GPU gets the
+        // audio of push i at push i + 1 instead of i + nslots - 1 (staged pushes skip the query)
+        if ((rc = st->harvest_done()) != SDRHIP_OK) return rc;
+    }
+    return st->ready();
+}
+
+int sdrhip_fm_stream_poll(sdrhip_fm_stream* st)
+{
+    SDRHIP_REQUIRE(st != nullptr, "sdrhip_fm_stream_poll");
+    int rc = st->harvest_done();
+    if (rc != SDRHIP_OK) return rc;
     return st->ready();
 }
 

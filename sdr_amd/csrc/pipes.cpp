@@ -172,6 +172,20 @@ static int harvest(sdrhip_pipe* p, int si)
     return SDRHIP_OK;
 }
 
+// harvest, oldest first, every in-flight submission the GPU has finished (never waits)
+static int harvest_done(sdrhip_pipe* p)
+{
+    for (int64_t k = p->pushes - (p->nslots - 1); k < p->pushes; k++) {
+        if (k < 0) continue;
+        const int si = (int)(k % p->nslots);
+        if (!p->slot[si].busy) continue;
+        if (hipEventQuery(p->slot[si].ev) != hipSuccess) break;      // still running (an error surfaces in the blocking harvest)
+        int rc = harvest(p, si);
+        if (rc != SDRHIP_OK) return rc;
+    }
+    return SDRHIP_OK;
+}
+
 static int ready_blocks(const sdrhip_pipe* p)
 {
     if (p->is_map()) {
@@ -389,6 +403,7 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
     if (!still_in_place) memcpy(dst, block, (size_t)n * ein);   // else: the caller filled the staging buffer in place
     p->lent = 0;
     p->staged += n;
+    const int64_t pushes_before = p->pushes;
     if (!coalescing) {
         // equal-sized blocks from the start: the seams are the multiples of that size and one run covers Cross and One
         // outputs alike; otherwise (ragged blocks) the two-part submission
@@ -399,6 +414,9 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
         // to lets the blocks pile up in the staging buffer and takes them as one launch when it frees up)
         if ((rc = fir_submit(p, p->staged, p->uniform_n)) != SDRHIP_OK) return rc;
     }
+    // a push that went out also collects whatever the GPU has finished meanwhile (a source slower than the GPU gets the
+    // results of push i at push i + 1 instead of i + nslots - 1); staged pushes skip the query
+    if (p->pushes != pushes_before && (rc = harvest_done(p)) != SDRHIP_OK) return rc;
     return ready_blocks(p);
 }
 
@@ -521,6 +539,7 @@ int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
         p->demod_blocks.push_back(n);
         p->pushes++;
         if ((rc = harvest(p, p->cur_slot())) != SDRHIP_OK) return rc;
+        if ((rc = harvest_done(p)) != SDRHIP_OK) return rc;
         return ready_blocks(p);
     }
 
@@ -562,6 +581,14 @@ float* sdrhip_pipe_input_buffer(sdrhip_pipe* p, int n)
     if (fir_open_slot(p, (size_t)(cap > p->staged + n ? cap : p->staged + n)) != SDRHIP_OK) return nullptr;
     p->lent = n;
     return p->staged_base(p->slot[p->cur_slot()]) + (size_t)p->staged * p->esz_in();
+}
+
+int sdrhip_pipe_poll(sdrhip_pipe* p)
+{
+    SDRHIP_REQUIRE(p != nullptr, "sdrhip_pipe_poll");
+    int rc = harvest_done(p);
+    if (rc != SDRHIP_OK) return rc;
+    return ready_blocks(p);
 }
 
 int sdrhip_pipe_flush(sdrhip_pipe* p)

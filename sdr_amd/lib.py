@@ -178,6 +178,7 @@ lib.sdrhip_fm_stream_destroy.argtypes = [_vp]
 lib.sdrhip_fm_stream_destroy.restype = None
 lib.sdrhip_fm_stream_push.argtypes = [_vp, _u8p, C.c_int]
 lib.sdrhip_fm_stream_flush.argtypes = [_vp]
+lib.sdrhip_fm_stream_poll.argtypes = [_vp]
 lib.sdrhip_fm_stream_set_coalesce.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_stream_set_adaptive.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_stream_input_buffer.argtypes = [_vp]
@@ -195,6 +196,7 @@ lib.sdrhip_pipe_input_buffer.argtypes = [_vp, C.c_int]
 lib.sdrhip_pipe_input_buffer.restype = _vp
 lib.sdrhip_pipe_push.argtypes = [_vp, _f32p, C.c_int]
 lib.sdrhip_pipe_flush.argtypes = [_vp]
+lib.sdrhip_pipe_poll.argtypes = [_vp]
 lib.sdrhip_pipe_pop.argtypes = [_vp, _f32p, C.c_int]
 lib.sdrhip_pipe_destroy.argtypes = [_vp]
 lib.sdrhip_pipe_destroy.restype = None
@@ -608,6 +610,10 @@ class FmStream(_Handle):
     def flush(self):
         return self._pop(check(lib.sdrhip_fm_stream_flush(self.h), "sdrhip_fm_stream_flush"))
 
+    def poll(self):
+        """blocks the GPU has finished meanwhile (never waits)"""
+        return self._pop(check(lib.sdrhip_fm_stream_poll(self.h), "sdrhip_fm_stream_poll"))
+
     def save(self):
         """sdrhip_fm_stream_save: drains the operator and returns its state as bytes (audio blocks that became ready stay
         inside the state / the stream: pop them from either)."""
@@ -673,6 +679,10 @@ class Pipe(_Handle):
     def flush(self):
         ready = check(lib.sdrhip_pipe_flush(self.h), "sdrhip_pipe_flush")
         return self._pop(ready)
+
+    def poll(self):
+        """blocks the GPU has finished meanwhile (never waits)"""
+        return self._pop(check(lib.sdrhip_pipe_poll(self.h), "sdrhip_pipe_poll"))
 
     def save(self):
         """sdrhip_pipe_save: drains the pipe and returns its state as bytes (blocks that became ready stay poppable)."""

@@ -260,6 +260,34 @@ def test_fm_stream_adaptive(hip, oracle, cap_blocks):
         st.set_adaptive(4 * B)                     # staged now: refuse
 
 
+def test_fm_stream_poll_delivers_a_push_without_another_push(hip, oracle):
+    """A real-time caller: push one source block, poll a little later -- the audio that push completed is there, no further
+    push and no flush needed (sdrhip_fm_stream_poll); the block sequence is the resident run's."""
+    import time
+    nblk = 100
+    u8 = S.iq_u8_fm(nblk * B)
+    exp = _model(oracle, u8, nblk)
+    chain = _chain(hip)
+    st = hip.FmStream(chain, B, 512)
+    got, late = [], 0
+    for i in range(nblk):
+        got += st.push(u8[2 * i * B: 2 * (i + 1) * B])
+        have = sum(len(b) for b in got)
+        # the audio outputs whose last input sample has arrived: chain.ready(N)
+        want = (chain.ready((i + 1) * B) // 512) * 512
+        deadline = time.time() + 2.0
+        while have < want and time.time() < deadline:
+            got += st.poll()
+            have = sum(len(b) for b in got)
+        late += have < want
+    assert late == 0, "poll did not deliver the audio of a finished push"
+    got += st.flush()
+    got = np.concatenate(got)
+    m = min(got.size, exp.size)
+    assert exp.size >= 16384 and m == exp.size
+    assert_bit_equal(got[:m], exp[:m], "polled stream")
+
+
 def test_chain_random_sweep(hip, oracle):
     """Seeded random receivers (decimation, tap counts, resampling ratio, gain, source block size, SIMD order): the
     device-resident chain in one launch, the same chain sharded in three, and the host-block stream operator all give the
