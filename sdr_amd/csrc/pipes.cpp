@@ -497,55 +497,97 @@ int sdrhip_pipe_dc_blocker(sdrhip_pipe** pp)
     return SDRHIP_OK;
 }
 
-int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
+// ---- map stages (fmDemod, dcBlockingFilter): one output vector per input vector --------------------------------------
+// Blocks are staged one behind the other in the slot's pinned buffer and go out as ONE run over all of them -- the carry of a
+// block is its predecessor's last sample (fmDemod, Demod.hs:41,46) / the filter's running pair kept on the device
+// (dcBlockingFilter, Filter.hs:730-739), which is exactly what a run over the concatenation computes; the block lengths are
+// remembered for the pops.  Submission is adaptive as for the FIR-like stages.  Runs of up to kDirectBytes read and write
+// pinned memory in place; larger ones go through the copy engines.
+static int map_submit(sdrhip_pipe* p)
 {
-    SDRHIP_REQUIRE(p != nullptr && block != nullptr && n > 0, "sdrhip_pipe_push");
-    if (!p->is_map()) return fir_like_push(p, block, n);
+    const int n = p->staged;
+    if (n == 0) return SDRHIP_OK;
     const int si = p->cur_slot();
     sdrhip_pipe::Slot& sl = p->slot[si];
     int rc;
-    // slot si was last used by push i - nslots and harvested during push i-1
-    if ((rc = harvest(p, si)) != SDRHIP_OK) return rc;
-
     const size_t ein = (size_t)p->esz_in() * 4, eout = (size_t)p->esz_out() * 4;
-    if ((rc = sl.hin.ensure((size_t)n * ein)) != SDRHIP_OK) return rc;
-    memcpy(sl.hin.p, block, (size_t)n * ein);
-
-    if (p->is_map()) {
-        // fmDemodVec last dat (Demod.hs:32-36,43-46) / dcBlockingFilter (Filter.hs:730-739): one output vector per input vector
-        DevBuf& d = p->din[si];              // last read by the kernels of push i - nslots, harvested above
+    if ((rc = sl.hout.ensure((size_t)n * eout)) != SDRHIP_OK) return rc;
+    // (dcBlockingFilter never in place: its lanes re-read their run-in and a short block is one lane's dependent loads)
+    const bool direct = p->direct_ok && p->kind == PK_DEMOD && (size_t)n * ein <= sdrhip_pipe::kDirectBytes;
+    const float* d_in;
+    float* d_out;
+    if (direct) {
+        d_in = (const float*)sl.hin.dev;
+        d_out = (float*)sl.hout.dev;
+    } else {
+        DevBuf& d = p->din[si];              // last read by the kernels of submission i - nslots, harvested when the slot was opened
         if ((rc = d.ensure((size_t)n * ein)) != SDRHIP_OK) return rc;
         if ((rc = sl.dout.ensure((size_t)n * eout)) != SDRHIP_OK) return rc;
-        if ((rc = sl.hout.ensure((size_t)n * eout)) != SDRHIP_OK) return rc;
         SDRHIP_CHECK_HIP(hipMemcpyAsync(d.p, sl.hin.p, (size_t)n * ein, hipMemcpyHostToDevice, p->up));
         SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_up, p->up));
         SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->stream, sl.ev_up, 0));
-        if (p->kind == PK_DEMOD) {
-            launch_fm_demod_fast(p->stream, (const float*)d.p, (float*)sl.dout.p, n, false, p->last_re, p->last_im);
-            p->last_re = block[2 * (n - 1)];
-            p->last_im = block[2 * (n - 1) + 1];
-        } else {
-            if ((rc = p->dc_ws.ensure(dc_blocker_workspace_bytes(n))) != SDRHIP_OK) return rc;
-            launch_dc_blocker(p->stream, n, 0.0f, 0.0f, (const float*)d.p, (float*)sl.dout.p, (float*)p->dc_state.p, p->dc_ws.p, 0,
-                              (const float*)p->dc_state.p);
-        }
-        SDRHIP_CHECK_HIP(hipGetLastError());
+        d_in = (const float*)d.p;
+        d_out = (float*)sl.dout.p;
+    }
+    if (p->kind == PK_DEMOD) {
+        launch_fm_demod_fast(p->stream, d_in, d_out, n, false, p->last_re, p->last_im);
+        const float* h = (const float*)sl.hin.p;
+        p->last_re = h[2 * (size_t)(n - 1)];
+        p->last_im = h[2 * (size_t)(n - 1) + 1];
+    } else {
+        if (dc_blocker_workspace_bytes(n) > p->dc_ws.cap) SDRHIP_CHECK_HIP(hipStreamSynchronize(p->stream));     // growing frees the old buffer
+        if ((rc = p->dc_ws.ensure(dc_blocker_workspace_bytes(n))) != SDRHIP_OK) return rc;
+        launch_dc_blocker(p->stream, n, 0.0f, 0.0f, d_in, d_out, (float*)p->dc_state.p, p->dc_ws.p, 0, (const float*)p->dc_state.p);
+    }
+    SDRHIP_CHECK_HIP(hipGetLastError());
+    if (direct) {
+        SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, p->stream));           // results in pinned memory, staging buffer free again
+    } else {
         SDRHIP_CHECK_HIP(hipEventRecord(sl.ev_k, p->stream));
         SDRHIP_CHECK_HIP(hipStreamWaitEvent(p->down, sl.ev_k, 0));
         SDRHIP_CHECK_HIP(hipMemcpyAsync(sl.hout.p, sl.dout.p, (size_t)n * eout, hipMemcpyDeviceToHost, p->down));
         SDRHIP_CHECK_HIP(hipEventRecord(sl.ev, p->down));
-        sl.n_out = n;
-        sl.busy = true;
-        p->demod_blocks.push_back(n);
-        p->pushes++;
-        if ((rc = harvest(p, p->cur_slot())) != SDRHIP_OK) return rc;
-        if ((rc = harvest_done(p)) != SDRHIP_OK) return rc;
-        return ready_blocks(p);
     }
+    sl.direct = direct;
+    sl.n_out = (int64_t)n * p->esz_out();
+    sl.busy = true;
+    p->staged = 0;
+    p->pushes++;
+    return harvest(p, p->cur_slot());      // the oldest submission: its slot is the next to be filled
+}
 
-    // ---- FIR-like stages --------------------------------------------------------
-    // (not reached: FIR-like stages return through fir_like_push above)
-    return SDRHIP_ERR_STATE;
+static int map_push(sdrhip_pipe* p, const float* block, int n)
+{
+    int rc;
+    const size_t ein = (size_t)p->esz_in() * 4;
+    static const int64_t abytes = getenv("SDRHIP_ADAPTIVE_BYTES") ? atoll(getenv("SDRHIP_ADAPTIVE_BYTES")) : (int64_t)sdrhip_pipe::kAdaptiveBytes;
+    const int64_t cap_bytes = p->adaptive > 1 ? abytes : 0;                  // what may pile up before a push has to go out
+    // room for this block behind what is staged: a pinned buffer does not grow with staged blocks in it
+    if (p->staged > 0 && ((size_t)(p->staged + n) * ein > p->slot[p->cur_slot()].hin.cap || (int64_t)p->staged + n > (1 << 30)) &&
+        (rc = map_submit(p)) != SDRHIP_OK) return rc;
+    sdrhip_pipe::Slot& sl = p->slot[p->cur_slot()];
+    if (p->staged == 0) {
+        // the slot's previous submission: results harvested, staging buffer no longer read (in place: the same event)
+        if ((rc = harvest(p, p->cur_slot())) != SDRHIP_OK) return rc;
+        const size_t want = (size_t)n * ein > (size_t)cap_bytes ? (size_t)n * ein : (size_t)cap_bytes;
+        if ((rc = sl.hin.ensure(want)) != SDRHIP_OK) return rc;
+    }
+    memcpy((char*)sl.hin.p + (size_t)p->staged * ein, block, (size_t)n * ein);
+    p->staged += n;
+    p->demod_blocks.push_back(n);
+    const int64_t pushes_before = p->pushes;
+    const bool room = (int64_t)(p->staged + n) * (int64_t)ein <= cap_bytes;
+    if (!room || !p->in_flight((p->cur_slot() + 1) % p->nslots)) {
+        if ((rc = map_submit(p)) != SDRHIP_OK) return rc;
+    }
+    if (p->pushes != pushes_before && (rc = harvest_done(p)) != SDRHIP_OK) return rc;
+    return ready_blocks(p);
+}
+
+int sdrhip_pipe_push(sdrhip_pipe* p, const float* block, int n)
+{
+    SDRHIP_REQUIRE(p != nullptr && block != nullptr && n > 0, "sdrhip_pipe_push");
+    return p->is_map() ? map_push(p, block, n) : fir_like_push(p, block, n);
 }
 
 int sdrhip_pipe_set_coalesce(sdrhip_pipe* p, int blocks)
@@ -562,7 +604,6 @@ int sdrhip_pipe_set_coalesce(sdrhip_pipe* p, int blocks)
 int sdrhip_pipe_set_adaptive(sdrhip_pipe* p, int max_blocks)
 {
     SDRHIP_REQUIRE(p != nullptr && max_blocks >= 0 && max_blocks != 1, "sdrhip_pipe_set_adaptive: 0 (off) or at least two blocks");
-    SDRHIP_REQUIRE(!p->is_map(), "sdrhip_pipe_set_adaptive: filter / decimator / resampler pipes only");
     SDRHIP_REQUIRE(p->staged == 0, "sdrhip_pipe_set_adaptive: blocks are staged (flush first)");
     p->adaptive = max_blocks;
     return SDRHIP_OK;
@@ -595,7 +636,7 @@ int sdrhip_pipe_flush(sdrhip_pipe* p)
 {
     SDRHIP_REQUIRE(p != nullptr, "sdrhip_pipe_flush");
     int rc;
-    if (p->staged > 0 && (rc = fir_submit(p, p->staged, p->uniform_n)) != SDRHIP_OK) return rc;
+    if (p->staged > 0 && (rc = p->is_map() ? map_submit(p) : fir_submit(p, p->staged, p->uniform_n)) != SDRHIP_OK) return rc;
     // oldest first
     const int first = p->cur_slot();
     for (int k = 0; k < p->nslots; k++)

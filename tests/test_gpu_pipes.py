@@ -90,6 +90,49 @@ def test_fm_demod_pipe(hip, oracle):
     _cmp(_drive(hip.fmDemod(), blocks), exp, "fmDemod")
 
 
+@pytest.mark.parametrize("adaptive", [32, 0])
+def test_map_pipes_random_blocks(hip, oracle, adaptive):
+    """fmDemod and dcBlockingFilter Pipes on ragged block sequences pushed as fast as Python can (adaptive submission: blocks
+    pile up while the GPU is busy and leave as one run over their concatenation; 0: every block its own run), with pauses and
+    polls in between: one output block per input block, the carry crossing block and run boundaries
+    (Demod.hs:40-46; Filter.hs:730-739)."""
+    import time
+    rng = np.random.default_rng(91 + SWEEP_SEED)
+    for trial in range(6 * SWEEP_SCALE):
+        nblk = int(rng.integers(5, 120))
+        sizes = [int(rng.choice([1, 7, 100, 1024, 4096, 8192, 8192, 8192, 20000])) for _ in range(nblk)]
+        if trial % 3 == 0:
+            sizes = [8192] * nblk
+        total = sum(sizes)
+        x = oracle.convert_u8(S.iq_u8_fm(total, seed=300 + trial))
+        blocks = _cut(x, 2, sizes)
+        exp = PM.fm_demod_pipe(oracle, blocks)
+        pipe = hip.fmDemod()
+        pipe.set_adaptive(adaptive)
+        got = []
+        for i, b in enumerate(blocks):
+            got += pipe.push(b)
+            if i % 17 == 16:
+                time.sleep(0.001)
+                got += pipe.poll()
+        got += pipe.flush()
+        _cmp(got, exp, f"fmDemod trial {trial} ({nblk} blocks)")
+        # dcBlockingFilter on a real signal with an offset
+        xr = (S.real_block(total, seed=400 + trial) * 0.5 + 0.25).astype(np.float32)
+        e_all, _, _ = oracle.dc_blocker(xr, 0.0, 0.0)
+        pipe = hip.dcBlockingFilter()
+        pipe.set_adaptive(adaptive)
+        got = []
+        for i, b in enumerate(_cut(xr, 1, sizes)):
+            got += pipe.push(b)
+            if i % 13 == 12:
+                time.sleep(0.001)
+                got += pipe.poll()
+        got += pipe.flush()
+        assert [g.size for g in got] == sizes, f"dcBlockingFilter trial {trial}: block lengths"
+        assert_bit_equal(np.concatenate(got), e_all, f"dcBlockingFilter trial {trial}")
+
+
 def test_convert_operator(hip, oracle):
     u8 = S.iq_u8(B)
     got = hip.interleavedIQUnsignedByteToFloatFast(u8)

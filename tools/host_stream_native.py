@@ -54,6 +54,11 @@ def main():
             p.set_adaptive(0)
             r = pipe_rate(L, p.h, n, fpe, B, 2000, zc)
             print(f"{name}, {'zero-copy' if zc else 'memcpy   '}, every push its own launch: {r / 1e6:8.1f} M elements/s ({n / r * 1e6:6.2f} us/push)")
+    # the map pipes (one output block per input block): fmDemod on 8192-sample cfloat blocks, dcBlockingFilter on 8192 floats
+    for name, kind, n, fpe in (("fmDemod Pipe, 8192-sample cfloat blocks", "fm_demod", B, 2), ("dcBlockingFilter Pipe, 8192-float blocks", "dc_blocker", B, 1)):
+        p = L.Pipe(kind)
+        r = pipe_rate(L, p.h, n, fpe, B, 4000, False)
+        print(f"{name}: {r / 1e6:8.1f} M elements/s ({n / r * 1e6:6.2f} us/push)")
 
 
 if __name__ == "__main__":
