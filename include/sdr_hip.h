@@ -485,6 +485,11 @@ int sdrhip_bench_fm_stream(sdrhip_fm_chain *chain, int n_samples, int pushes, in
                            double *samples_per_s, long long *audio_blocks);
 int sdrhip_bench_pipe(struct sdrhip_pipe *p, int n, int floats_per_element, int block_size_out, int pushes, int zero_copy,
                       double *elements_per_s);
+/* the FM receiver composed of four Level-1 Pipes the way examples/fm/fm.hs:34-41 composes it (firDecimator -> fmDemod ->
+ * firResampler -> firFilter, each re-blocking to `block` elements), fed `pushes` cfloat blocks of `block` samples; every output
+ * block of a stage is popped and pushed into the next one by the loop.  *samples_per_s = source samples per second. */
+int sdrhip_bench_fm_pipes(const sdrhip_decimator *dec, const sdrhip_resampler *res, const sdrhip_filter *fil, int block, int pushes,
+                          double *samples_per_s, long long *audio_blocks);
 
 /* ------------------------------------------------------------------------ */
 /* (3) Pipe operators on host blocks                                        */

@@ -103,4 +103,71 @@ int sdrhip_bench_pipe(sdrhip_pipe* p, int n, int floats_per_element, int block_s
     return SDRHIP_OK;
 }
 
+// The FM receiver as the reference composes it (examples/fm/fm.hs:34-41) out of four Level-1 Pipes: firDecimator -> fmDemod ->
+// firResampler -> firFilter, every stage re-blocking to `block` elements, fed `pushes` cfloat blocks of `block` samples
+// (the convert is the caller's P.map); every output block of a stage is popped and pushed into the next one by this loop, as
+// the Pipes library would.  *samples_per_s = source samples per wall second; *audio_blocks = blocks that left the filter.
+int sdrhip_bench_fm_pipes(const sdrhip_decimator* dec, const sdrhip_resampler* res, const sdrhip_filter* fil, int block, int pushes,
+                          double* samples_per_s, long long* audio_blocks)
+{
+    SDRHIP_REQUIRE(dec && res && fil && block > 0 && pushes > 0 && samples_per_s, "sdrhip_bench_fm_pipes");
+    sdrhip_pipe *pd = nullptr, *pm = nullptr, *pr = nullptr, *pf = nullptr;
+    int rc = sdrhip_pipe_fir_decimator(&pd, dec, block);
+    if (rc == SDRHIP_OK) rc = sdrhip_pipe_fm_demod(&pm);
+    if (rc == SDRHIP_OK) rc = sdrhip_pipe_fir_resampler(&pr, res, block);
+    if (rc == SDRHIP_OK) rc = sdrhip_pipe_fir_filter(&pf, fil, block);
+    auto cleanup = [&]() {
+        for (sdrhip_pipe* p : {pd, pm, pr, pf})
+            if (p) sdrhip_pipe_destroy(p);
+    };
+    if (rc != SDRHIP_OK) { cleanup(); return rc; }
+    std::vector<float> src((size_t)2 * block), a((size_t)2 * block), b((size_t)2 * block);
+    uint32_t s = 4242u;
+    for (auto& v : src) { s = s * 1664525u + 1013904223u; v = (float)(int32_t)s * (1.0f / 2147483648.0f); }
+    long long blocks = 0;
+    // drain stage `from` downwards: every ready block goes into the next stage, whose ready blocks go on
+    auto cascade = [&](int ready_dec) -> int {
+        int r;
+        while (ready_dec-- > 0) {
+            int n1 = sdrhip_pipe_pop(pd, a.data(), block);
+            if (n1 <= 0) continue;
+            int ready_dem = sdrhip_pipe_push(pm, a.data(), n1);
+            if (ready_dem < 0) return ready_dem;
+            while (ready_dem-- > 0) {
+                int n2 = sdrhip_pipe_pop(pm, b.data(), 2 * block);
+                if (n2 <= 0) continue;
+                int ready_res = sdrhip_pipe_push(pr, b.data(), n2);
+                if (ready_res < 0) return ready_res;
+                while (ready_res-- > 0) {
+                    int n3 = sdrhip_pipe_pop(pr, a.data(), block);
+                    if (n3 <= 0) continue;
+                    r = sdrhip_pipe_push(pf, a.data(), n3);
+                    if (r < 0) return r;
+                    while (r-- > 0)
+                        if (sdrhip_pipe_pop(pf, b.data(), block) > 0) blocks++;
+                }
+            }
+        }
+        return SDRHIP_OK;
+    };
+    auto one = [&]() -> int {
+        int ready = sdrhip_pipe_push(pd, src.data(), block);
+        if (ready < 0) return ready;
+        return cascade(ready);
+    };
+    for (int i = 0; i < pushes / 10 + 64; i++)
+        if ((rc = one()) != SDRHIP_OK) { cleanup(); return rc; }
+    blocks = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < pushes; i++)
+        if ((rc = one()) != SDRHIP_OK) { cleanup(); return rc; }
+    // drain: flush each stage in turn and hand what it releases downstream
+    if ((rc = sdrhip_pipe_flush(pd)) < 0 || (rc = cascade(rc)) != SDRHIP_OK) { cleanup(); return rc < 0 ? rc : SDRHIP_ERR_STATE; }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *samples_per_s = (double)block * pushes / dt;
+    if (audio_blocks) *audio_blocks = blocks;
+    cleanup();
+    return SDRHIP_OK;
+}
+
 }  // extern "C"

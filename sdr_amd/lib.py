@@ -167,6 +167,7 @@ lib.sdrhip_bench_copy.argtypes = [_vp, _vp, _vp, C.c_size_t]
 lib.sdrhip_bench_copy2.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]
 lib.sdrhip_bench_fm_stream.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
 lib.sdrhip_bench_pipe.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+lib.sdrhip_bench_fm_pipes.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
 lib.sdrhip_debug_tiled_launches.argtypes = []
 lib.sdrhip_debug_tiled_launches.restype = C.c_longlong
 lib.sdrhip_dc_blocker_workspace_bytes.argtypes = [C.c_int64]

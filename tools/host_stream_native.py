@@ -54,6 +54,11 @@ def main():
             p.set_adaptive(0)
             r = pipe_rate(L, p.h, n, fpe, B, 2000, zc)
             print(f"{name}, {'zero-copy' if zc else 'memcpy   '}, every push its own launch: {r / 1e6:8.1f} M elements/s ({n / r * 1e6:6.2f} us/push)")
+    # the receiver composed of four Level-1 Pipes, as fm.hs composes it
+    sps, blocks = C.c_double(), C.c_longlong()
+    L.check(L.lib.sdrhip_bench_fm_pipes(dec.h, res.h, fil.h, B, 20000, C.byref(sps), C.byref(blocks)), "sdrhip_bench_fm_pipes")
+    print(f"firDecimator -> fmDemod -> firResampler -> firFilter as four Pipes, 8192-sample cfloat source blocks: {sps.value / 1e6:8.1f} Msamples/s "
+          f"({B / sps.value * 1e6:6.2f} us per source block, {blocks.value} audio blocks)")
     # the map pipes (one output block per input block): fmDemod on 8192-sample cfloat blocks, dcBlockingFilter on 8192 floats
     for name, kind, n, fpe in (("fmDemod Pipe, 8192-sample cfloat blocks", "fm_demod", B, 2), ("dcBlockingFilter Pipe, 8192-float blocks", "dc_blocker", B, 1)):
         p = L.Pipe(kind)
