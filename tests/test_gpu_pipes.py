@@ -133,6 +133,26 @@ def test_map_pipes_random_blocks(hip, oracle, adaptive):
         assert_bit_equal(np.concatenate(got), e_all, f"dcBlockingFilter trial {trial}")
 
 
+def test_pipe_poll_delivers_without_another_push(hip, oracle):
+    """sdrhip_pipe_poll: the output of the block just pushed is there a moment later, no further push, no flush."""
+    import time
+    x = oracle.convert_u8(S.iq_u8(12 * B))
+    blocks = _cut(x, 2, [B] * 12)
+    taps = S.taps_decim127()
+    exp, _ = PM.fir_decimator_pipe(PM.FilterModel(oracle, taps, PM.ORDER_AVX, complex_=True, factor=8), blocks, 512)
+    pipe = hip.firDecimator(hip.Decimator(8, taps, hip.ORDER_AVX, complex_=True), 512)
+    got = []
+    for i, b in enumerate(blocks):
+        got += pipe.push(b)
+        want = (((i + 1) * B - 128) // 8 + 1) // 512          # whole 512-output blocks computable from the samples so far
+        deadline = time.time() + 2.0
+        while len(got) < want and time.time() < deadline:
+            got += pipe.poll()
+        assert len(got) >= want, f"block {i}: poll delivered {len(got)} of {want} blocks"
+    got += pipe.flush()
+    _cmp(got, exp, "polled firDecimator")
+
+
 def test_convert_operator(hip, oracle):
     u8 = S.iq_u8(B)
     got = hip.interleavedIQUnsignedByteToFloatFast(u8)
