@@ -607,6 +607,22 @@ def main():
                              "what the receiver is fed; the headline `value` is measured on uniform random bytes"}
         dbg("fm input done")
 
+    # The main workload with two passes in flight (two chain objects, workspaces and audio buffers on two HIP streams): what a
+    # host that keeps the GPU fed with independent batches gets.  Reported beside `value`, which stays the one-stream figure
+    # whose per-kernel durations (roofline, stage_ms, the rocprofv3 summaries) are not blurred by co-resident kernels.
+    main_two = None
+    if extras:
+        try:
+            stm = max(2, args.steps // 4)
+            elm, pm2, slm, samem = measure_in_flight(args.blocks, stm, 1, 2)
+            main_two = {"value": round(world * slm * pm2 * stm / elm / 1e6, 1), "unit": "Msamples/s", "ms_per_pass": round(elm / (pm2 * stm) * 1e3, 4),
+                        "what": "the same passes queued on two HIP streams in turn (separate chain objects, input, workspace and audio "
+                                "buffers): the memory-heavy tail kernels of one pass run beside the VALU-bound decimator of the other"
+                                + ("" if samem is None else f"; both streams' audio identical: {samem}")}
+        except Exception as e:                          # noqa: BLE001
+            main_two = f"failed: {e!r}"
+        dbg("two passes in flight done")
+
     # BASELINE configs[4]'s shard size: 2^20 samples (128 blocks) per GPU per pass -- launch/latency-bound, the case where the
     # halo exchange matters; reported next to the main line, same run
     shard_1m = None
@@ -769,6 +785,7 @@ def main():
             **({} if events_in_region else {"stage_ms_from": "a separate short run of the same passes (the timed region of a launch-bound shard carries no event records)"}),
             "tail_ms": round(tail_ms, 5),
             "fm_carrier_input": fm_input,
+            "two_passes_in_flight": main_two,
             "shard_1M_samples_per_gpu": shard_1m,
             "without_halo_exchange": replicas,
             "host_streamed": host,
