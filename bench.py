@@ -567,11 +567,50 @@ def main():
         # the data the FM pipeline actually feeds this stage: convert(u8 IQ), i.e. cfloat values k/128
         x_u8 = (torch.randint(0, 256, (2 * n1,), device="cuda", dtype=torch.uint8).to(torch.float32) - 128.0) * (1.0 / 128.0)
         t_u8d = k2c_time(x_u8, reps=600, warm=100)
+        # the same launches alternating between two HIP streams (separate outputs): a stream of independent buffers keeps two
+        # launches in flight, and the seam fix-up, the launch gaps and the ramps of one hide behind the tile kernel of the other
+        k2c_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+        def k2c_two_streams(x, reps, rounds=3):
+            """(one-stream, two-stream) wall seconds per launch, alternating rounds (a row's place in a run moves it by +-5 %)"""
+            k1 = (n1 - 128) // 8 + 1
+            dec = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
+            sts = k2c_streams              # the same two streams for both inputs: HIP deals streams onto a few hardware queues in
+                                           # creation order, and a later pair may share one
+            os_ = [torch.empty(2 * k1 + 64, device="cuda") for _ in range(2)]
+            def go(ns, nr):
+                for i in range(nr):
+                    j = i % ns
+                    dec.run(x.data_ptr(), 0, os_[j].data_ptr(), 0, k1, BLOCK, stream=sts[j].cuda_stream)
+            go(1, 100)
+            torch.cuda.synchronize()
+            acc = [0.0, 0.0]
+            for _ in range(rounds):
+                for ns in (1, 2):
+                    go(ns, 30)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    go(ns, reps)
+                    torch.cuda.synchronize()
+                    acc[ns - 1] += (time.perf_counter() - t0) / reps
+            return acc[0] / rounds, acc[1] / rounds
+        try:
+            u1, u2 = k2c_two_streams(x_uni, 200)
+            c1, c2 = k2c_two_streams(x_u8, 200)
+            two_flight = {"input_uniform": {"one_stream_wall": k2c_fields(u1), "two_streams": k2c_fields(u2)},
+                          "input_convert_u8": {"one_stream_wall": k2c_fields(c1), "two_streams": k2c_fields(c2)},
+                          "what": "launches alternating between two HIP streams (separate outputs) against the same launches on one stream, "
+                                  "wall clock per launch, three alternating rounds of 200 launches each: what a caller with a queue of "
+                                  "independent buffers gets per buffer -- the seam fix-up, the launch gaps and the ramps of one launch run "
+                                  "beside the tile kernel of the other (tools/k2c_two_streams.py)"}
+        except Exception as e:                          # noqa: BLE001
+            two_flight = f"failed: {e!r}"
         del x_u8
         cfg1 = {"kernel": "k_decimate_c4 (cfloat in) + seam fix-up", "samples_per_launch": n1, "bound": "hbm", "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", **k2c_fields(t_uni), "input": "uniform [-1,1) f32",
                 "when": "sustained: 1000 back-to-back launches after 400 warm-up launches of the same kernel, before anything else ran on the GPU",
                 "input_convert_u8": {**k2c_fields(t_u8d), "input": "convert(u8 IQ): the values the FM pipeline feeds this stage (600 launches)"},
+                "two_launches_in_flight": two_flight,
                 "ceilings_same_process": {
                     "stream_8to1_plain_loads": {"ms": round(t_plain * 1e3, 5), "read_only_frac": round(8.0 * n1 / t_plain / 1e9 / HBM_PEAK_GBS, 4)},
                     "stream_8to1_nontemporal_loads": {"ms": round(t_nt * 1e3, 5), "read_only_frac": round(8.0 * n1 / t_nt / 1e9 / HBM_PEAK_GBS, 4)},
