@@ -374,6 +374,8 @@ int resamp_run_demod(const ResampDesc* r, hipStream_t s, const float* d_iq, bool
     if (r->cplx) {
         if (launch_resample3c_fast(s, g, r->corder, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out)) {
             // specialised complex 3-group kernel took it
+        } else if (launch_resample_cycle_fast(s, g, r->lanes, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out, true, r->corder)) {
+            // thread-per-cycle kernel took it (odd decimations, "RC2" orders)
         } else if (!launch_resample_split(s, g, true, r->lanes, r->corder, t, r->d_groups, r->d_plain, d_in, d_out))
             launch_resample_cplx(s, g, r->corder, t, r->d_groups, r->d_plain, d_in, d_out);
     } else if (g.seamBI > 0 && g.count <= small_generic_r) {

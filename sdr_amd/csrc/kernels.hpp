@@ -134,8 +134,9 @@ long long decimate_real16_launch_count();
 // kernels_resample_cycle.hip: real resamplers I/D with an odd decimation (I <= 6, D in {3,5,7}), any filter length up to
 // 1024 taps per group, AVX / SSE lane order: one thread per polyphase cycle, rolled walk with taps from LDS.  False = not
 // this kernel's shape (the caller falls through to the split / generic kernels).
+// cplx: complex data in the "RC2" orders (corder CO_X4 / CO_X2: eight / four complex partials)
 bool launch_resample_cycle_fast(hipStream_t s, const Geom& g, int lanes, const ResampTable& t, const int* increments, const float* d_groups,
-                                const float* d_plain_taps, const float* d_in, float* d_out);
+                                const float* d_plain_taps, const float* d_in, float* d_out, bool cplx = false, ComplexOrder corder = CO_SEQ);
 long long resample_cycle_launch_count();
 
 // Fast paths (kernels_fast.hip).  Return false when the configuration is not one

@@ -49,7 +49,10 @@ struct Walk {
 constexpr int CY_NT = 256;
 constexpr int CY_NV = 8;                       // 16-byte vectors a thread stages at most
 
-template <int I, int D, int L>
+// CPLX: complex data (resampleAVXRC / resampleSSERC, resample.c:106-142 -> avx_dotprod_C / sse_dotprod_C, common.h:108-155, the
+// "RC2" order: L complex partials over taps m, m + L, ..; q_k = p_k + p_{k+L/2}, then (q0 + q1) + (q2 + q3) or q0 + q1).  A complex
+// stream is a float stream of twice the length whose elements come in pairs: the staging is the real kernel's, positions x 2.
+template <int I, int D, int L, bool CPLX>
 __global__ void __launch_bounds__(CY_NT) k_resample_cycle(const float* __restrict__ in, int64_t pos0, int ncycles, int64_t avail_total,
                                                           const float* __restrict__ groups, int row_stride, int nloop,
                                                           float* __restrict__ out)
@@ -58,15 +61,16 @@ __global__ void __launch_bounds__(CY_NT) k_resample_cycle(const float* __restric
     static_assert(L == 8 || L == 4, "AVX or SSE lane count");
     constexpr Walk<I, D> W{};
     constexpr int PM = W.premax;
+    constexpr int ES = CPLX ? 2 : 1;                                   // floats per element
     extern __shared__ __attribute__((aligned(16))) float cy_lds[];
     const int tid = threadIdx.x;
     const int cyc0 = blockIdx.x * CY_NT;
-    const int span = (CY_NT - 1) * D + PM + nloop + 24;               // + 24: the sliding window runs up to two steps past the last tap
-    const int64_t first = pos0 + (int64_t)cyc0 * D;                   // first input of the tile, relative to `in`
+    const int span = ES * ((CY_NT - 1) * D + PM + nloop + 24);        // floats; + 24: the sliding window runs up to two steps past the last tap
+    const int64_t first = ES * (pos0 + (int64_t)cyc0 * D);            // first input float of the tile, relative to `in`
     // aligned staging: the LDS copy starts at the 16-byte boundary at or below the tile's first input
     const int shift = (int)((reinterpret_cast<uintptr_t>(in + first) & 15) >> 2);
     const float* src = in + first - shift;
-    const int64_t avail = avail_total - (int64_t)cyc0 * D + shift;    // floats that exist from src on (the first `shift` of them
+    const int64_t avail = ES * (avail_total - (int64_t)cyc0 * D) + shift;    // floats that exist from src on (the first `shift` of them
                                                                       // may lie in front of the caller's data: they are in the
                                                                       // same 16-byte line as in[first], never used)
     const int span4 = (span + shift + 3) / 4;
@@ -99,12 +103,14 @@ __global__ void __launch_bounds__(CY_NT) k_resample_cycle(const float* __restric
     __syncthreads();
     const int cyc = cyc0 + tid;
     if (cyc >= ncycles) return;
-    const float* wp = tile + shift + tid * D;
-    float acc[I][L];
+    const float* wp = tile + shift + tid * (D * ES);
+    float acc[I][L][ES];
 #pragma unroll
     for (int g = 0; g < I; g++)
 #pragma unroll
-        for (int l = 0; l < L; l++) acc[g][l] = 0.0f;
+        for (int l = 0; l < L; l++)
+#pragma unroll
+            for (int e = 0; e < ES; e++) acc[g][l][e] = 0.0f;
     // taps: wave-uniform loads straight from the group table (s_load_dwordx8), a chunk of GC groups one chunk ahead of its use;
     // window: PM + 24 registers = what two steps need, the second step's last eight and the next pair's in flight
     constexpr int GC = I <= 4 ? I : (I + 1) / 2, NCH = (I + GC - 1) / GC;
@@ -119,16 +125,16 @@ __global__ void __launch_bounds__(CY_NT) k_resample_cycle(const float* __restric
             }
         }
     };
-    float w[PM + 24];
+    float w[ES * (PM + 24)];
 #pragma unroll
-    for (int k = 0; k < PM + 8; k++) w[k] = wp[k];
+    for (int k = 0; k < ES * (PM + 8); k++) w[k] = wp[k];
     float c[GC][8];
     load_taps(c, 0, 0);
     // one step = eight taps of every group; BASE = where the step's window starts in w[]
     auto step = [&](auto base_tag, int j0) {
         constexpr int BASE = decltype(base_tag)::value;
 #pragma unroll
-        for (int i = 0; i < 8; i++) w[BASE + PM + 8 + i] = wp[j0 + PM + 8 + i];        // next step's values, in flight during this step
+        for (int i = 0; i < 8 * ES; i++) w[ES * (BASE + PM + 8) + i] = wp[ES * (j0 + PM + 8) + i];        // next step's values, in flight during this step
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) {
             float cn[GC][8];
@@ -139,7 +145,10 @@ __global__ void __launch_bounds__(CY_NT) k_resample_cycle(const float* __restric
                 const int g = ch * GC + q;
                 if (g < I) {
 #pragma unroll
-                    for (int i = 0; i < 8; i++) acc[g][i % L] = acc[g][i % L] + c[q][i] * w[BASE + W.pre[g] + i];   // tap j0 + i: lane i % L
+                    for (int i = 0; i < 8; i++)
+#pragma unroll
+                        for (int e = 0; e < ES; e++)
+                            acc[g][i % L][e] = acc[g][i % L][e] + c[q][i] * w[ES * (BASE + W.pre[g] + i) + e];   // tap j0 + i: lane i % L
                 }
             }
 #pragma unroll
@@ -154,7 +163,7 @@ __global__ void __launch_bounds__(CY_NT) k_resample_cycle(const float* __restric
         step(std::integral_constant<int, 0>{}, j0);
         step(std::integral_constant<int, 8>{}, j0 + 8);
 #pragma unroll
-        for (int k = 0; k < PM + 8; k++) w[k] = w[k + 16];
+        for (int k = 0; k < ES * (PM + 8); k++) w[k] = w[k + 16 * ES];
     }
     // SSE order pads the groups to a multiple of four taps only: a last half step
     auto half_step = [&](auto base_tag, int j) {
@@ -163,7 +172,9 @@ __global__ void __launch_bounds__(CY_NT) k_resample_cycle(const float* __restric
         for (int g = 0; g < I; g++) {
             const float* row = groups + g * row_stride + j;
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[g][i % L] = acc[g][i % L] + row[i] * w[BASE + W.pre[g] + i];
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int e = 0; e < ES; e++) acc[g][i % L][e] = acc[g][i % L][e] + row[i] * w[ES * (BASE + W.pre[g] + i) + e];
         }
     };
     if (j0 + 8 <= nloop) {
@@ -172,26 +183,36 @@ __global__ void __launch_bounds__(CY_NT) k_resample_cycle(const float* __restric
     } else if constexpr (L == 4) {
         if (j0 + 4 <= nloop) half_step(std::integral_constant<int, 0>{}, j0);
     }
-    float* o = out + (int64_t)cyc * I;
+    float* o = out + (int64_t)cyc * (I * ES);
 #pragma unroll
-    for (int g = 0; g < I; g++) {
-        if constexpr (L == 8) o[g] = ((acc[g][0] + acc[g][1]) + (acc[g][2] + acc[g][3])) + ((acc[g][4] + acc[g][5]) + (acc[g][6] + acc[g][7]));
-        else o[g] = (acc[g][0] + acc[g][1]) + (acc[g][2] + acc[g][3]);
-    }
+    for (int g = 0; g < I; g++)
+#pragma unroll
+        for (int e = 0; e < ES; e++) {
+            float r;
+            if constexpr (!CPLX) {
+                if constexpr (L == 8) r = ((acc[g][0][e] + acc[g][1][e]) + (acc[g][2][e] + acc[g][3][e])) + ((acc[g][4][e] + acc[g][5][e]) + (acc[g][6][e] + acc[g][7][e]));
+                else r = (acc[g][0][e] + acc[g][1][e]) + (acc[g][2][e] + acc[g][3][e]);
+            } else {
+                if constexpr (L == 8)
+                    r = ((acc[g][0][e] + acc[g][4][e]) + (acc[g][1][e] + acc[g][5][e])) + ((acc[g][2][e] + acc[g][6][e]) + (acc[g][3][e] + acc[g][7][e]));
+                else r = (acc[g][0][e] + acc[g][2][e]) + (acc[g][1][e] + acc[g][3][e]);
+            }
+            o[g * ES + e] = r;
+        }
 }
 
 std::atomic<long long> g_cycle_launches{0};
 
-template <int I, int D, int L>
+template <int I, int D, int L, bool CPLX>
 bool launch_cycle(hipStream_t s, const float* d_in, int64_t pos, int ncycles, int nloop, const float* d_groups, int row_stride, float* d_out)
 {
     constexpr Walk<I, D> W{};
-    const int span = (CY_NT - 1) * D + W.premax + nloop + 24;
+    const int span = (CPLX ? 2 : 1) * ((CY_NT - 1) * D + W.premax + nloop + 24);
     const int span4_max = (span + 3 + 3) / 4;
     if (span4_max > CY_NV * CY_NT) return false;
     const size_t lds_bytes = ((size_t)4 * span4_max + 16) * sizeof(float);
     if (lds_bytes > 60 * 1024) return false;
-    auto kern = k_resample_cycle<I, D, L>;
+    auto kern = k_resample_cycle<I, D, L, CPLX>;
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -211,8 +232,13 @@ bool launch_cycle(hipStream_t s, const float* d_in, int64_t pos, int ncycles, in
 long long resample_cycle_launch_count() { return g_cycle_launches.load(); }
 
 bool launch_resample_cycle_fast(hipStream_t s, const Geom& g, int lanes, const ResampTable& t, const int* increments, const float* d_groups,
-                                const float* d_plain_taps, const float* d_in, float* d_out)
+                                const float* d_plain_taps, const float* d_in, float* d_out, bool cplx, ComplexOrder corder)
 {
+    if (cplx) {
+        if (!(corder == CO_X4 || corder == CO_X2)) return false;          // the "RC2" orders of resampleAVXRC / resampleSSERC
+        lanes = corder == CO_X4 ? 8 : 4;
+    }
+    const int es = cplx ? 2 : 1;
     static const bool off = getenv("SDRHIP_RESAMP_CYCLE") != nullptr && atoi(getenv("SDRHIP_RESAMP_CYCLE")) == 0;     // A/B: the split kernel
     if (off || t.force_seq || t.ext != nullptr || g.seamBI < 0 || g.count < 4096) return false;
     if (!(lanes == 8 || lanes == 4) || t.ngroups != g.I || t.nloop < 8 || t.nloop % lanes != 0 || t.nloop > 1024) return false;
@@ -235,17 +261,22 @@ bool launch_resample_cycle_fast(hipStream_t s, const Geom& g, int lanes, const R
     const int64_t skip = lead > 0 ? t.pre[lead - 1] + increments[(t.group0 + lead - 1) % I] : 0;
     const int64_t pos = t.pos0 + skip;
     bool took = false;
-#define CYC(IV, DV) if (I == IV && D == DV) took = lanes == 8 ? launch_cycle<IV, DV, 8>(s, d_in, pos, ncycles, t.nloop, d_groups, t.row_stride, d_out + lead) \
-                                                              : launch_cycle<IV, DV, 4>(s, d_in, pos, ncycles, t.nloop, d_groups, t.row_stride, d_out + lead)
-    CYC(1, 3); CYC(2, 3); CYC(1, 5); CYC(2, 5); CYC(3, 5); CYC(4, 5); CYC(2, 7); CYC(3, 7); CYC(4, 7); CYC(5, 7); CYC(6, 7);
+#define CYC(IV, DV) if (I == IV && D == DV) took = lanes == 8 ? launch_cycle<IV, DV, 8, false>(s, d_in, pos, ncycles, t.nloop, d_groups, t.row_stride, d_out + lead) \
+                                                              : launch_cycle<IV, DV, 4, false>(s, d_in, pos, ncycles, t.nloop, d_groups, t.row_stride, d_out + lead)
+#define CYCC(IV, DV) if (I == IV && D == DV) took = lanes == 8 ? launch_cycle<IV, DV, 8, true>(s, d_in, pos, ncycles, t.nloop, d_groups, t.row_stride, d_out + 2 * lead) \
+                                                               : launch_cycle<IV, DV, 4, true>(s, d_in, pos, ncycles, t.nloop, d_groups, t.row_stride, d_out + 2 * lead)
+    if (!cplx) { CYC(1, 3); CYC(2, 3); CYC(1, 5); CYC(2, 5); CYC(3, 5); CYC(4, 5); CYC(2, 7); CYC(3, 7); CYC(4, 7); CYC(5, 7); CYC(6, 7); }
+    else { CYCC(1, 3); CYCC(2, 3); CYCC(1, 5); CYCC(2, 5); CYCC(3, 5); CYCC(4, 5); CYCC(2, 7); CYCC(3, 7); CYCC(4, 7); CYCC(5, 7); }   // (6/7: 250+ VGPRs)
 #undef CYC
+#undef CYCC
     if (!took) return false;
     Geom gs = g;
     gs.seamBI = 0;          // every output as One first; seams are fixed up below
     if (lead > 0) {
         Geom gl = gs;
         gl.count = lead;
-        launch_resample_real(s, gl, lanes, t, d_groups, d_plain_taps, d_in, d_out);
+        if (cplx) launch_resample_cplx(s, gl, corder, t, d_groups, d_plain_taps, d_in, d_out);
+        else launch_resample_real(s, gl, lanes, t, d_groups, d_plain_taps, d_in, d_out);
     }
     if (tail > 0) {
         const int done = lead + I * ncycles;
@@ -257,7 +288,8 @@ bool launch_resample_cycle_fast(hipStream_t s, const Geom& g, int lanes, const R
         tt.pos0 = pos + (int64_t)ncycles * D;
         int acc = 0;
         for (int q = 0; q < I; q++) { tt.pre[q] = acc; acc += increments[q]; }
-        launch_resample_real(s, gt, lanes, tt, d_groups, d_plain_taps, d_in, d_out + done);
+        if (cplx) launch_resample_cplx(s, gt, corder, tt, d_groups, d_plain_taps, d_in, d_out + es * done);
+        else launch_resample_real(s, gt, lanes, tt, d_groups, d_plain_taps, d_in, d_out + done);
     }
     if (g.seamBI != 0) {
         int64_t first, last;
@@ -270,7 +302,11 @@ bool launch_resample_cycle_fast(hipStream_t s, const Geom& g, int lanes, const R
             const int64_t last_m = g.k_begin + g.count - 1;
             const int64_t in_avail = (last_m * g.D + g.I - 1) / g.I - g.in_base + t.nloop;          // inputs the caller guarantees
             auto uni = [&](int PER) { return t.nloop + (PER * g.D + g.I - 1) / g.I + 4; };
-            if (per <= 32 && uni(32) <= 192)
+            if (cplx) {
+                const int64_t total = (int64_t)nseams * per;
+                hipLaunchKernelGGL(k_resample_crossfix<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, d_plain_taps, t.ntaps_plain, d_in,
+                                   d_out, first, nseams, per);
+            } else if (per <= 32 && uni(32) <= 192)
                 hipLaunchKernelGGL((k_resample_real_crossfix<32, 192, 32>), dim3((nseams + 7) / 8), dim3(256), 0, s, g, d_plain_taps, t.ntaps_plain, d_in,
                                    d_out, first, nseams, in_avail);
             else if (per <= 64 && uni(64) <= 384)

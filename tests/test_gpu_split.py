@@ -221,7 +221,7 @@ def test_resampler_families(hip, oracle, order, complex_, I, D, ntaps):
     # 3/10 with 64-tap groups has specialised kernels: real AVX / SSE (k_resample3_fast), complex AVX / SSE (k_resample3c_fast)
     is_special = (I, D) == (3, 10) and 185 <= ntaps <= 192
     # real I/D with an odd decimation 3 / 5 / 7 has the thread-per-cycle kernel (kernels_resample_cycle.hip), both lane orders
-    is_cycle = not complex_ and D in (3, 5, 7)
+    is_cycle = D in (3, 5, 7)                            # complex data too (the RC2 orders), round 3
     # interpolation 1 and decimation 2 / 4 / 8 / 16: the real decimator's kernel (one polyphase group, the same lane order)
     is_decim = not complex_ and I == 1 and D in (2, 4, 8, 16)
     before, before_cycle, before16 = _tiled(hip), hip.lib.sdrhip_debug_resample_cycle_launches(), hip.lib.sdrhip_debug_decimate_real16_launches()
@@ -237,22 +237,27 @@ def test_resampler_families(hip, oracle, order, complex_, I, D, ntaps):
     assert_bit_equal(got, exp, "cut into launches (every starting group)")
 
 
+@pytest.mark.parametrize("complex_", [False, True])
 @pytest.mark.parametrize("order", [PM.ORDER_AVX, PM.ORDER_SSE])
 @pytest.mark.parametrize("I,D", [(1, 3), (2, 3), (1, 5), (2, 5), (3, 5), (4, 5), (2, 7), (3, 7), (4, 7), (5, 7), (6, 7)])
 @pytest.mark.parametrize("ntaps", [37, 150, 700])
-def test_cycle_resampler(hip, oracle, order, I, D, ntaps):
-    """Every instantiation of the thread-per-cycle kernel (kernels_resample_cycle.hip): short / medium / long filters (a
-    single step of the rolled walk, an odd and an even number of steps, the SSE half step), launches cut at every
-    starting group, against the restated Pipe (resample.c:52-87 for One outputs, FilterInternal.hs:410-423 at seams)."""
-    x = S.real_block(NBLK * B)
+def test_cycle_resampler(hip, oracle, order, I, D, ntaps, complex_):
+    """Every instantiation of the thread-per-cycle kernel (kernels_resample_cycle.hip), real and complex data: short / medium /
+    long filters (a single step of the rolled walk, an odd and an even number of steps, the SSE half step), launches cut at
+    every starting group, against the restated Pipe (resample.c:52-87 / :106-142 for One outputs, FilterInternal.hs:410-423 at
+    seams)."""
+    if complex_ and (I, D) == (6, 7):
+        pytest.skip("complex 6/7 stays on the lane-split kernel (250+ registers)")
+    w = 2 if complex_ else 1
+    x = S.cfloat_block(NBLK * B) if complex_ else S.real_block(NBLK * B)
     taps = S.gauss_taps(ntaps, 100 * I + D + ntaps)
-    model = PM.ResamplerModel(oracle, I, D, taps, order)
-    blocks, _ = PM.fir_resampler_pipe(model, _split(x, 1, B), 512)
+    model = PM.ResamplerModel(oracle, I, D, taps, order, complex_)
+    blocks, _ = PM.fir_resampler_pipe(model, _split(x, w, B), 512)
     exp = np.concatenate(blocks)
-    K = exp.size
-    r = hip.Resampler(I, D, taps, order)
+    K = exp.size // w
+    r = hip.Resampler(I, D, taps, order, complex_)
     before = hip.lib.sdrhip_debug_resample_cycle_launches()
-    got = _run(r, to_dev(x), 1, K, B, out_block=512)
+    got = _run(r, to_dev(x), w, K, B, out_block=512)
     groups_taps = -(-ntaps // I)
     lanes = 8 if order == PM.ORDER_AVX else 4
     if -(-groups_taps // lanes) * lanes >= 8:
@@ -260,13 +265,13 @@ def test_cycle_resampler(hip, oracle, order, I, D, ntaps):
     assert_bit_equal(got, exp, f"{I}/{D}, {ntaps} taps: one launch")
     cuts = [4099 + q for q in range(I)]
     cuts = [c + 4100 * q for q, c in enumerate(cuts)] + [K - 4500]
-    got = _run(r, to_dev(x), 1, K, B, cuts=[c for c in cuts if 0 < c < K], out_block=512)
+    got = _run(r, to_dev(x), w, K, B, cuts=[c for c in cuts if 0 < c < K], out_block=512)
     assert_bit_equal(got, exp, f"{I}/{D}, {ntaps} taps: cut into launches")
     # no seams (one contiguous buffer)
-    model1 = PM.ResamplerModel(oracle, I, D, taps, order)
+    model1 = PM.ResamplerModel(oracle, I, D, taps, order, complex_)
     blocks1, _ = PM.fir_resampler_pipe(model1, [x], 512)
     exp1 = np.concatenate(blocks1)
-    got1 = _run(r, to_dev(x), 1, exp1.size, 0, out_block=512)
+    got1 = _run(r, to_dev(x), w, exp1.size // w, 0, out_block=512)
     assert_bit_equal(got1, exp1, f"{I}/{D}, {ntaps} taps: no seams")
 
 
