@@ -351,6 +351,11 @@ long long sdrhip_debug_decimate_real16_launches(void);
 /* A/B switch (measurements only; results are identical): 0 = the tiled AVX-order decimator runs every tile through its general
  * instantiation, 1 (default) = whole tiles through the specialised one.  SDRHIP_FULL_TILES=0/1 sets the initial value. */
 void sdrhip_debug_set_full_tiles(int on);
+/* A/B switch (measurements only; results are identical): 1 (default) = decimate-by-8, 128-tap, AVX-order launches that are not
+ * launch-bound take the register-resident systolic kernel (kernels_systolic.hip, round 4), 0 = the LDS-tiled kernel everywhere.
+ * SDRHIP_SYSTOLIC=0/1 sets the initial value.  sdrhip_debug_systolic_launches: launches it has served, process-wide. */
+void sdrhip_debug_set_systolic(int on);
+long long sdrhip_debug_systolic_launches(void);
 /* fmDemod inside the resampler's tile loader for large batches (>= 2^18 resampler outputs per run): the demodulated stream
  * never makes its round trip through HBM (12 B per decimated sample less traffic); the per-stage timing then books the pair
  * under `resample`.  Same bits.  Off by default (environment SDRHIP_FUSE_DEMOD=1 turns it on): measured, the pair takes

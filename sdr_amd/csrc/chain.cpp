@@ -553,6 +553,8 @@ long long sdrhip_debug_small_chain_launches(void) { return fm_chain_small_launch
 long long sdrhip_debug_resample_cycle_launches(void) { return resample_cycle_launch_count(); }
 long long sdrhip_debug_decimate_real16_launches(void) { return decimate_real16_launch_count(); }
 void sdrhip_debug_set_full_tiles(int on) { set_full_tiles(on); }
+void sdrhip_debug_set_systolic(int on) { set_systolic(on); }
+long long sdrhip_debug_systolic_launches(void) { return systolic_launch_count(); }
 
 int sdrhip_fm_chain_set_demod_fusion(sdrhip_fm_chain* c, int enable)
 {

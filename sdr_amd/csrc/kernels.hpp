@@ -184,6 +184,12 @@ int small_launch_outputs();
 // last_tap_zero: tap P-1 is the zero the constructor padded the filter with (lets the u8 path skip its MACs)
 bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps,
                              const void* d_in, bool in_is_u8, float* d_out, bool last_tap_zero = false);
+// kernels_systolic.hip (round 4): the One outputs of a decimate-by-8, 128-tap, AVX-order launch by the register-resident systolic
+// walk (d_taps: plain taps, pre-scaled by 1/128 for u8 input).  false = not this shape / too small, nothing launched.
+bool launch_decimate_c4_systolic(hipStream_t s, const Geom& g, const float* d_taps, int P, const void* d_in, bool in_is_u8, float* d_out,
+                                 bool last_tap_zero);
+void set_systolic(int on);          // A/B switch (SDRHIP_SYSTOLIC=0: the tile kernel everywhere)
+long long systolic_launch_count();  // diagnostics
 void set_full_tiles(int on);   // A/B switch of the FULL-tile instantiations of the AVX-order tiled decimator (decimate_tile.hpp)
 // kernels_fast_orders.hip: the same tiled decimator for the SSE "RC" and the "RC2" summation orders (CO_L2, CO_X4, CO_X2)
 bool launch_decimate_c_orders_fast(hipStream_t s, const Geom& g, ComplexOrder order, const float* d_plain_taps, int P,

@@ -1,0 +1,96 @@
+"""GPU parity of the register-resident systolic decimator (kernels_systolic.hip, round 4): the decimate-by-8, 128-tap, AVX-order
+launches that are not launch-bound.  Bit-equal with the oracle's decimateAVXRC restatement (decimate.c:105-113), with the restated
+Pipes where seams are on, and with the LDS-tiled kernel it replaces -- whole strips, the ragged last strip, launches cut at
+arbitrary outputs, u8 and cfloat input."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_bit_equal
+from oracle import pipes_model as PM
+import signals as S
+from gpu_util import to_dev, dev_empty_f32, ptr, to_host
+
+pytestmark = pytest.mark.gpu
+
+B = 8192
+MIN = 64 * 240 * 4          # the launcher's threshold: fewer outputs stay on the tile kernel
+
+
+def _dup(h):
+    return np.repeat(h, 2)
+
+
+@pytest.fixture
+def counted(hip):
+    hip.lib.sdrhip_debug_set_systolic(1)
+    before = hip.lib.sdrhip_debug_systolic_launches()
+    yield lambda: hip.lib.sdrhip_debug_systolic_launches() - before
+    hip.lib.sdrhip_debug_set_systolic(1)
+
+
+@pytest.mark.parametrize("extra", [0, 1, 3, 239, 240, 247, 4 * 240 + 5, 38563])
+@pytest.mark.parametrize("u8", [True, False])
+def test_one_outputs_match_the_oracle(hip, oracle, counted, extra, u8):
+    """seam_block = 0 (every output in SIMD order): whole strips and every kind of ragged end."""
+    K = MIN + extra
+    n = 8 * (K - 1) + 128
+    taps = S.taps_decim127()
+    h = np.concatenate([taps, np.zeros(1, np.float32)])
+    raw = S.iq_u8(n)
+    x = oracle.convert_u8(raw) if u8 else S.cfloat_block(n)
+    dec = hip.Decimator(8, taps, hip.ORDER_AVX, complex_=True)
+    out = dev_empty_f32(2 * K + 64)
+    out.fill_(float("nan"))
+    d_in = to_dev(raw if u8 else x)
+    (dec.run_u8 if u8 else dec.run)(ptr(d_in), 0, ptr(out), 0, K, 0)
+    got = to_host(out)
+    assert counted() == 1, "the systolic kernel did not take this launch"
+    assert_bit_equal(got[:2 * K], oracle.decimate_rc(4, K, 8, _dup(h), x), f"K = {K}")
+    assert np.isnan(got[2 * K:]).all(), "wrote past the launch's outputs"
+
+
+@pytest.mark.parametrize("u8", [True, False])
+def test_seamed_stream_cut_into_launches(hip, oracle, counted, u8):
+    """8192-sample seams (Cross outputs by the fix-up kernel), the stream cut at awkward outputs: each launch has its own x0."""
+    nblk = 240           # seamed launches up to 5 * 32768 outputs stay on the tile kernel (their Cross outputs are computed in place)
+    raw = S.iq_u8(nblk * B)
+    x = oracle.convert_u8(raw) if u8 else S.cfloat_block(nblk * B)
+    taps = S.taps_decim127()
+    model = PM.FilterModel(oracle, taps, PM.ORDER_AVX, complex_=True, factor=8)
+    blocks, _ = PM.fir_decimator_pipe(model, [x[2 * i * B: 2 * (i + 1) * B] for i in range(nblk)], 4096)
+    exp = np.concatenate(blocks)
+    K = exp.size // 2
+    assert K > 5 * 32768 + 65536
+    dec = hip.Decimator(8, taps, hip.ORDER_AVX, complex_=True)
+    d_in = to_dev(raw if u8 else x)
+    out = dev_empty_f32(2 * K)
+    for cuts in ([], [2 * 3], [K - 65536]):        # launch starts stay 16-byte aligned (even outputs); the last launch of the third cut is small
+        out.fill_(float("nan"))
+        edges = [0] + cuts + [K]
+        for a, b in zip(edges[:-1], edges[1:]):
+            (dec.run_u8 if u8 else dec.run)(ptr(d_in), 0, ptr(out) + 8 * a, a, b, B)
+        assert_bit_equal(to_host(out), exp, f"cuts {cuts}")
+    assert counted() == 3
+
+
+@pytest.mark.parametrize("u8", [True, False])
+def test_same_bits_as_the_tile_kernel_at_2_to_the_24(hip, counted, u8):
+    n = 1 << 24
+    g = torch.Generator(device="cuda").manual_seed(11)
+    if u8:
+        d_in = torch.randint(0, 256, (2 * n + 4096,), dtype=torch.uint8, device="cuda", generator=g)
+    else:
+        d_in = torch.rand(2 * n + 4096, device="cuda", generator=g) * 2 - 1
+    taps = S.taps_decim127()
+    dec = hip.Decimator(8, taps, hip.ORDER_AVX, complex_=True)
+    K = (n - 128) // 8 + 1
+    outs = []
+    for on in (1, 0):
+        hip.lib.sdrhip_debug_set_systolic(on)
+        out = dev_empty_f32(2 * K)
+        (dec.run_u8 if u8 else dec.run)(ptr(d_in), 0, ptr(out), 0, K, B)
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert counted() == 1
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
