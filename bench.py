@@ -173,13 +173,13 @@ def plumbing_check(args, rank, world):
 
 
 def k2_source_sha256():
-    """Digest of the dominant kernel's sources (the tile kernel + its launcher) with comments and white space stripped:
+    """Digest of the dominant kernel's sources (the systolic kernel, the tile kernel + their launcher) with comments and white space stripped:
     profiles/k2_traffic.json is only quoted while it was measured on this version of the code (tools/summarize_profile.py
     writes the same digest)."""
     import hashlib
     import re
     h = hashlib.sha256()
-    for name in ("decimate_tile.hpp", "kernels_fast.hip"):
+    for name in ("decimate_tile.hpp", "kernels_fast.hip", "kernels_systolic.hip"):
         text = open(os.path.join(ROOT, "sdr_amd", "csrc", name), "r").read()
         text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
         text = re.sub(r"//[^\n]*", " ", text)
@@ -302,7 +302,7 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
-    def measure(blocks, steps, warmup, passes, ramp_s, timing, graph=False, do_exchange=True, data="uniform"):
+    def measure(blocks, steps, warmup, passes, ramp_s, timing, graph=False, do_exchange=True, data="uniform", lib_overlap=False):
         """One configuration: `blocks` 8192-sample blocks per GPU per pass.  Returns the max-over-ranks wall time of
         `steps` steps of `passes` passes each, the per-stage HIP-event times and the plan.  graph: the chain's kernels of
         one pass replayed from a hipGraph captured once (sdrhip_fm_chain_graph_*): one launch per pass instead of one per kernel."""
@@ -325,8 +325,15 @@ def main():
         else:
             buf = torch.randint(0, 256, (2 * (S_len + plan.halo_cap),), dtype=torch.uint8, device="cuda", generator=gen)
         audio = torch.empty(plan.q1 - plan.q0, dtype=torch.float32, device="cuda")
+        # lib_overlap (N = 1): two passes in flight INSIDE the library (sdrhip_fm_chain_set_overlap): consecutive runs alternate
+        # between two internal streams and workspace halves; the audio is double-buffered as that contract asks
+        lib_overlap = lib_overlap and world == 1 and not graph
+        if lib_overlap:
+            chain.set_overlap(True)
+            audio_b = torch.empty_like(audio)
         ws_bytes = chain.workspace_bytes(S_len + plan.halo_cap)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+        flip = [0]
         # N > 1: the halo (the right neighbour's first ~4k samples) travels while this rank already computes the outputs
         # that need only its own samples, [q0, q_mid); the few that reach into the halo, [q_mid, q1), run on a second stream
         # as soon as it has landed.  Two chain objects: each keeps its own timing events.
@@ -355,6 +362,10 @@ def main():
                                     plan.q1, ws_b.data_ptr(), ws_bytes)
 
         def one_pass():
+            if lib_overlap:
+                flip[0] ^= 1
+                chain.run(buf.data_ptr(), plan.s0, plan.n_in, (audio_b if flip[0] else audio).data_ptr(), plan.q0, plan.q1, ws.data_ptr(), ws_bytes, stream=sptr)
+                return
             if not overlap:
                 if world > 1:
                     exchange(stream)
@@ -417,11 +428,18 @@ def main():
         for _ in range(steps):
             for _ in range(passes):
                 one_pass()
+        if lib_overlap:
+            chain.join(sptr)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        same_audio = None
+        if lib_overlap:
+            same_audio = bool(torch.equal(audio.view(torch.int32), audio_b.view(torch.int32)))
+            chain.set_overlap(False)
+            del audio_b
         stage_ms, runs = ({}, 0)
         if timing:
             stage_ms, runs = chain.read_timing()
@@ -440,7 +458,8 @@ def main():
                 crc = gathered
         del g_all, g_a, g_b
         del buf, audio, ws
-        return {"elapsed": elapsed, "passes": passes, "stage_ms": stage_ms, "plan": plan, "S_len": S_len, "overlap": overlap, "crc": crc}
+        return {"elapsed": elapsed, "passes": passes, "stage_ms": stage_ms, "plan": plan, "S_len": S_len, "overlap": overlap, "crc": crc,
+                "lib_overlap": lib_overlap, "same_audio": same_audio}
 
     def measure_in_flight(blocks, steps, warmup, nflight, do_exchange=True):
         """Launch-bound shards: `nflight` passes in flight, pass i on HIP stream i % nflight with its own input / audio
@@ -606,7 +625,7 @@ def main():
         except Exception as e:                          # noqa: BLE001
             two_flight = f"failed: {e!r}"
         del x_u8
-        cfg1 = {"kernel": "k_decimate_c4 (cfloat in) + seam fix-up", "samples_per_launch": n1, "bound": "hbm", "peak": HBM_PEAK_GBS,
+        cfg1 = {"kernel": "k_decimate_systolic<cfloat> + seam fix-up", "samples_per_launch": n1, "bound": "hbm", "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", **k2c_fields(t_uni), "input": "uniform [-1,1) f32",
                 "when": "sustained: 1000 back-to-back launches after 400 warm-up launches of the same kernel, before anything else ran on the GPU",
                 "input_convert_u8": {**k2c_fields(t_u8d), "input": "convert(u8 IQ): the values the FM pipeline feeds this stage (600 launches)"},
@@ -630,9 +649,17 @@ def main():
     # per-stage HIP events inside the timed region (ten event records per pass) when a pass is long enough not to notice them;
     # a launch-bound shard (e.g. --blocks 128, BASELINE configs[4]) is timed without them and its stage times come from a
     # short separate run of the same passes
-    events_in_region = args.blocks >= 2048
-    main_run = measure(args.blocks, args.steps, args.warmup, args.passes_per_step, 0.3, events_in_region)
-    if not events_in_region:
+    # N = 1: `value` is measured with two passes in flight inside the library (sdrhip_fm_chain_set_overlap; what a streaming caller
+    # gets for one flag) and stage_ms / roofline come from a one-pass-at-a-time run of the same passes right after it, so that
+    # per-kernel durations are not blurred by co-resident kernels (BENCH_NO_LIB_OVERLAP=1: one pass at a time throughout).
+    want_overlap = world == 1 and os.environ.get("BENCH_NO_LIB_OVERLAP") != "1" and args.blocks >= 2048
+    events_in_region = args.blocks >= 2048 and not want_overlap
+    main_run = measure(args.blocks, args.steps, args.warmup, args.passes_per_step, 0.3, events_in_region, lib_overlap=want_overlap)
+    single_pass = None
+    if want_overlap:
+        single_pass = measure(args.blocks, args.steps, 1, main_run["passes"], 0.05, True)
+        main_run["stage_ms"] = single_pass["stage_ms"]
+    elif not events_in_region:
         main_run["stage_ms"] = measure(args.blocks, max(2, args.steps // 4), 1, main_run["passes"], 0.05, True)["stage_ms"]
     dbg("main measurement done")
     # the same run on a frequency-modulated carrier instead of uniform random bytes (the chip is power-limited and the power
@@ -712,6 +739,73 @@ def main():
                                    "frac": round(9.0 * (1 << 27) / t_after / 1e9 / HBM_PEAK_GBS, 4),
                                    "when": "same kernel and input, 20 launches right after the chain measurement of this process"}
         dbg("cfg1 after-chain done")
+
+    # Socket power, power cap and shader clock behind the "power-limited" reading of the kernels (VERDICT r03 "next" #2): each
+    # row keeps the GPU busy with ONE kind of launch for ~2.5 s while a sampler thread reads the amdgpu hwmon files of THIS
+    # device (tools/power_probe.py: power1_input, freq1_input, power1_cap); the reported power is filtered by the SMU with a
+    # time constant of a few hundred ms, hence the long rows and the mean over their last 60 %.
+    power = None
+    if rank == 0 and world == 1 and extras and os.environ.get("BENCH_NO_POWER") != "1":
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import power_probe as PP
+            bdf = PP.device_bdf(dev)
+            smp = PP.HwmonSampler(0.05, bdf)
+            if not smp.available:
+                power = {"available": False, "device_bdf": bdf, "note": "no hwmon directory for this device under /sys/bus/pci/devices"}
+            else:
+                def power_row(fn, per_launch_s, samples_per_launch, seconds=2.5):
+                    torch.cuda.synchronize()
+                    n_l = max(8, int(seconds / max(per_launch_s, 1e-6)))
+                    smp.start()
+                    t0 = time.perf_counter()
+                    for _ in range(n_l):
+                        fn()
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    st = PP.HwmonSampler.summarize(smp.stop(), t_lo=0.4 * dt)
+                    row = {"seconds": round(dt, 2), "launches": n_l, "us_per_launch": round(dt / n_l * 1e6, 1)}
+                    if samples_per_launch:
+                        row["Gsamples_per_s"] = round(samples_per_launch * n_l / dt / 1e9, 1)
+                    if st:
+                        row.update({"mean_w": round(st["mean_w"], 1), "min_w": round(st["min_w"], 1), "max_w": round(st["max_w"], 1),
+                                    "mean_sclk_mhz": round(st["mean_sclk_mhz"], 0) if st["mean_sclk_mhz"] else None, "telemetry_samples": st["samples"]})
+                    return row
+                smp.start()
+                time.sleep(1.0)
+                idle = PP.HwmonSampler.summarize(smp.stop())
+                npw = 1 << 27
+                kpw = (npw - 128) // 8 + 1
+                decp = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
+                xo = torch.empty(2 * kpw + 64, device="cuda")
+                xu = torch.randint(0, 256, (2 * npw,), dtype=torch.uint8, device="cuda")
+                rows = {}
+                rows["k2_u8_decimator_2^27_samples"] = power_row(lambda: decp.run_u8(xu.data_ptr(), 0, xo.data_ptr(), 0, kpw, BLOCK, stream=sptr), 1.8e-4, npw)
+                del xu
+                xf = torch.rand(2 * npw, device="cuda") * 2 - 1
+                rows["k2_cfloat_decimator_2^27_samples"] = power_row(lambda: decp.run(xf.data_ptr(), 0, xo.data_ptr(), 0, kpw, BLOCK, stream=sptr), 2.4e-4, npw)
+                so = torch.empty(npw // 4 + 64, device="cuda")
+                rows["stream_8to1_nontemporal_loads_2^27_samples"] = power_row(
+                    lambda: L.check(L.lib.sdrhip_bench_stream_8to1(sptr, xf.data_ptr(), so.data_ptr(), 8 * npw, 1)), 2.0e-4, npw)
+                del xf, so, xo
+                # the whole chain, the main workload's pass
+                S_p = args.blocks * BLOCK
+                plan_p = sharding.ShardPlan(chain, 0, 1, S_p)
+                buf_p = torch.randint(0, 256, (2 * (S_p + plan_p.halo_cap),), dtype=torch.uint8, device="cuda")
+                aud_p = torch.empty(plan_p.q1 - plan_p.q0, dtype=torch.float32, device="cuda")
+                wsb = chain.workspace_bytes(S_p + plan_p.halo_cap)
+                ws_p = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+                rows["fm_chain_pass"] = power_row(lambda: chain.run(buf_p.data_ptr(), plan_p.s0, plan_p.n_in, aud_p.data_ptr(), plan_p.q0, plan_p.q1,
+                                                                     ws_p.data_ptr(), wsb, stream=sptr), 1.05e-3 * args.blocks / 65536, S_p)
+                del buf_p, aud_p, ws_p
+                power = {"available": True, "device_bdf": bdf, "cap_w": smp.cap_watts(),
+                         "idle": {"mean_w": round(idle["mean_w"], 1), "mean_sclk_mhz": round(idle["mean_sclk_mhz"], 0)} if idle else None,
+                         "rows": rows,
+                         "how": "tools/power_probe.py HwmonSampler (amdgpu hwmon power1_input / freq1_input / power1_cap of the device's own PCI "
+                                "address, 50 ms period), mean over the last 60 % of each ~2.5 s row of back-to-back launches"}
+        except Exception as e:                          # noqa: BLE001
+            power = {"available": False, "error": repr(e)}
+        dbg("power rows done")
 
     # Host-streamed operation (PCIe inclusive, never `value`): the C-ABI host-block operators at the reference's own block
     # sizes, timed by the library's C loops (a compiled caller's cost per push; tools/host_stream_native.py)
@@ -802,9 +896,12 @@ def main():
                 "halo_transport": None if world == 1 else ("rccl: ncclSend/ncclRecv inside libsdr_hip.so (sdrhip_fm_chain_halo_exchange) on the compute stream"
                                                            if comm is not None else "host memory through gloo (fallback / plumbing check)"),
                 "order": "AVX (bit-exact vs reference AVX path)",
+                "overlap": ("two passes in flight inside the library (sdrhip_fm_chain_set_overlap): consecutive runs alternate between two internal "
+                            "streams and workspace halves; both audio buffers identical: " + str(main_run["same_audio"])) if main_run["lib_overlap"]
+                           else "none: one pass at a time on one stream",
             },
             "roofline": {
-                "kernel": "k_decimate_c4 (u8->cfloat convert fused + 128-tap complex decimate-by-8) + seam fix-up",
+                "kernel": "k_decimate_systolic<u8> (u8->cfloat convert fused + 128-tap complex decimate-by-8, register-resident systolic walk) + seam fix-up",
                 "bound": "valu",
                 "achieved": round(valu_achieved, 2),
                 "peak": VALU_PEAK_TFLOPS,
@@ -821,6 +918,10 @@ def main():
             },
             "roofline_config1_cfloat_decimate": cfg1,
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+            **({"one_pass_at_a_time": {"value": round(world * single_pass["S_len"] * single_pass["passes"] * args.steps / single_pass["elapsed"] / 1e6, 1),
+                                       "ms_per_pass": round(single_pass["elapsed"] / (args.steps * single_pass["passes"]) * 1e3, 4),
+                                       "what": "the same passes one at a time on one stream, with the per-stage HIP events in the timed region: the run "
+                                               "stage_ms and roofline are taken from"}} if single_pass is not None else {}),
             **({} if events_in_region else {"stage_ms_from": "a separate short run of the same passes (the timed region of a launch-bound shard carries no event records)"}),
             "tail_ms": round(tail_ms, 5),
             "fm_carrier_input": fm_input,
@@ -828,6 +929,7 @@ def main():
             "shard_1M_samples_per_gpu": shard_1m,
             "without_halo_exchange": replicas,
             "host_streamed": host,
+            "power": power,
             "cpu_baseline": cpu,
         }
         print(json.dumps(result))

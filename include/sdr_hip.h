@@ -323,6 +323,19 @@ void sdrhip_fm_chain_graph_destroy(sdrhip_fm_graph *g);
  * wait for the internal one before the call returns control of the stream.  Results do not
  * depend on nsub (every kernel works in global stream indices). */
 int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain *c, int nsub);
+/* Two runs in flight (round 4; default off).  The receiver's successive batches are independent given their raw input
+ * (examples/fm/fm.hs:34-41: no stage carries a RESULT from one batch into the next -- only input samples), so with on = 1
+ * consecutive sdrhip_fm_chain_run calls alternate between two internal HIP streams and the two halves of the workspace: the
+ * memory-heavy tail kernels of run k execute beside the power-bound decimator of run k+1.  Contract while it is on:
+ *   - sdrhip_fm_chain_workspace_bytes returns twice the single-run size; pass that much to every run;
+ *   - run k starts after everything queued on the caller's `stream` at the time of the call (the producer of its input);
+ *   - when the call for run k returns, `stream` has been made to wait for run k-1 -- NOT for run k.  So consecutive runs
+ *     must write different audio buffers (double-buffer them), and run k's audio may be consumed on `stream` after the call
+ *     for run k+1, or after sdrhip_fm_chain_join(c, stream), which makes `stream` wait for every run still in flight;
+ *   - results are bit-identical to on = 0 (the same kernels on the same ranges); hipGraph capture needs on = 0.
+ * sdrhip_fm_chain_set_overlap drains the runs in flight (host-side wait) before it changes the mode. */
+int sdrhip_fm_chain_set_overlap(sdrhip_fm_chain *c, int on);
+int sdrhip_fm_chain_join(sdrhip_fm_chain *c, void *stream);
 /* fmDemod -> resampler -> audio filter (* gain) as ONE kernel (the demodulated and resampled streams never leave LDS)
  * when the chain has the FM receiver's shape (3/10 resampler with 64-float groups, 64 half-tap symmetric filter, AVX
  * order, buffers longer than one tile).  mode 0 = never (the three stage kernels), 1 = always, 2 = auto (default): only

@@ -77,6 +77,25 @@ struct sdrhip_fm_chain {
         if (!(decim.factor == 8 && decim.Lp == 128 && decim.corder == CO_L4 && !decim.h_scaled.empty())) return false;
         return !resamp.cplx && resamp.lanes == 8 && !audio.cplx && audio.sym && audio.lanes == 8 && audio.factor == 1;
     }
+    // Two runs in flight (sdrhip_fm_chain_set_overlap, round 4): consecutive runs alternate between two internal streams
+    // ("lanes") and the two halves of the workspace, so the memory-heavy tail kernels of run k execute beside the power-bound
+    // decimator of run k+1.  Consecutive runs of a stream are independent given their raw input (fm.hs:34-41: a block's
+    // audio needs nothing of the previous block's results), which is what makes this legal.
+    int overlap = 0;
+    hipStream_t lane[2] = {nullptr, nullptr};
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    bool lane_busy[2] = {false, false};
+    unsigned run_idx = 0;
+    int ensure_lanes()
+    {
+        if (lane[0]) return SDRHIP_OK;
+        for (int j = 0; j < 2; j++) {
+            SDRHIP_CHECK_HIP(hipStreamCreateWithFlags(&lane[j], hipStreamNonBlocking));
+            SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&ev_in[j], hipEventDisableTiming));
+            SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&ev_out[j], hipEventDisableTiming));
+        }
+        return SDRHIP_OK;
+    }
     hipStream_t aux = nullptr;
     std::vector<hipEvent_t> ev_k2;       // per sub-batch: decimator output ready
     hipEvent_t ev_done = nullptr;        // aux finished this run
@@ -110,6 +129,12 @@ struct sdrhip_fm_chain {
     ~sdrhip_fm_chain()
     {
         if (aux) (void)hipStreamSynchronize(aux);
+        for (int j = 0; j < 2; j++) {
+            if (lane[j]) (void)hipStreamSynchronize(lane[j]);
+            if (ev_in[j]) (void)hipEventDestroy(ev_in[j]);
+            if (ev_out[j]) (void)hipEventDestroy(ev_out[j]);
+            if (lane[j]) (void)hipStreamDestroy(lane[j]);
+        }
         for (auto ev : ev_pool) (void)hipEventDestroy(ev);
         for (auto ev : ev_k2) (void)hipEventDestroy(ev);
         if (ev_done) (void)hipEventDestroy(ev_done);
@@ -255,7 +280,8 @@ size_t sdrhip_fm_chain_workspace_bytes(const sdrhip_fm_chain* c, int64_t n_in)
     int64_t nm = nk * c->resamp.I / c->resamp.D + 4;
     // + the overlap each of the (up to 16) sub-batches recomputes and its alignment padding
     const size_t conv = c->fused_first_stage() ? 0 : align_up((size_t)(n_in + 16) * 8, 256) + 16 * align_up((size_t)(c->decim.Lp + 16) * 8, 256);
-    return conv + align_up((size_t)nk * 8, 256) + align_up((size_t)nk * 4, 256) + align_up((size_t)nm * 4, 256) + 256 + 16 * (64 << 10);
+    const size_t one = conv + align_up((size_t)nk * 8, 256) + align_up((size_t)nk * 4, 256) + align_up((size_t)nm * 4, 256) + 256 + 16 * (64 << 10);
+    return c->overlap ? 2 * align_up(one, 256) : one;      // two runs in flight: one half per lane
 }
 
 namespace {
@@ -266,7 +292,56 @@ struct SubRange {
 };
 }  // namespace
 
+static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq, int64_t s0, int64_t n_in,
+                        float* d_audio, int64_t q0, int64_t q1, void* d_workspace, size_t workspace_bytes);
+
 int sdrhip_fm_chain_run(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq, int64_t s0, int64_t n_in,
+                        float* d_audio, int64_t q0, int64_t q1, void* d_workspace, size_t workspace_bytes)
+{
+    SDRHIP_REQUIRE(c != nullptr, "sdrhip_fm_chain_run");
+    if (!c->overlap) return chain_run_on(c, stream, d_in_iq, s0, n_in, d_audio, q0, q1, d_workspace, workspace_bytes);
+    // two runs in flight: this run goes to lane j, after everything queued on the caller's stream so far (its input's
+    // producer); the caller's stream is then made to wait for the PREVIOUS run (lane 1 - j), not for this one
+    hipStream_t s = (hipStream_t)stream;
+    int rc = c->ensure_lanes();
+    if (rc != SDRHIP_OK) return rc;
+    const int j = (int)(c->run_idx++ & 1u);
+    SDRHIP_CHECK_HIP(hipEventRecord(c->ev_in[j], s));
+    SDRHIP_CHECK_HIP(hipStreamWaitEvent(c->lane[j], c->ev_in[j], 0));
+    const size_t half = (workspace_bytes / 2) & ~(size_t)255;
+    rc = chain_run_on(c, (void*)c->lane[j], d_in_iq, s0, n_in, d_audio, q0, q1, d_workspace ? (char*)d_workspace + (size_t)j * half : nullptr, half);
+    if (rc != SDRHIP_OK) return rc;
+    SDRHIP_CHECK_HIP(hipEventRecord(c->ev_out[j], c->lane[j]));
+    c->lane_busy[j] = true;
+    if (c->lane_busy[1 - j]) SDRHIP_CHECK_HIP(hipStreamWaitEvent(s, c->ev_out[1 - j], 0));
+    return SDRHIP_OK;
+}
+
+int sdrhip_fm_chain_join(sdrhip_fm_chain* c, void* stream)
+{
+    SDRHIP_REQUIRE(c != nullptr, "sdrhip_fm_chain_join");
+    for (int j = 0; j < 2; j++)
+        if (c->lane_busy[j]) {
+            SDRHIP_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, c->ev_out[j], 0));
+            c->lane_busy[j] = false;
+        }
+    return SDRHIP_OK;
+}
+
+int sdrhip_fm_chain_set_overlap(sdrhip_fm_chain* c, int on)
+{
+    SDRHIP_REQUIRE(c != nullptr && (on == 0 || on == 1), "sdrhip_fm_chain_set_overlap");
+    // switching modes with runs still in flight: drain them first (a host-side wait; this is a configuration call)
+    for (int j = 0; j < 2; j++)
+        if (c->lane_busy[j]) {
+            SDRHIP_CHECK_HIP(hipStreamSynchronize(c->lane[j]));
+            c->lane_busy[j] = false;
+        }
+    c->overlap = on;
+    return SDRHIP_OK;
+}
+
+static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq, int64_t s0, int64_t n_in,
                         float* d_audio, int64_t q0, int64_t q1, void* d_workspace, size_t workspace_bytes)
 {
     SDRHIP_REQUIRE(c != nullptr, "sdrhip_fm_chain_run");
@@ -496,8 +571,8 @@ int sdrhip_fm_chain_graph_create(sdrhip_fm_graph** out, sdrhip_fm_chain* c, cons
 {
     SDRHIP_REQUIRE(out != nullptr && c != nullptr, "sdrhip_fm_chain_graph_create");
     *out = nullptr;
-    SDRHIP_REQUIRE(!c->timing && c->nsub == 1, "sdrhip_fm_chain_graph_create: per-stage timing and sub-batch pipelining record events on the "
-                                               "chain's own streams: switch them off for a captured run");
+    SDRHIP_REQUIRE(!c->timing && c->nsub == 1 && !c->overlap, "sdrhip_fm_chain_graph_create: per-stage timing, sub-batch pipelining and two runs "
+                                               "in flight record events on the chain's own streams: switch them off for a captured run");
     sdrhip_fm_graph* g = new sdrhip_fm_graph();
     hipError_t e = hipStreamCreateWithFlags(&g->cap, hipStreamNonBlocking);
     if (e != hipSuccess) { set_error("sdrhip_fm_chain_graph_create: %s", hipGetErrorString(e)); delete g; return SDRHIP_ERR_HIP; }

@@ -126,6 +126,8 @@ lib.sdrhip_fm_chain_graph_launch.argtypes = [_vp, _vp]
 lib.sdrhip_fm_chain_graph_destroy.argtypes = [_vp]
 lib.sdrhip_fm_chain_graph_destroy.restype = None
 lib.sdrhip_fm_chain_set_pipelining.argtypes = [_vp, C.c_int]
+lib.sdrhip_fm_chain_set_overlap.argtypes = [_vp, C.c_int]
+lib.sdrhip_fm_chain_join.argtypes = [_vp, _vp]
 lib.sdrhip_fm_chain_set_fused_tail.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_set_small_chain.argtypes = [_vp, C.c_int, _i64, C.c_int]
 lib.sdrhip_debug_small_chain_launches.restype = C.c_longlong
@@ -450,6 +452,13 @@ class FmChain(_Handle):
 
     def set_pipelining(self, nsub):
         check(lib.sdrhip_fm_chain_set_pipelining(self.h, nsub), "sdrhip_fm_chain_set_pipelining")
+
+    def set_overlap(self, on):
+        """Two runs in flight: consecutive runs alternate between two internal streams and workspace halves (sdr_hip.h)."""
+        check(lib.sdrhip_fm_chain_set_overlap(self.h, 1 if on else 0), "sdrhip_fm_chain_set_overlap")
+
+    def join(self, stream=0):
+        check(lib.sdrhip_fm_chain_join(self.h, stream), "sdrhip_fm_chain_join")
 
     def set_fused_tail(self, mode=2):
         """0 = stage kernels, 1 = the fused tail kernel wherever the chain's shape allows, 2 = auto (short runs only)."""

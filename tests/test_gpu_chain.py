@@ -633,3 +633,46 @@ def test_fm_stream_many_mixed_pushes(hip):
     got = np.concatenate(got)
     assert got.size == q1 // B * B
     assert_bit_equal(got, ref[: got.size], "mixed pushes vs resident run")
+
+
+@pytest.mark.parametrize("nblk", [40, 600])
+def test_two_runs_in_flight_equal_the_single_stream(hip, nblk):
+    """sdrhip_fm_chain_set_overlap (round 4): consecutive runs alternate between two internal streams and workspace halves.
+    Seven back-to-back runs over three different inputs, audio double-buffered as the contract asks, the input of a run produced
+    on the caller's stream right before it -- bit-equal with the same runs one at a time.  nblk = 40: the one-kernel chain;
+    600: the stage kernels (systolic decimator, fmDemod, resampler, filter and their seam fix-ups)."""
+    total = nblk * B
+    chain = _chain(hip)
+    q0, q1, _ = chain.plan(0, total, total)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    inputs = [torch.randint(0, 256, (2 * total,), dtype=torch.uint8, device="cuda", generator=gen) for _ in range(3)]
+    refs = [torch.from_numpy(_run(hip, chain, x, 0, total, q0, q1)).cuda() for x in inputs]
+    chain.set_overlap(True)
+    ws_bytes = chain.workspace_bytes(total)
+    assert ws_bytes >= 2 * (chain.workspace_bytes(total) // 2)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    audio = [torch.zeros(q1 - q0, device="cuda") for _ in range(2)]
+    stage = torch.empty_like(inputs[0])
+    st = torch.cuda.current_stream()
+    checked = 0
+    order = [0, 1, 2, 2, 0, 1, 0]
+    for k, which in enumerate(order):
+        # the previous-but-one run's audio is complete on this stream now: check it before its buffer is reused
+        if k >= 2:
+            assert torch.equal(audio[k % 2].view(torch.int32), refs[order[k - 2]].view(torch.int32)), f"run {k - 2}"
+            checked += 1
+        stage_k = stage if k % 2 == 0 else inputs[which]          # every other run reads an input copied in just before it
+        if k % 2 == 0:
+            stage.copy_(inputs[which])
+        chain.run(ptr(stage_k), 0, total, ptr(audio[k % 2]), q0, q1, ptr(ws), ws_bytes, stream=st.cuda_stream)
+        if k % 2 == 0 and k + 2 < len(order):
+            # `stage` is overwritten two runs later: that copy is queued on the caller's stream, which by then waits for this run
+            pass
+    chain.join(st.cuda_stream)
+    n = len(order)
+    assert torch.equal(audio[(n - 1) % 2].view(torch.int32), refs[order[n - 1]].view(torch.int32))
+    assert torch.equal(audio[(n - 2) % 2].view(torch.int32), refs[order[n - 2]].view(torch.int32))
+    assert checked == n - 2
+    chain.set_overlap(False)
+    again = _run(hip, chain, inputs[1], 0, total, q0, q1)
+    assert np.array_equal(again.view(np.int32), refs[1].cpu().numpy().view(np.int32))

@@ -66,7 +66,8 @@ def main():
     bench = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
     # since round 3 a K2 launch is two kernels: the FULL-tile instantiation (all but at most 64 tiles) and the general one for
     # the remainder; the traffic of a launch is their sum, the kernel named is the one that moves (nearly) all of it
-    k2s = [k for k in ours if k.startswith("k_decimate_c4<") and "FETCH_SIZE" in ours[k]]
+    # since round 4 the launch is ONE kernel again, the systolic walk (whole and ragged strips in the same launch)
+    k2s = [k for k in ours if k.startswith(("k_decimate_systolic<true", "k_decimate_c4<")) and "FETCH_SIZE" in ours[k]]
     k2 = max(k2s, key=lambda k: ours[k].get("FETCH_SIZE", 0.0))
     fetch_kib = sum(ours[k].get("FETCH_SIZE", 0.0) for k in k2s)
     write_kib = sum(ours[k].get("WRITE_SIZE", 0.0) for k in k2s)
@@ -95,7 +96,8 @@ def main():
         c_f = pmc("pmc_fetch_k2c")
         c_w = pmc("pmc_write_k2c")
         # template arguments <D, P, R, NT, U8, TC, GUARD, NP, ORD>: the cfloat-in instantiation has U8 = false
-        kcs = [k for k in c_f if k.startswith("k_decimate_c4<") and k[k.index("<") + 1:].split(",")[4].strip() == "false"]
+        kcs = [k for k in c_f if k.startswith("k_decimate_systolic<false")
+               or (k.startswith("k_decimate_c4<") and k[k.index("<") + 1:].split(",")[4].strip() == "false")]
         kc = max(kcs, key=lambda k: c_f[k].get("FETCH_SIZE", 0.0))
         n_c = 1 << 27
         fk = sum(c_f[k].get("FETCH_SIZE", 0.0) for k in kcs)
@@ -105,7 +107,8 @@ def main():
                    "hbm_bytes_per_launch": 2.0 * fk * 1024.0 + wk * 1024.0, "algorithmic_bytes_per_launch": 9.0 * n_c,
                    "ratio": (2.0 * fk * 1024.0 + wk * 1024.0) / (9.0 * n_c),
                    "kernels_fast_sha256": traffic["kernels_fast_sha256"],
-                   "how": "as k2_traffic.json, over `python tools/prof_k2.py 27 f32` (cfloat IQ in, 2^27 samples per launch, no seams)"},
+                   "how": "as k2_traffic.json, over `python tools/prof_k2.py 27 f32 8192 400 200` (cfloat IQ in, 2^27 samples per launch, 8192-sample seams: the "
+                          "seam fix-up kernel's traffic is a row of its own in the pmc csv)"},
                   open(os.path.join(dst, "k2c_traffic.json"), "w"), indent=1)
     except Exception as e:          # noqa: BLE001
         print("no k2c passes:", e)
