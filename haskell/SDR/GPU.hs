@@ -38,7 +38,9 @@ module SDR.GPU (
     GpuFmChain, gpuFmChain, fmReceiverGpu
     ) where
 
+import           Control.Exception             (throwIO)
 import           Control.Monad
+import           Data.IORef
 import           Control.Monad.Primitive       (RealWorld)
 import           Data.Complex
 import qualified Data.Vector.Storable.Mutable  as VSM
@@ -83,13 +85,19 @@ foreign import ccall safe "sdrhip_pipe_set_adaptive"   c_pipe_set_adaptive :: Pt
 foreign import ccall safe "sdrhip_fm_stream_set_adaptive" c_stream_set_adaptive :: Ptr SdrStream -> CInt -> IO CInt
 -- blocks ready to pop after collecting (without waiting) what the GPU has finished: for consumers that want the audio of the
 -- block they just pushed before the next one arrives
-foreign import ccall unsafe "sdrhip_pipe_poll"      c_pipe_poll   :: Ptr SdrPipe -> IO CInt
-foreign import ccall unsafe "sdrhip_fm_stream_poll" c_stream_poll :: Ptr SdrStream -> IO CInt
+-- (`safe`: collecting a finished batch may wait on a HIP event and copies whole result batches; an `unsafe` call would hold
+-- the capability and the GC for that long)
+foreign import ccall safe "sdrhip_pipe_poll"      c_pipe_poll   :: Ptr SdrPipe -> IO CInt
+foreign import ccall safe "sdrhip_fm_stream_poll" c_stream_poll :: Ptr SdrStream -> IO CInt
 foreign import ccall safe "sdrhip_fm_chain_create"     c_chain_create      :: Ptr (Ptr SdrChain) -> CInt -> CInt -> Ptr CFloat -> CInt -> CInt -> CInt -> Ptr CFloat -> CInt -> Ptr CFloat -> CInt -> CFloat -> Int64 -> IO CInt
 foreign import ccall safe "sdrhip_fm_stream_create"    c_stream_create     :: Ptr (Ptr SdrStream) -> Ptr SdrChain -> CInt -> CInt -> IO CInt
 foreign import ccall safe "sdrhip_fm_stream_push"      c_stream_push       :: Ptr SdrStream -> Ptr CUChar -> CInt -> IO CInt
 foreign import ccall safe "sdrhip_fm_stream_pop"       c_stream_pop        :: Ptr SdrStream -> Ptr CFloat -> CInt -> IO CInt
 foreign import ccall safe "convertCAVX"                c_convertCAVX       :: CInt -> Ptr CUChar -> Ptr CFloat -> IO ()
+-- the drop-in symbols return void: a failure inside one reaches this handler instead of abort() (sdrhip_set_error_handler)
+type ErrorHandler = CInt -> CString -> IO ()
+foreign import ccall "wrapper" mkErrorHandler :: ErrorHandler -> IO (FunPtr ErrorHandler)
+foreign import ccall safe "sdrhip_set_error_handler"   c_set_error_handler :: FunPtr ErrorHandler -> IO ()
 -- the record seam (include/sdr_hip.h, "the record seam on HOST vectors"): One = the C SIMD kernel on one buffer,
 -- Cross = the sequential kernel on `drop i last ++ next` (FilterInternal.hs:397-423)
 foreign import ccall safe "sdrhip_filter_num_coeffs"    c_filter_num_coeffs    :: Ptr SdrFilter -> IO CInt
@@ -111,6 +119,25 @@ check :: CInt -> IO CInt
 check rc
     | rc < 0    = c_last_error >>= peekCString >>= \msg -> error ("sdr_hip: " ++ msg)
     | otherwise = return rc
+
+-- | Failures of the void drop-in symbols ('convertCAVX' and the @foreign import@s of SDR.FilterInternal when the
+--   reference is relinked against libsdr_hip.so): the C side records the message, calls this handler and returns to
+--   its caller; the wrapper raises after the foreign call -- the reference raises from its Pipes too (Filter.hs:526-527),
+--   it does not die.  Installed once, on first use of this module.
+{-# NOINLINE dropInFailure #-}
+dropInFailure :: IORef (Maybe String)
+dropInFailure = unsafePerformIO $ do
+    ref <- newIORef Nothing
+    h <- mkErrorHandler $ \_code msg -> peekCString msg >>= writeIORef ref . Just
+    c_set_error_handler h
+    return ref
+
+-- | Run a void drop-in call and raise if it reported a failure.
+dropIn :: IO () -> IO ()
+dropIn act = do
+    writeIORef dropInFailure Nothing
+    act
+    readIORef dropInFailure >>= maybe (return ()) (\msg -> throwIO (userError ("sdr_hip: " ++ msg)))
 
 withCoeffs :: [Float] -> (Ptr CFloat -> CInt -> IO a) -> IO a
 withCoeffs cs act = withArrayLen (map realToFrac cs) $ \n p -> act p (fromIntegral n)
@@ -258,7 +285,7 @@ interleavedIQUnsignedByteToFloatGpu :: VS.Vector CUChar -> VS.Vector (Complex Fl
 interleavedIQUnsignedByteToFloatGpu inBuf = unsafePerformIO $ do
     fp <- mallocForeignPtrArray (VS.length inBuf) :: IO (ForeignPtr CFloat)
     VS.unsafeWith inBuf $ \iPtr -> withForeignPtr fp $ \oPtr ->
-        c_convertCAVX (fromIntegral $ VS.length inBuf) iPtr oPtr
+        dropIn $ c_convertCAVX (fromIntegral $ VS.length inBuf) iPtr oPtr
     return $ VS.unsafeCast $ VS.unsafeFromForeignPtr0 fp (VS.length inBuf)
 
 -- | 'dcBlockingFilter' (Filter.hs:730-739): one output vector per input vector, the filter state

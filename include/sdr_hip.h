@@ -43,8 +43,8 @@
  * block's first "One".  seam_block = 0 means one
  * contiguous buffer: every output is "One" (what a single FFI call computes).
  *
- * Errors: drop-in symbols cannot report (void returns): on a HIP failure they
- * print to stderr and abort().  sdrhip_* return SDRHIP_OK (0) or a negative code;
+ * Errors: drop-in symbols cannot report (void returns): on a failure they call the
+ * handler of sdrhip_set_error_handler and return, or -- without one -- print to stderr and abort().  sdrhip_* return SDRHIP_OK (0) or a negative code;
  * sdrhip_last_error() returns a thread-local message.
  */
 #ifndef SDR_HIP_H
@@ -154,6 +154,13 @@ void fmDemodF(int num, float last_re, float last_im, const float *in_iq, float *
 
 const char *sdrhip_version(void);
 const char *sdrhip_last_error(void);
+/* Drop-in symbols return void, so a failure inside one (HIP error, out of memory, an argument the reference itself would
+ * index out of bounds with) cannot be reported: by default they print the message and abort().  With a handler installed
+ * (process-wide; NULL restores the default) the failing call instead records the message (sdrhip_last_error), calls
+ * handler(code, message) and -- when the handler comes back -- returns to ITS caller at once, outputs unspecified.  A Haskell
+ * host sets a flag in the handler and raises after the foreign call (haskell/SDR/GPU.hs: the reference raises from its
+ * Pipes too, Filter.hs:526-527); a C host may longjmp out of the handler instead. */
+void sdrhip_set_error_handler(void (*handler)(int code, const char *message));
 int sdrhip_device_count(void);
 int sdrhip_set_device(int dev);
 int sdrhip_device_name(char *buf, int buflen);

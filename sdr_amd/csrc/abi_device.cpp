@@ -35,6 +35,21 @@ void set_error(const char* fmt, ...)
 }
 const char* get_error() { return g_err; }
 
+static std::atomic<void (*)(int, const char*)> g_error_handler{nullptr};
+void dropin_fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    if (auto h = g_error_handler.load()) {
+        h(code, g_err);
+        throw DropinAbort{};          // the handler came back: unwind to the drop-in symbol, which returns to its caller
+    }
+    fprintf(stderr, "libsdr_hip: %s\n", g_err);
+    abort();
+}
+
 int upload_floats(float** d, const std::vector<float>& h)
 {
     *d = nullptr;
@@ -408,6 +423,7 @@ int sdrhip_set_small_launch_outputs(int outputs)
 
 const char* sdrhip_version(void) { return "sdr_hip 0.1 (gfx950)"; }
 const char* sdrhip_last_error(void) { return get_error(); }
+void sdrhip_set_error_handler(void (*handler)(int code, const char* message)) { g_error_handler.store(handler); }
 
 int sdrhip_device_count(void)
 {

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <string>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -32,20 +33,20 @@ using Ctx = ScratchCtx;
 void die_if(int rc, const char* what)
 {
     if (rc != SDRHIP_OK) {
-        fprintf(stderr, "libsdr_hip: %s: %s\n", what, sdrhip_last_error());
-        abort();
+        const std::string why = sdrhip_last_error();
+        dropin_fail(rc, "%s: %s", what, why.c_str());
     }
 }
 
-// a leased context or abort(): the drop-in symbols cannot report
+// a leased context or dropin_fail(): the drop-in symbols cannot report
 struct Lease {
     ScratchLease l;
     Ctx* c;
     Lease() : c(l.c)
     {
         if (!c) {
-            fprintf(stderr, "libsdr_hip: %s\n", sdrhip_last_error());
-            abort();
+            const std::string why = sdrhip_last_error();
+            dropin_fail(SDRHIP_ERR_HIP, "%s", why.c_str());
         }
     }
 };
@@ -110,7 +111,7 @@ Geom flat_geom(int num, int D, int Lp)
 
 // real taps, real data
 void fir_real(int lanes, bool sym, int num, int factor, int numCoeffs, float* coeffs, float* in, float* out)
-{
+try {
     if (num <= 0) return;
     Lease l;
     Ctx& c = *l.c;
@@ -122,11 +123,11 @@ void fir_real(int lanes, bool sym, int num, int factor, int numCoeffs, float* co
     float* d_out = (float*)stage_out(c, direct, (size_t)num * 4);
     launch_fir_real(c.stream, flat_geom(num, factor, span), lanes, sym, d_taps, numCoeffs, nullptr, d_in, d_out);
     finish(c, direct, out, (size_t)num * 4);
-}
+} catch (const DropinAbort&) {}
 
 // real taps, complex data.  numCoeffs is the length of the array as passed.
 void fir_cplx(ComplexOrder order, bool sym, int num, int factor, int numCoeffs, float* coeffs, float* in, float* out)
-{
+try {
     if (num <= 0) return;
     Lease l;
     Ctx& c = *l.c;
@@ -155,12 +156,12 @@ void fir_cplx(ComplexOrder order, bool sym, int num, int factor, int numCoeffs, 
         launch_fir_cplx(c.stream, g, order, sym, d_taps, numCoeffs, nullptr, d_in, d_out);
     }
     finish(c, direct, out, (size_t)num * 8);
-}
+} catch (const DropinAbort&) {}
 
 // polyphase resamplers (resample.c:34-142)
 int resample_groups(bool cplx, int lanes_or_order, int buf_size, int num_coeffs, int starting_group, int num_groups,
                     int* increments, float** coeffs, float* in, float* out)
-{
+try {
     if (num_groups <= 0) return starting_group;       // the reference's loop would divide by zero: nothing to compute
     int end_group = (int)(((int64_t)starting_group + (buf_size > 0 ? buf_size : 0)) % num_groups);
     if (buf_size <= 0) return starting_group;
@@ -214,11 +215,11 @@ int resample_groups(bool cplx, int lanes_or_order, int buf_size, int num_coeffs,
     else launch_resample_real(c.stream, g, simd, t, d_taps, nullptr, d_in, d_out);
     finish(c, direct, out, (size_t)buf_size * esz);
     return end_group;
-}
+} catch (const DropinAbort&) { return starting_group; }
 
 template <class Fn>
 void elementwise(const void* in, size_t in_bytes, void* out, size_t out_bytes, Fn launch)
-{
+try {
     Lease l;
     Ctx& c = *l.c;
     const bool direct = fits_direct(in_bytes, out_bytes);
@@ -226,7 +227,7 @@ void elementwise(const void* in, size_t in_bytes, void* out, size_t out_bytes, F
     void* d_out = stage_out(c, direct, out_bytes);
     launch(c.stream, d_in, d_out);
     finish(c, direct, out, out_bytes);
-}
+} catch (const DropinAbort&) {}
 
 }  // namespace
 
@@ -286,7 +287,7 @@ void filterAVXSymmetricRC(int num, int numCoeffs, float* c, float* in, float* ou
 
 void dcBlocker(int num, float lastSample, float lastOutput, float* finalSample, float* finalOutput, float* inBuf,
                float* outBuf)
-{
+try {
     if (num <= 0) {
         *finalSample = lastSample;
         *finalOutput = lastOutput;
@@ -313,7 +314,7 @@ void dcBlocker(int num, float lastSample, float lastOutput, float* finalSample, 
     }
     *finalSample = fin[0];
     *finalOutput = fin[1];
-}
+} catch (const DropinAbort&) {}
 
 // ---- decimate.c ---------------------------------------------------------------------
 void decimateRR(int num, int factor, int numCoeffs, float* c, float* in, float* out) { fir_real(1, false, num, factor, numCoeffs, c, in, out); }
@@ -334,12 +335,11 @@ void decimateAVXSymmetricRC(int num, int factor, int numCoeffs, float* c, float*
 // recurrence from `filter_offset`.
 void resampleRR(int buf_size, int coeff_size, int interpolation, int decimation, int filter_offset, float* coeffs,
                 float* in_buf, float* out_buf)
-{
+try {
     if (buf_size <= 0) return;
     if (interpolation < 1 || decimation <= interpolation || filter_offset < 0 || filter_offset >= interpolation) {
         // outside these the reference's own recurrence (resample.c:16-32) indexes before its arrays
-        fprintf(stderr, "libsdr_hip: resampleRR: need 1 <= interpolation < decimation and 0 <= filter_offset < interpolation\n");
-        abort();
+        dropin_fail(SDRHIP_ERR_ARG, "resampleRR: need 1 <= interpolation < decimation and 0 <= filter_offset < interpolation");
     }
     Lease l;
     Ctx& c = *l.c;
@@ -382,7 +382,7 @@ void resampleRR(int buf_size, int coeff_size, int interpolation, int decimation,
     g.I = interpolation;
     launch_resample_real(c.stream, g, 1, t, nullptr, d_taps, d_in, d_out);
     finish(c, direct, out_buf, (size_t)buf_size * 4);
-}
+} catch (const DropinAbort&) {}
 
 int resample2RR(int n, int nc, int sg, int ng, int* inc, float** c, float* in, float* out) { return resample_groups(false, 1, n, nc, sg, ng, inc, c, in, out); }
 int resampleSSERR(int n, int nc, int sg, int ng, int* inc, float** c, float* in, float* out) { return resample_groups(false, 4, n, nc, sg, ng, inc, c, in, out); }

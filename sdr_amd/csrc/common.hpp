@@ -31,14 +31,16 @@ const char* get_error();
         }                                                                \
     } while (0)
 
-// abort()-style check for the void-returning drop-in symbols
+// Failure inside a drop-in symbol (void returns: they cannot report).  dropin_fail records the message (sdrhip_last_error),
+// then calls the process-wide handler installed with sdrhip_set_error_handler and unwinds to the extern "C" boundary, which
+// returns to the caller with the outputs unspecified; without a handler it prints and abort()s, as rounds 1-3 did.
+struct DropinAbort {};
+[[noreturn]] void dropin_fail(int code, const char* fmt, ...);
 #define SDRHIP_DIE_HIP(expr)                                                                         \
     do {                                                                                             \
         hipError_t _e = (expr);                                                                      \
-        if (_e != hipSuccess) {                                                                      \
-            fprintf(stderr, "libsdr_hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-            abort();                                                                                 \
-        }                                                                                            \
+        if (_e != hipSuccess)                                                                        \
+            ::sdrhip::dropin_fail(SDRHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
 inline int round_up(int n, int d) { return ((n + d - 1) / d) * d; }

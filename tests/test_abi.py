@@ -27,7 +27,7 @@ def declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)
-    skip = {"defined", "sizeof"}
+    skip = {"defined", "sizeof", "void"}      # `void (*handler)(...)`: a function-pointer parameter, not a function
     return sorted({n for n in names if n not in skip and not n.isupper()})
 
 
@@ -162,3 +162,33 @@ def test_round2_entry_points_fail_loudly_without_a_gpu(L):
     ch = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, 8192)
     h = ch.halo_samples()
     assert h % 8 == 0 and ch.max_halo() <= h < ch.max_halo() + 8
+
+
+def test_drop_in_failures_reach_the_error_handler_instead_of_abort(L):
+    """sdrhip_set_error_handler (round 4): a failure inside a void drop-in symbol calls the handler and returns to the caller
+    (default without a handler: print + abort(), which this very test would not survive).  resampleRR's argument check needs
+    no GPU: interpolation 0 is outside what the reference's own recurrence can index (resample.c:16-32)."""
+    seen = []
+    HANDLER = C.CFUNCTYPE(None, C.c_int, C.c_char_p)
+    cb = HANDLER(lambda code, msg: seen.append((code, msg.decode())))
+    L.lib.sdrhip_set_error_handler.argtypes = [HANDLER]
+    L.lib.sdrhip_set_error_handler.restype = None
+    L.lib.sdrhip_set_error_handler(cb)
+    try:
+        x = np.zeros(64, np.float32)
+        y = np.full(8, 7.0, np.float32)
+        fp = C.POINTER(C.c_float)
+        L.lib.resampleRR.argtypes = [C.c_int] * 5 + [fp] * 3
+        L.lib.resampleRR.restype = None
+        L.lib.resampleRR(8, 4, 0, 3, 0, x.ctypes.data_as(fp), x.ctypes.data_as(fp), y.ctypes.data_as(fp))
+        assert len(seen) == 1 and seen[0][0] == -1 and "resampleRR" in seen[0][1], seen       # SDRHIP_ERR_ARG
+        assert "resampleRR" in L.lib.sdrhip_last_error().decode()
+        assert (y == 7.0).all()                       # returned at once: nothing computed, nothing written
+        # without a device every other drop-in symbol fails at its first HIP call: same route
+        if L.device_count() == 0:
+            L.lib.scale.argtypes = [C.c_int, C.c_float, fp, fp]
+            L.lib.scale.restype = None
+            L.lib.scale(8, 2.0, x.ctypes.data_as(fp), y.ctypes.data_as(fp))
+            assert len(seen) == 2 and seen[1][0] != 0
+    finally:
+        L.lib.sdrhip_set_error_handler(HANDLER())     # NULL: back to print + abort()
