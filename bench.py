@@ -144,7 +144,7 @@ def plumbing_check(args, rank, world):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
     chain = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), gain=0.2, block=BLOCK)
-    S_len = min(args.blocks, 16) * BLOCK
+    S_len = min(args.blocks, 128) * BLOCK                            # up to BASELINE configs[4]'s shard: 2^20 samples per rank
     plan = sharding.ShardPlan(chain, rank, world, S_len)
     stream = S.iq_u8(world * S_len + plan.halo_cap)                # the same global stream on every rank
     buf = torch.zeros(2 * plan.n_in, dtype=torch.uint8)
@@ -157,17 +157,22 @@ def plumbing_check(args, rank, world):
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     right0 = ((rank + 1) % world) * S_len
     ok = bool(np.array_equal(buf[2 * S_len:].numpy(), stream[2 * right0:2 * (right0 + plan.halo_cap)])) or world == 1
-    plans = [(plan.q0, plan.q1, ok)]
+    mine = (plan.q0, plan.q1, ok, float(el.item()))
+    plans = [mine]
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         plans = [None] * world
-        dist.all_gather_object(plans, (plan.q0, plan.q1, ok))
+        dist.all_gather_object(plans, mine)
     if rank == 0:
         tiles = all(a[1] == b[0] for a, b in zip(plans[:-1], plans[1:]))
         print(json.dumps({"plumbing_only": True, "metric": "none (BENCH_PLUMBING=1: launch, plans and halo exchange only, no device work)",
                           "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks_seen": len(plans),
                           "halo_ok_on_every_rank": all(p[2] for p in plans), "owned_outputs_tile_the_stream": tiles,
-                          "halo_transport": "host memory through gloo", "seconds": round(float(el.item()), 4)}))
+                          "halo_transport": "host memory through gloo", "seconds": round(float(el.item()), 4),
+                          "samples_per_rank": S_len, "halo_samples": plan.halo_cap,
+                          # a shard's first audio output rarely starts a polyphase cycle: the resampler's group (phase) of q0
+                          "resampler_group_of_first_output_per_rank": [p[0] % 3 for p in plans],
+                          "seconds_per_rank": [round(p[3], 4) for p in plans]}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -444,7 +449,10 @@ def main():
         if timing:
             stage_ms, runs = chain.read_timing()
             chain.enable_timing(False)
+        rank_elapsed = [elapsed]
         if world > 1:
+            rank_elapsed = [None] * world
+            dist.all_gather_object(rank_elapsed, elapsed)
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -459,7 +467,7 @@ def main():
         del g_all, g_a, g_b
         del buf, audio, ws
         return {"elapsed": elapsed, "passes": passes, "stage_ms": stage_ms, "plan": plan, "S_len": S_len, "overlap": overlap, "crc": crc,
-                "lib_overlap": lib_overlap, "same_audio": same_audio}
+                "lib_overlap": lib_overlap, "same_audio": same_audio, "rank_elapsed": rank_elapsed}
 
     def measure_in_flight(blocks, steps, warmup, nflight, do_exchange=True):
         """Launch-bound shards: `nflight` passes in flight, pass i on HIP stream i % nflight with its own input / audio
@@ -830,6 +838,20 @@ def main():
                 dbg(f"host {name} done")
             except Exception as e:                      # noqa: BLE001
                 host[name] = f"failed: {e!r}"
+        # latency, which is what a real-time 1.28 MS/s source cares about (examples/fm/fm.hs:24; the reference plays the audio through
+        # pulse, Pulse.hs:28): one 8192-sample block per push, the time from the push call to the pop of the audio it completed
+        try:
+            host["push_to_audio_us"] = {
+                "paced_1.28_MS_per_s": H.fm_stream_latency(L, chain, BLOCK, 300, pace_us=6400.0),
+                "paced_1.28_MS_per_s_every_push_its_own_launch": H.fm_stream_latency(L, chain, BLOCK, 300, pace_us=6400.0, adaptive_off=True),
+                "unpaced_adaptive": H.fm_stream_latency(L, chain, BLOCK, 4000),
+                "unpaced_every_push_its_own_launch": H.fm_stream_latency(L, chain, BLOCK, 2000, adaptive_off=True),
+                "what": "sdrhip_bench_fm_stream_latency: audio leaves in 256-sample blocks, each charged to the push that made it computable; "
+                        "paced = one push every 6.4 ms with the consumer polling in between (the GPU is idle when a push arrives: the figure is "
+                        "launch + run + the result's way back); unpaced = pushes back to back (results lag behind by the submissions in flight, "
+                        "and adaptive submission trades latency for throughput: fm_stream_1_block_per_push above is THAT run's throughput)"}
+        except Exception as e:                          # noqa: BLE001
+            host["push_to_audio_us"] = f"failed: {e!r}"
         try:
             res = L.Resampler(3, 10, S.taps_resamp191(), L.ORDER_AVX)
             pp = L.Pipe("resampler", res, BLOCK)
@@ -928,6 +950,12 @@ def main():
             "two_passes_in_flight": main_two,
             "shard_1M_samples_per_gpu": shard_1m,
             "without_halo_exchange": replicas,
+            # N > 1: how to read the line on its own -- the ranks' own clocks around the timed region (ms per pass; `value` uses the
+            # slowest) and the share of the trivially-parallel bound (the same passes without the exchange) that survives it
+            **({"per_rank_ms_per_pass": [round(e / (args.steps * passes) * 1e3, 4) for e in main_run["rank_elapsed"]],
+                "scaling_efficiency": round((total_samples / elapsed / 1e6) / replicas["value"], 4) if replicas and replicas.get("value") else None,
+                "scaling_efficiency_what": "value / without_halo_exchange.value: 1.0 = the halo exchange costs nothing; the driver's own "
+                                           "efficiency (value at N over N x value at 1) needs the N = 1 run"} if world > 1 else {}),
             "host_streamed": host,
             "power": power,
             "cpu_baseline": cpu,

@@ -473,7 +473,7 @@ int sdrhip_fm_stream_pop(sdrhip_fm_stream *st, float *out, int capacity);
  * save: drains the operator and writes the state (*used = its size);
  * restore: into a freshly created stream over a chain of the same taps and block sizes; returns the number of audio blocks
  * ready to pop.  A restored stream fed the remaining samples yields the audio the uninterrupted stream would have. */
-size_t sdrhip_fm_stream_state_bytes(const sdrhip_fm_stream *st);
+size_t sdrhip_fm_stream_state_bytes(sdrhip_fm_stream *st);   /* not const: it drains (submits, waits, moves results) */
 int sdrhip_fm_stream_save(sdrhip_fm_stream *st, void *buf, size_t capacity, size_t *used);
 int sdrhip_fm_stream_restore(sdrhip_fm_stream *st, const void *buf, size_t bytes);
 
@@ -508,6 +508,9 @@ int sdrhip_bench_copy2(void *stream, const void *d_in, void *d_out, size_t bytes
 struct sdrhip_pipe;
 int sdrhip_bench_fm_stream(sdrhip_fm_chain *chain, int n_samples, int pushes, int zero_copy, int coalesce_samples,
                            double *samples_per_s, long long *audio_blocks);
+/* push-to-audio latency of sdrhip_fm_stream (bench_host.cpp): out[0..4] = p50, p99, max, mean latency and the mean duration of
+ * the push call, microseconds; pace_us > 0 paces the pushes like a real-time source (6400 us per 8192 samples at 1.28 MS/s) */
+int sdrhip_bench_fm_stream_latency(sdrhip_fm_chain *chain, int n_samples, int pushes, double pace_us, int adaptive_off, double *out);
 int sdrhip_bench_pipe(struct sdrhip_pipe *p, int n, int floats_per_element, int block_size_out, int pushes, int zero_copy,
                       double *elements_per_s);
 /* the FM receiver composed of four Level-1 Pipes the way examples/fm/fm.hs:34-41 composes it (firDecimator -> fmDemod ->
@@ -536,10 +539,12 @@ int sdrhip_pipe_push(sdrhip_pipe *p, const float *block, int n);
 /* Throughput knobs of the filter / decimator / resampler pipes (results never depend on them):
  *  - set_coalesce(blocks): equal-sized pushes are staged in the pinned buffer and submitted `blocks` at a
  *    time (one upload, one run over the batch with its interior seams, one download); a push of another
- *    size ends the uniform run.  0 / 1 = every push on its own.
+ *    size ends the uniform run.  0 / 1 = every push on its own.  blocks > 1 takes precedence over adaptive submission
+ *    (exactly `blocks` per submission, whatever the GPU is doing).
  *  - set_adaptive(max_blocks): the same, decided by the GPU: a push is submitted at once while the slot its submission would
  *    move on to is free, and staged behind the earlier ones while that slot is still running (up to max_blocks, and never more
- *    than is read in place over PCIe: 512 KiB); a source slower than the GPU sees every push go out immediately, a faster
+ *    than 4 MiB of staged input (SDRHIP_ADAPTIVE_BYTES; batches past 512 KiB go through the copy engines instead of being read
+ *    in place over PCIe); a source slower than the GPU sees every push go out immediately, a faster
  *    one sees fewer, larger launches.  Which push returns which block then depends on timing.  0 = off.
  *  - input_buffer(n): the pinned staging memory the next push of n elements will be uploaded from; fill it
  *    and push that pointer to skip the host-side copy. */
@@ -555,7 +560,7 @@ int sdrhip_pipe_pop(sdrhip_pipe *p, float *out, int capacity);
  * the last few input elements, the carried fmDemod sample / dcBlocker pair, the output not yet popped; restore loads it into a
  * freshly created pipe of the same kind over a descriptor of the same taps; returns the blocks ready to pop. */
 /* state_bytes drains the pipe (like flush) and returns the exact size the save that follows needs (0 = the drain failed). */
-size_t sdrhip_pipe_state_bytes(const sdrhip_pipe *p);
+size_t sdrhip_pipe_state_bytes(sdrhip_pipe *p);   /* not const: it drains (submits, waits, moves results) */
 int sdrhip_pipe_save(sdrhip_pipe *p, void *buf, size_t capacity, size_t *used);
 int sdrhip_pipe_restore(sdrhip_pipe *p, const void *buf, size_t bytes);
 void sdrhip_pipe_destroy(sdrhip_pipe *p);

@@ -4,6 +4,7 @@
 // block size (8192 samples) is as much as the work itself.
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <vector>
 
@@ -64,6 +65,79 @@ int sdrhip_bench_fm_stream(sdrhip_fm_chain* chain, int n_samples, int pushes, in
     *samples_per_s = (double)n_samples * pushes / dt;
     if (audio_blocks) *audio_blocks = blocks;
     sdrhip_fm_stream_destroy(st);
+    return SDRHIP_OK;
+}
+
+// Push-to-audio LATENCY of sdrhip_fm_stream (round 4): `pushes` pushes of `n_samples` u8 IQ samples; audio leaves the operator
+// in blocks of 256 samples (every push of 8192 samples completes at least one), and every popped block is charged to the push
+// that made it computable (sdrhip_fm_chain_ready): latency = host time of the pop - host time at which that push was called.
+// pace_us > 0: one push every pace_us microseconds (a 1.28 MS/s source delivers 8192 samples every 6400 us), polling for the
+// audio in between, as a real-time consumer would; 0: back to back, collecting what is ready at every push (results then lag
+// behind by the submissions in flight).  adaptive_off: every push its own submission.  out[0..4] = p50, p99, max, mean latency
+// and mean duration of the push call itself, all in microseconds.
+int sdrhip_bench_fm_stream_latency(sdrhip_fm_chain* chain, int n_samples, int pushes, double pace_us, int adaptive_off, double* out)
+{
+    SDRHIP_REQUIRE(chain != nullptr && n_samples > 0 && pushes > 8 && out != nullptr, "sdrhip_bench_fm_stream_latency");
+    sdrhip_fm_stream* st = nullptr;
+    constexpr int kOut = 256;
+    int rc = sdrhip_fm_stream_create(&st, chain, n_samples, kOut);
+    if (rc != SDRHIP_OK) return rc;
+    if (adaptive_off && (rc = sdrhip_fm_stream_set_adaptive(st, 0)) != SDRHIP_OK) { sdrhip_fm_stream_destroy(st); return rc; }
+    std::vector<uint8_t> src((size_t)2 * n_samples);
+    uint32_t sd = 99u;
+    for (auto& b : src) { sd = sd * 1664525u + 1013904223u; b = (uint8_t)(sd >> 24); }
+    using clk = std::chrono::steady_clock;
+    const int warm = 32;
+    std::vector<clk::time_point> t_push((size_t)warm + pushes);
+    std::vector<int64_t> blocks_after((size_t)warm + pushes);       // audio blocks computable once push i is in
+    for (int i = 0; i < warm + pushes; i++) blocks_after[i] = sdrhip_fm_chain_ready(chain, (int64_t)(i + 1) * n_samples) / kOut;
+    std::vector<double> lat;
+    lat.reserve((size_t)pushes * 2);
+    std::vector<float> blk(kOut);
+    int64_t popped = 0;
+    size_t owner = 0;                                               // first push whose blocks_after exceeds `popped`
+    double push_call_us = 0.0;
+    auto collect = [&](int ready) {
+        const auto now = clk::now();
+        while (ready-- > 0) {
+            if (sdrhip_fm_stream_pop(st, blk.data(), kOut) <= 0) break;
+            while (owner < blocks_after.size() && blocks_after[owner] <= popped) owner++;
+            if (owner < blocks_after.size() && owner >= (size_t)warm) lat.push_back(std::chrono::duration<double, std::micro>(now - t_push[owner]).count());
+            popped++;
+        }
+    };
+    const auto t_start = clk::now();
+    for (int i = 0; i < warm + pushes; i++) {
+        if (pace_us > 0) {
+            const auto due = t_start + std::chrono::duration_cast<clk::duration>(std::chrono::duration<double, std::micro>(pace_us * i));
+            // a real-time consumer polls for audio while it waits for the next block of the source
+            while (clk::now() < due) {
+                const int r = sdrhip_fm_stream_poll(st);
+                if (r < 0) { sdrhip_fm_stream_destroy(st); return r; }
+                collect(r);
+            }
+        }
+        t_push[i] = clk::now();
+        const int r = sdrhip_fm_stream_push(st, src.data(), n_samples);
+        if (r < 0) { sdrhip_fm_stream_destroy(st); return r; }
+        if (i >= warm) push_call_us += std::chrono::duration<double, std::micro>(clk::now() - t_push[i]).count();
+        collect(r);
+    }
+    {
+        const int r = sdrhip_fm_stream_flush(st);
+        if (r < 0) { sdrhip_fm_stream_destroy(st); return r; }
+        collect(r);
+    }
+    sdrhip_fm_stream_destroy(st);
+    if (lat.empty()) { set_error("sdrhip_bench_fm_stream_latency: no audio block came back"); return SDRHIP_ERR_STATE; }
+    std::sort(lat.begin(), lat.end());
+    double mean = 0.0;
+    for (double v : lat) mean += v;
+    out[0] = lat[lat.size() / 2];
+    out[1] = lat[(size_t)((lat.size() - 1) * 0.99)];
+    out[2] = lat.back();
+    out[3] = mean / (double)lat.size();
+    out[4] = push_call_us / pushes;
     return SDRHIP_OK;
 }
 

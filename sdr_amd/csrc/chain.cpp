@@ -975,7 +975,7 @@ int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
     if (iq != dst) memcpy(dst, iq, (size_t)n * 2);   // else: the caller filled our staging buffer in place
     st->staged += n;
     bool submit = st->staged >= st->coalesce;
-    if (st->adaptive > 0 && submit) {
+    if (st->adaptive > 0 && st->coalesce == 0 && submit) {     // an explicit set_coalesce takes precedence: fixed batches
         // a GPU that keeps up gets every push at once (lowest latency); one that is still busy with the slot this submission
         // would move on to lets the pushes pile up in the staging buffer and takes them as ONE launch when it frees up
         const bool room = st->staged + st->max_block <= st->capacity();
@@ -1024,11 +1024,10 @@ struct StreamStateHeader {
 constexpr uint32_t kStateMagic = 0x53444d46u;   // "FMDS"
 }  // namespace
 
-size_t sdrhip_fm_stream_state_bytes(const sdrhip_fm_stream* cst)
+size_t sdrhip_fm_stream_state_bytes(sdrhip_fm_stream* st)
 {
-    if (cst == nullptr) return 0;
+    if (st == nullptr) return 0;
     // exact: drains the operator exactly as sdrhip_fm_stream_save will (0 = the drain failed, sdrhip_last_error)
-    sdrhip_fm_stream* st = const_cast<sdrhip_fm_stream*>(cst);
     if (sdrhip_fm_stream_flush(st) < 0) return 0;
     return sizeof(StreamStateHeader) + (size_t)(2 * st->hist_n) + (st->fifo.size() - st->head) * sizeof(float);
 }

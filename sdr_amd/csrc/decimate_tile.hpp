@@ -19,7 +19,10 @@ struct Tile {
     static_assert(CHUNK % 2 == 0, "chunk must hold whole float4s");
     // padded LDS layout: 2 float2 of padding after every CHUNK samples
     __host__ __device__ static constexpr int lds_idx(int s) { return s + 2 * (s / CHUNK); }
-    static constexpr int LDS_F2 = SPAN + 2 * (SPAN / CHUNK) + 2;
+    // + 8 float2 of slack: the last thread's final sample-block prefetch of mac_window (blocks of up to 8 samples, NB = ceil(WIN / TC))
+    // may reach past SPAN when D is not a multiple of the block (the D = 1 filter tiles); the values are never used (taps >= P are
+    // skipped) but the reads must stay inside the allocation
+    static constexpr int LDS_F2 = SPAN + 2 * (SPAN / CHUNK) + 2 + 8;
     static constexpr size_t LDS_BYTES = (size_t)LDS_F2 * 8;
 };
 
@@ -58,7 +61,7 @@ __device__ __forceinline__ void mac_window(const float2* __restrict__ win, const
     static_assert(P % TC == 0, "taps are walked in blocks of TC");
     // the guarded walk pairs whole tap chunks with whole sample blocks: decimation a multiple of TC.  The exact-length walk
     // takes any decimation, D = 1 (a FILTER: R consecutive outputs per thread, a sample meets up to R taps) included; its
-    // last sample block may then reach past the window (taps >= P are skipped, the reads stay inside the tile's padding)
+    // last sample block may then reach past the window (taps >= P are skipped, the reads stay inside the tile's slack: Tile::LDS_F2)
     static_assert(!GUARD || (T::WIN % TC == 0 && D % TC == 0), "the guarded walk pairs tap chunks with sample blocks");
     static_assert(TC % NP == 0 || NP % TC == 0, "partial of a tap = its index mod NP");
     static_assert(!GUARD || TC % NP == 0, "the guarded walk derives the partial from the index inside the chunk");

@@ -72,9 +72,11 @@ struct sdrhip_pipe {
     int adaptive = getenv("SDRHIP_STREAM_ADAPTIVE") ? atoi(getenv("SDRHIP_STREAM_ADAPTIVE")) : kAdaptiveBlocks;
     static constexpr int kAdaptiveBlocks = 32;
     // blocks per submission in force for blocks of `uni` elements: the adaptive cap stays inside what is read in place
+    // an explicit sdrhip_pipe_set_coalesce(p, N > 1) takes precedence: exactly N blocks per submission, as documented
+    bool adaptive_on() const { return adaptive > 1 && coalesce <= 1; }
     int coalesce_eff(int uni) const
     {
-        if (adaptive > 1 && uni > 0) {
+        if (adaptive_on() && uni > 0) {
             const int64_t esz = (int64_t)(cplx_in ? 2 : 1) * 4;
             // (measured, 8192-sample cfloat blocks into firDecimator: batches of up to 0.5 / 1 / 4 / 16 MiB -> 2.7 / 2.3-3.0 /
             // 3.0-4.9 / 3.7-4.8 G elements/s; batches past kDirectBytes go through the copy engines)
@@ -409,7 +411,7 @@ static int fir_like_push(sdrhip_pipe* p, const float* block, int n)
         // outputs alike; otherwise (ragged blocks) the two-part submission
         if ((rc = fir_submit(p, p->staged, p->all_uniform ? p->uniform_n : 0)) != SDRHIP_OK) return rc;
     } else if (p->staged >= (int64_t)ce * p->uniform_n ||
-               (p->adaptive > 1 && !p->in_flight((p->cur_slot() + 1) % p->nslots))) {
+               (p->adaptive_on() && !p->in_flight((p->cur_slot() + 1) % p->nslots))) {
         // (adaptive: a GPU that keeps up gets every push at once; one still busy with the slot this submission would move on
         // to lets the blocks pile up in the staging buffer and takes them as one launch when it frees up)
         if ((rc = fir_submit(p, p->staged, p->uniform_n)) != SDRHIP_OK) return rc;
@@ -569,14 +571,17 @@ static int map_push(sdrhip_pipe* p, const float* block, int n)
     if (p->staged == 0) {
         // the slot's previous submission: results harvested, staging buffer no longer read (in place: the same event)
         if ((rc = harvest(p, p->cur_slot())) != SDRHIP_OK) return rc;
-        const size_t want = (size_t)n * ein > (size_t)cap_bytes ? (size_t)n * ein : (size_t)cap_bytes;
+        // room for what may pile up, sized by the blocks this pipe actually sees (not the whole cap for tiny blocks)
+        const int64_t pile = p->adaptive > 1 ? (int64_t)p->adaptive * (int64_t)n * (int64_t)ein : 0;
+        const size_t want_cap = (size_t)(pile < cap_bytes ? pile : cap_bytes);
+        const size_t want = (size_t)n * ein > want_cap ? (size_t)n * ein : want_cap;
         if ((rc = sl.hin.ensure(want)) != SDRHIP_OK) return rc;
     }
     memcpy((char*)sl.hin.p + (size_t)p->staged * ein, block, (size_t)n * ein);
     p->staged += n;
     p->demod_blocks.push_back(n);
     const int64_t pushes_before = p->pushes;
-    const bool room = (int64_t)(p->staged + n) * (int64_t)ein <= cap_bytes;
+    const bool room = (int64_t)(p->staged + n) * (int64_t)ein <= cap_bytes && (size_t)(p->staged + n) * ein <= sl.hin.cap;
     if (!room || !p->in_flight((p->cur_slot() + 1) % p->nslots)) {
         if ((rc = map_submit(p)) != SDRHIP_OK) return rc;
     }
@@ -671,13 +676,12 @@ struct PipeStateHeader {
 constexpr uint32_t kPipeMagic = 0x50504453u;   // "SDPP"
 }  // namespace
 
-size_t sdrhip_pipe_state_bytes(const sdrhip_pipe* cp)
+size_t sdrhip_pipe_state_bytes(sdrhip_pipe* p)
 {
-    if (cp == nullptr) return 0;
+    if (p == nullptr) return 0;
     // Exact, not an estimate: the pipe is drained here exactly as sdrhip_pipe_save will drain it (what is staged goes out, both
     // slots are harvested into the fifo), so the size returned is what the save that follows needs -- whatever the ratio of
     // the stage and the size of the blocks in flight.  0 = the drain failed (sdrhip_last_error).
-    sdrhip_pipe* p = const_cast<sdrhip_pipe*>(cp);
     if (sdrhip_pipe_flush(p) < 0) return 0;
     return sizeof(PipeStateHeader) + (size_t)p->hist_n * p->esz_in() * sizeof(float) + p->fifo_size() * sizeof(float) +
            p->demod_blocks.size() * sizeof(int32_t);

@@ -170,6 +170,7 @@ lib.sdrhip_bench_stream_8to1.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]
 lib.sdrhip_bench_copy.argtypes = [_vp, _vp, _vp, C.c_size_t]
 lib.sdrhip_bench_copy2.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]
 lib.sdrhip_bench_fm_stream.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+lib.sdrhip_bench_fm_stream_latency.argtypes = [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double)]
 lib.sdrhip_bench_pipe.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
 lib.sdrhip_bench_fm_pipes.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
 lib.sdrhip_debug_tiled_launches.argtypes = []

@@ -50,6 +50,24 @@ def test_gpus_n_starts_n_ranks_by_itself():
     assert r["plumbing_only"] is True and r["value"] is None  # never mistaken for a measurement
 
 
+def test_eight_ranks_at_the_shard_size_of_baseline_config_4():
+    """BASELINE configs[4] as far as a box without GPUs goes (VERDICT r03 "next" #7): `python bench.py --gpus 8` starts eight ranks,
+    each owning a 2^20-sample shard; the library's plans tile the stream, every rank receives its right neighbour's head, and most
+    shards start in the middle of a polyphase cycle of the 3/10 resampler."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["BENCH_PLUMBING"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--blocks", "128", "--steps", "2", "--warmup", "1", "--no-extras"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["ranks_seen"] == 8 and r["samples_per_rank"] == 1 << 20
+    assert r["halo_ok_on_every_rank"] and r["owned_outputs_tile_the_stream"]
+    assert len(r["seconds_per_rank"]) == 8
+    assert sum(1 for g in r["resampler_group_of_first_output_per_rank"] if g != 0) >= 4, r["resampler_group_of_first_output_per_rank"]
+
+
 def test_world_size_that_disagrees_with_gpus_is_refused():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BENCH_PLUMBING="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-extras"],

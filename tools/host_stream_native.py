@@ -13,6 +13,14 @@ def fm_stream_rate(L, chain, n_samples, pushes, zero_copy=True, coalesce=0):
     return sps.value, blocks.value
 
 
+def fm_stream_latency(L, chain, n_samples, pushes, pace_us=0.0, adaptive_off=False):
+    """p50 / p99 / max / mean push-to-audio latency and the mean push call, microseconds (sdrhip_bench_fm_stream_latency)."""
+    out = (C.c_double * 5)()
+    L.check(L.lib.sdrhip_bench_fm_stream_latency(chain.h, n_samples, pushes, float(pace_us), int(adaptive_off), out), "sdrhip_bench_fm_stream_latency")
+    return {"p50_us": round(out[0], 1), "p99_us": round(out[1], 1), "max_us": round(out[2], 1), "mean_us": round(out[3], 1),
+            "push_call_us": round(out[4], 2)}
+
+
 def pipe_rate(L, pipe_handle, n, floats_per_element, block_out, pushes, zero_copy=True):
     eps = C.c_double()
     L.check(L.lib.sdrhip_bench_pipe(pipe_handle, n, floats_per_element, block_out, pushes, int(zero_copy), C.byref(eps)), "sdrhip_bench_pipe")
