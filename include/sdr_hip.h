@@ -376,6 +376,14 @@ void sdrhip_debug_set_full_tiles(int on);
  * SDRHIP_SYSTOLIC=0/1 sets the initial value.  sdrhip_debug_systolic_launches: launches it has served, process-wide. */
 void sdrhip_debug_set_systolic(int on);
 long long sdrhip_debug_systolic_launches(void);
+/* fmDemod inside the first stage's kernel (round 4; default OFF, SDRHIP_FUSE_K2K3=0/1): when the first stage is the FM receiver's
+ * (decimate by 8, 128 taps, AVX order, u8 IQ in) and the run is not launch-bound, the register-resident systolic decimator
+ * demodulates its outputs in place and stores the demodulated stream -- the decimated stream (8 B written + 8 B read per decimator
+ * output, the largest intermediate of the chain) never reaches HBM.  Same bits; the per-stage timing then books both under
+ * `decimate` and reports 0 for `fm_demod`.  Measured slower than the two kernels on MI355X (chain.cpp: 1.095 against 1.052 ms per
+ * 2^29-sample pass): fmDemod's arithmetic hides behind its own memory traffic as a kernel of its own and does not inside a
+ * kernel bound by instruction issue. */
+int sdrhip_fm_chain_set_decim_demod_fusion(sdrhip_fm_chain *c, int enable);
 /* fmDemod inside the resampler's tile loader for large batches (>= 2^18 resampler outputs per run): the demodulated stream
  * never makes its round trip through HBM (12 B per decimated sample less traffic); the per-stage timing then books the pair
  * under `resample`.  Same bits.  Off by default (environment SDRHIP_FUSE_DEMOD=1 turns it on): measured, the pair takes

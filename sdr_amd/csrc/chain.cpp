@@ -57,6 +57,19 @@ struct sdrhip_fm_chain {
     // SDRHIP_FUSED_TAIL=0/1/2.
     int fused_tail = getenv("SDRHIP_FUSED_TAIL") ? atoi(getenv("SDRHIP_FUSED_TAIL")) : 2;
     bool fuse_demod = getenv("SDRHIP_FUSE_DEMOD") ? atoi(getenv("SDRHIP_FUSE_DEMOD")) != 0 : false;   // fmDemod in the resampler's tile loader
+    // fmDemod in the systolic decimator's epilogue (round 4, kernels_systolic.hip): the decimated stream -- the largest intermediate,
+    // 8 B written and 8 B read per decimator output -- never reaches HBM.  OFF by default: measured on MI355X (2^29 samples per pass,
+    // alternating A/B in one process, tools/k2k3_fusion_ab.py) the pair costs 0.908-0.911 ms fused against 0.688-0.691 + 0.159-0.160 ms
+    // as two kernels (whole pass 1.094-1.098 against 1.050-1.055 ms).  The stand-alone fmDemod streams at 5 TB/s with its ~120
+    // instructions per sample hidden behind its own memory traffic; moved into the decimator, the same instructions are added to a
+    // kernel that is bound by instruction issue and power, and the 1.07 GB of traffic saved (0.14 J at 130 pJ/B) buys back less than
+    // that.  Kept as an option (same bits; sdrhip_fm_chain_set_decim_demod_fusion, SDRHIP_FUSE_K2K3=1) and under test.
+    bool fuse_k2k3 = getenv("SDRHIP_FUSE_K2K3") ? atoi(getenv("SDRHIP_FUSE_K2K3")) != 0 : false;
+    bool k2k3_shape_ok() const
+    {
+        return fuse_k2k3 && !fuse_demod && fused_tail != 3 && fused_first_stage() && decim.corder == CO_L4 && decim.factor == 8 && decim.Lp == 128 &&
+               block >= 0;
+    }
     bool tail_shape_any() const { return !resamp.cplx && resamp.lanes == 8 && !audio.cplx && audio.sym && audio.lanes == 8 && audio.factor == 1; }
     bool tail_shape_ok(int64_t n_out) const
     {
@@ -470,7 +483,16 @@ static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
         hipEvent_t b = nullptr;
         // K1+K2 on the caller's stream: u8 -> cfloat -> decimate (convert.c:37-50 fused into decimate.c:105-113)
         if ((rc = begin_span(0, s, &b)) != SDRHIP_OK) return rc;
-        if (c->fused_first_stage()) {
+        bool k2k3 = false;
+        if (c->k2k3_shape_ok() && !c->tail_shape_ok(r.q1 - r.q0)) {
+            // ... and K3 in the same kernel: y straight from the decimator's registers, d never written (kernels_systolic.hip)
+            if ((rc = c->decim.ensure_device()) != SDRHIP_OK) return rc;
+            const bool last_zero = (int)c->decim.h_plain.size() == c->decim.Lp && c->decim.h_plain[c->decim.Lp - 1] == 0.0f;
+            k2k3 = launch_decimate_demod_systolic(s, d_in_iq, s0, r.kd0, r.kd1, r.ky0, c->decim.d_scaled, c->decim.d_cross, c->decim.Lp, last_zero,
+                                                  c->block, d_y);
+        }
+        if (k2k3) {
+        } else if (c->fused_first_stage()) {
             if ((rc = fir_run(&c->decim, s, d_in_iq, true, s0, d_d, r.kd0, r.kd1, c->block)) != SDRHIP_OK) return rc;
         } else {
             float* d_x = (float*)(ws + r.off_x);
@@ -529,9 +551,11 @@ static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
             if ((rc = end_span(2, st, b)) != SDRHIP_OK) return rc;
         } else {
             // K3: fmDemod; at stream start the carried sample is 0 (Demod.hs:41)
-            if ((rc = begin_span(1, st, &b)) != SDRHIP_OK) return rc;
-            launch_fm_demod_fast(st, d_d + 2 * (r.ky0 - r.kd0), d_y, r.ky1 - r.ky0, r.ky0 > r.kd0, 0.0f, 0.0f);
-            if ((rc = end_span(1, st, b)) != SDRHIP_OK) return rc;
+            if (!k2k3) {
+                if ((rc = begin_span(1, st, &b)) != SDRHIP_OK) return rc;
+                launch_fm_demod_fast(st, d_d + 2 * (r.ky0 - r.kd0), d_y, r.ky1 - r.ky0, r.ky0 > r.kd0, 0.0f, 0.0f);
+                if ((rc = end_span(1, st, b)) != SDRHIP_OK) return rc;
+            }
             // K4: polyphase resample
             if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;
             if ((rc = resamp_run(&c->resamp, st, d_y, r.ky0, d_z, r.m0, r.m1, c->block, c->block)) != SDRHIP_OK) return rc;
@@ -630,6 +654,13 @@ long long sdrhip_debug_decimate_real16_launches(void) { return decimate_real16_l
 void sdrhip_debug_set_full_tiles(int on) { set_full_tiles(on); }
 void sdrhip_debug_set_systolic(int on) { set_systolic(on); }
 long long sdrhip_debug_systolic_launches(void) { return systolic_launch_count(); }
+
+int sdrhip_fm_chain_set_decim_demod_fusion(sdrhip_fm_chain* c, int enable)
+{
+    SDRHIP_REQUIRE(c != nullptr && (enable == 0 || enable == 1), "sdrhip_fm_chain_set_decim_demod_fusion");
+    c->fuse_k2k3 = enable != 0;
+    return SDRHIP_OK;
+}
 
 int sdrhip_fm_chain_set_demod_fusion(sdrhip_fm_chain* c, int enable)
 {

@@ -188,6 +188,10 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
 // walk (d_taps: plain taps, pre-scaled by 1/128 for u8 input).  false = not this shape / too small, nothing launched.
 bool launch_decimate_c4_systolic(hipStream_t s, const Geom& g, const float* d_taps, int P, const void* d_in, bool in_is_u8, float* d_out,
                                  bool last_tap_zero);
+// the FM chain's K2 + K3 in one launch: decimator outputs [kd0, kd1) demodulated in place, y[k] for k in [ky0, kd1) stored at d_y[k - ky0]
+bool launch_decimate_demod_systolic(hipStream_t s, const uint8_t* d_in, int64_t in_base, int64_t kd0, int64_t kd1, int64_t ky0,
+                                    const float* d_scaled_taps, const float* d_plain_taps, int P, bool last_tap_zero, int64_t seam_block,
+                                    float* d_y);
 void set_systolic(int on);          // A/B switch (SDRHIP_SYSTOLIC=0: the tile kernel everywhere)
 long long systolic_launch_count();  // diagnostics
 void set_full_tiles(int on);   // A/B switch of the FULL-tile instantiations of the AVX-order tiled decimator (decimate_tile.hpp)

@@ -127,6 +127,7 @@ lib.sdrhip_fm_chain_graph_destroy.argtypes = [_vp]
 lib.sdrhip_fm_chain_graph_destroy.restype = None
 lib.sdrhip_fm_chain_set_pipelining.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_set_overlap.argtypes = [_vp, C.c_int]
+lib.sdrhip_fm_chain_set_decim_demod_fusion.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_join.argtypes = [_vp, _vp]
 lib.sdrhip_fm_chain_set_fused_tail.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_set_small_chain.argtypes = [_vp, C.c_int, _i64, C.c_int]
@@ -453,6 +454,10 @@ class FmChain(_Handle):
 
     def set_pipelining(self, nsub):
         check(lib.sdrhip_fm_chain_set_pipelining(self.h, nsub), "sdrhip_fm_chain_set_pipelining")
+
+    def set_decim_demod_fusion(self, on):
+        """fmDemod in the systolic decimator's epilogue (default on): the decimated stream never reaches HBM."""
+        check(lib.sdrhip_fm_chain_set_decim_demod_fusion(self.h, 1 if on else 0), "sdrhip_fm_chain_set_decim_demod_fusion")
 
     def set_overlap(self, on):
         """Two runs in flight: consecutive runs alternate between two internal streams and workspace halves (sdr_hip.h)."""

@@ -676,3 +676,58 @@ def test_two_runs_in_flight_equal_the_single_stream(hip, nblk):
     chain.set_overlap(False)
     again = _run(hip, chain, inputs[1], 0, total, q0, q1)
     assert np.array_equal(again.view(np.int32), refs[1].cpu().numpy().view(np.int32))
+
+
+def test_decimator_demod_fusion_matches_pipes(hip, oracle):
+    """Round 4: fmDemod in the systolic decimator's epilogue (the decimated stream never reaches HBM).  300 source blocks -- past
+    the one-kernel chain's range, so the stage kernels run -- against the restated Pipes."""
+    nblk = 300
+    u8 = S.iq_u8(nblk * B)
+    exp = _model(oracle, u8, nblk)
+    chain = _chain(hip)
+    chain.set_decim_demod_fusion(True)          # off by default (measured slower than the two kernels, chain.cpp)
+    total = nblk * B
+    q0, q1, _ = chain.plan(0, total, total)
+    before = hip.lib.sdrhip_debug_systolic_launches()
+    got = _run(hip, chain, to_dev(u8), 0, total, 0, q1)
+    assert hip.lib.sdrhip_debug_systolic_launches() == before + 1
+    assert exp.size >= 8 * B
+    assert_bit_equal(got[: exp.size], exp, "fused decimate + fmDemod vs pipes")
+
+
+@pytest.mark.parametrize("kind", ["noise", "silence with bursts", "fm"])
+def test_decimator_demod_fusion_on_equals_off(hip, kind):
+    """The same chain with the fusion switched off (decimator, then fmDemod as its own kernel): whole stream from its first sample,
+    shards that start in the middle (a predecessor output instead of the stream's zero), ragged ends, every seam."""
+    n = (1 << 23) + 8 * 1237
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    if kind == "noise":
+        u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda", generator=gen)
+    elif kind == "fm":
+        u8 = to_dev(S.iq_u8_fm(n))
+    else:
+        # long runs of exact zeros (u8 128): decimator outputs that are exactly 0 (phase of 0 is 0, Demod.hs) next to live ones
+        u8 = torch.full((2 * n,), 128, dtype=torch.uint8, device="cuda")
+        for a in range(0, n, 1 << 18):
+            u8[2 * a: 2 * (a + 3000)] = torch.randint(0, 256, (6000,), dtype=torch.uint8, device="cuda", generator=gen)
+    chain = _chain(hip)
+    q0, q1, _ = chain.plan(0, n, n)
+    ranges = [(0, n, q0, q1)]
+    # a shard in the middle of the stream: its own samples plus the halo it needs
+    s0 = 3 * B * 37
+    qa, qb, halo = chain.plan(s0, s0 + (1 << 22), n)
+    ranges.append((s0, (1 << 22) + halo, qa, qb))
+    ranges.append((s0, (1 << 22) + halo, qa + 1234, qb - 4321))
+    for (a, cnt, qa_, qb_) in ranges:
+        outs = []
+        for on in (True, False):
+            chain.set_decim_demod_fusion(on)
+            ws_bytes = chain.workspace_bytes(cnt)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+            out = torch.full((qb_ - qa_ + 16,), float("nan"), device="cuda")
+            chain.run(ptr(u8) + 2 * a, a, cnt, ptr(out), qa_, qb_, ptr(ws), ws_bytes)
+            torch.cuda.synchronize()
+            outs.append(out)
+        chain.set_decim_demod_fusion(False)
+        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (kind, a, cnt, qa_, qb_)
+        assert not torch.isnan(outs[0][: qb_ - qa_]).any()

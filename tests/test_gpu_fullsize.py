@@ -196,6 +196,7 @@ def test_chain_demod_fusion_is_invisible(hip, start_blocks):
         chain = hip.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, block)
         chain.set_fused_tail(0)                                    # the stage kernels, whatever the environment asks for
         chain.set_small_chain(0)
+        chain.set_decim_demod_fusion(False)                        # (round 4's fusion of fmDemod into the DECIMATOR has its own tests)
         ws = torch.empty(chain.workspace_bytes(n), dtype=torch.uint8, device="cuda")
         s0 = start_blocks * B
         q0, q1, _ = chain.plan(s0, s0 + n, s0 + n)
@@ -214,3 +215,16 @@ def test_chain_demod_fusion_is_invisible(hip, start_blocks):
             outs.append(out)
         assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), f"block {block}: fused differs"
         assert torch.equal(outs[0].view(torch.int32), outs[2].view(torch.int32))
+        # ... and the decimator-side fusion gives the same audio as all of them
+        chain.set_demod_fusion(False)
+        chain.set_decim_demod_fusion(True)
+        ws.fill_(0x5A)
+        out = torch.zeros(q1 - q0, dtype=torch.float32, device="cuda")
+        chain.enable_timing(True)
+        chain.run(ptr(u8), s0, n, ptr(out), q0, q1, ptr(ws), ws.numel())
+        torch.cuda.synchronize()
+        stage_ms, _ = chain.read_timing()
+        chain.enable_timing(False)
+        assert stage_ms["fm_demod"] == 0.0 and stage_ms["decimate"] > 0.0, "fmDemod in the decimator's epilogue is booked under `decimate`"
+        assert torch.equal(outs[0].view(torch.int32), out.view(torch.int32)), f"block {block}: decimator-side fusion differs"
+        chain.set_decim_demod_fusion(False)

@@ -124,6 +124,22 @@ def main():
             for r in csv.DictReader(open(path)):
                 if "sdrhip" in r["Name"]:
                     w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+            # round 4: the traced run warms up with the same kernel (tools/prof_k2.py: 400 of 600 launches); the sustained figure is the
+            # mean over each kernel's LAST 200 dispatches, and what bench.py times is the span from one launch's start to the next one's
+            tpath = os.path.join(src, sub, "bench_kernel_trace.csv")
+            if sub == "stats_k2c" and os.path.exists(tpath):
+                per = collections.defaultdict(list)
+                for r in csv.DictReader(open(tpath)):
+                    if "sdrhip" in r["Kernel_Name"]:
+                        per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+                w.writerow([])
+                w.writerow(["kernel", "last_200_dispatches_avg_ns", "last_200_period_ns (start to start, = the launch time bench.py sees)"])
+                for k, v in sorted(per.items()):
+                    v.sort()
+                    last = v[-200:]
+                    avg = sum(e - b for b, e in last) / len(last)
+                    period = (last[-1][0] - last[0][0]) / max(1, len(last) - 1)
+                    w.writerow([k, f"{avg:.0f}", f"{period:.0f}"])
     for sub, name in (("pmc_sq_k2c", f"{tag}_k2c_pmc.csv"), ("pmc_shard", f"{tag}_shard_pmc.csv")):
         if not os.path.exists(os.path.join(src, sub, "bench_counter_collection.csv")):
             continue
