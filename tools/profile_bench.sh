@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --passes-per-step 1 --blocks $BLOCKS"
+CMD="env BENCH_NO_LIB_OVERLAP=1 python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --passes-per-step 1 --blocks $BLOCKS"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/bench_stats_run.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- $CMD > $OUT/bench_fetch_run.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- $CMD > $OUT/bench_write_run.log 2>&1
