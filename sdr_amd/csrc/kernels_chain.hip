@@ -317,7 +317,11 @@ struct DemodSide {
     int yseam, ykeep;      // yseam = 0: nothing to keep
 };
 
-template <int NG, int NLOOP, int INC0, int INC1, int INC2, int NT, bool DEMOD = false, int L = 8>
+// PK (round 4): the 8 lane partials as four packed pairs -- v_pk_mul_f32 by an SGPR pair of taps + v_pk_add_f32, half the VALU
+// instructions of the scalar walk.  A group whose window starts at an odd float (PRE = 7) pairs the partials (1,2) (3,4) (5,6) (7,0)
+// instead, so that its sample pairs are the same aligned register pairs; taps 0 and 63 are then single operations.  Every partial
+// still adds its products in increasing tap order from +0: same bits.
+template <int NG, int NLOOP, int INC0, int INC1, int INC2, int NT, bool DEMOD = false, int L = 8, bool PK = false>
 __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restrict__ in, int64_t pos0, int ncycles,
                                                         int64_t avail_total, const float* __restrict__ groups,
                                                         int row_stride, float* __restrict__ out, DemodSide dm)
@@ -411,15 +415,54 @@ __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restric
     // window start = 10*t floats: 8-byte aligned, and a 10-dword lane stride is conflict-free
     // for ds_read_b64 (distinct even banks within each 32-lane group)
     static_assert(PERIOD % 2 == 0, "8-byte aligned thread windows");
-    float w[WIN + 1];
     const float* win = lds + threadIdx.x * PERIOD;
+    float res[3];
+    if constexpr (PK && L == 8) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        static_assert(NLOOP % 8 == 0 && WIN % 2 == 1, "pairs below assume an even tap count and windows of 7 + NLOOP floats");
+        f2 W2[(WIN + 1) / 2];
+#pragma unroll
+        for (int i = 0; i < (WIN + 1) / 2; i++) {
+            const float2 q = *reinterpret_cast<const float2*>(win + 2 * i);
+            W2[i] = f2{q.x, q.y};
+        }
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            const float* c = groups + g * row_stride;
+            float acc[8];
+            if constexpr (true) {
+                if (PRE[g] % 2 == 0) {
+                    f2 A[4];
+#pragma unroll
+                    for (int p = 0; p < 4; p++) A[p] = f2{0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 0; j < NLOOP; j += 2) A[(j % 8) / 2] = A[(j % 8) / 2] + W2[(PRE[g] + j) / 2] * f2{c[j], c[j + 1]};
+#pragma unroll
+                    for (int p = 0; p < 4; p++) { acc[2 * p] = A[p].x; acc[2 * p + 1] = A[p].y; }
+                } else {
+                    // B[p] = (partial 2p + 1, partial 2p + 2 mod 8): B[3] = (partial 7, partial 0)
+                    f2 B[4];
+#pragma unroll
+                    for (int p = 0; p < 4; p++) B[p] = f2{0.0f, 0.0f};
+                    B[3].y = 0.0f + c[0] * W2[PRE[g] / 2].y;                               // tap 0: sample PRE is the high half of its pair
+#pragma unroll
+                    for (int j = 1; j + 1 < NLOOP; j += 2) B[((j % 8) - 1) / 2] = B[((j % 8) - 1) / 2] + W2[(PRE[g] + j) / 2] * f2{c[j], c[j + 1]};
+                    B[3].x = B[3].x + c[NLOOP - 1] * W2[(PRE[g] + NLOOP - 1) / 2].x;       // tap NLOOP - 1: the low half of the last pair
+                    acc[0] = B[3].y; acc[7] = B[3].x;
+#pragma unroll
+                    for (int p = 0; p < 3; p++) { acc[2 * p + 1] = B[p].x; acc[2 * p + 2] = B[p].y; }
+                }
+            }
+            res[g] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        }
+    } else {
+    float w[WIN + 1];
 #pragma unroll
     for (int i = 0; i < (WIN + 1) / 2; i++) {
         const float2 q = *reinterpret_cast<const float2*>(win + 2 * i);
         w[2 * i] = q.x;
         w[2 * i + 1] = q.y;
     }
-    float res[3];
 #pragma unroll
     for (int g = 0; g < 3; g++) {
         const float* c = groups + g * row_stride;
@@ -431,6 +474,7 @@ __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restric
         for (int j = 0; j < NLOOP; j++) acc[j % L] = acc[j % L] + c[j] * w[PRE[g] + j];
         if constexpr (L == 8) res[g] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         else res[g] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
     }
     // one 12-byte store per thread: the wave writes 768 contiguous bytes
     struct __attribute__((packed, aligned(4))) f3 { float a, b, c; };
@@ -531,6 +575,13 @@ bool launch_filter_cplx4_fast(hipStream_t s, const Geom& g, const float* d_dup_t
 // output whose phase step is input p of this launch (y_count of them), d_in is then the y BUFFER, which this call fills
 // only where other kernels read it: the first and last kEdge inputs (stand-alone fmDemod launches: the few outputs before the
 // first / after the last whole polyphase cycle) and the neighbourhood of every seam (written by the tile kernel).
+// SDRHIP_RESAMP_PK=0/1: the packed-pair walk of k_resample3_fast (A/B; same bits)
+static bool resample_pk_enabled()
+{
+    static const bool on = getenv("SDRHIP_RESAMP_PK") ? atoi(getenv("SDRHIP_RESAMP_PK")) != 0 : true;
+    return on;
+}
+
 bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& t, const int* increments,
                                const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out,
                                const float* d_iq, bool iq_has_prev, int64_t y_count, int lanes)
@@ -585,6 +636,9 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
                                d_groups, t.row_stride, d_out + lead, dm);
         } else if (lanes == 4)
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, false, 4>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
+                               d_groups, t.row_stride, d_out + lead, dm);
+        else if (t.nloop == 64 && resample_pk_enabled())
+            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, false, 8, true>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);
         else if (t.nloop == 64)
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,

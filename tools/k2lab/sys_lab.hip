@@ -180,6 +180,7 @@ __device__ __forceinline__ void load_strip_samples_u8(const void* __restrict__ i
 // No barrier: the buffer belongs to the wave (lgkmcnt orders its own writes and reads).
 constexpr int CF_ROW = 36;                  // dwords per half row (32 + 4 of padding): lane l reads row l, conflict-free per 16 lanes
 constexpr int CF_WAVE_DW = 64 * CF_ROW;     // 9216 B per wave
+template <bool NTL = false>
 __device__ __forceinline__ void load_strip_samples_cf(const float* __restrict__ in, int64_t strip_s0, float* __restrict__ wbuf, int lane, f2 (&S)[32])
 {
     const float* base = in + 2 * strip_s0;
@@ -187,7 +188,16 @@ __device__ __forceinline__ void load_strip_samples_cf(const float* __restrict__ 
     for (int h = 0; h < 2; h++) {
         float4 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = *reinterpret_cast<const float4*>(base + 64 * (8 * j + (lane >> 3)) + 32 * h + 4 * (lane & 7));
+        for (int j = 0; j < 8; j++) {
+            const float* p = base + 64 * (8 * j + (lane >> 3)) + 32 * h + 4 * (lane & 7);
+            if constexpr (NTL) {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+                v[j] = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+                v[j] = *reinterpret_cast<const float4*>(p);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) *reinterpret_cast<float4*>(wbuf + CF_ROW * (8 * j + (lane >> 3)) + 4 * (lane & 7)) = v[j];
 #pragma unroll
@@ -207,7 +217,7 @@ template <bool U8, int PSKIP, int CFMODE, bool MASK>
 __global__ void __launch_bounds__(256, SYS_WPE) k_sysv(const void* __restrict__ in, int64_t x0, int nstrips, const float* __restrict__ taps,
                                                       float* __restrict__ out, ClkProbe* pr)
 {
-    __shared__ __attribute__((aligned(16))) float tbuf[(!U8 && CFMODE == 1) ? 4 * CF_WAVE_DW : 4];
+    __shared__ __attribute__((aligned(16))) float tbuf[(!U8 && CFMODE >= 1) ? 4 * CF_WAVE_DW : 4];
     const int lane = threadIdx.x & 63;
     // XCD-aware order (as the tile kernel's): within every 64 workgroups XCD x takes 8 consecutive ones
     const int b = blockIdx.x;
@@ -221,7 +231,9 @@ __global__ void __launch_bounds__(256, SYS_WPE) k_sysv(const void* __restrict__ 
     if constexpr (U8) {
         load_strip_samples_u8(in, strip_s0 + 32 * lane, S);
     } else if constexpr (CFMODE == 1) {
-        load_strip_samples_cf(reinterpret_cast<const float*>(in), strip_s0, tbuf + CF_WAVE_DW * (threadIdx.x >> 6), lane, S);
+        load_strip_samples_cf<false>(reinterpret_cast<const float*>(in), strip_s0, tbuf + CF_WAVE_DW * (threadIdx.x >> 6), lane, S);
+    } else if constexpr (CFMODE == 2) {
+        load_strip_samples_cf<true>(reinterpret_cast<const float*>(in), strip_s0, tbuf + CF_WAVE_DW * (threadIdx.x >> 6), lane, S);
     } else {
         const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(in) + 2 * (strip_s0 + 32 * lane));
 #pragma unroll
@@ -359,6 +371,7 @@ int main(int argc, char** argv)
     auto prod_cf = [&](float* o) { lab_prod_launch(false, dx, nout, dt, o, pr); };
     auto sys_u8 = [&](float* o) { hipLaunchKernelGGL((k_sys<true, 1>), dim3(nstrips / 4), dim3(256), 0, 0, (const void*)du, (int64_t)0, nstrips, dt128, o); };
     auto sysv_u8 = [&](float* o) { hipLaunchKernelGGL((k_sysv<true, 1, 0, false>), dim3(gsys), dim3(256), 0, 0, (const void*)du, (int64_t)0, nstrips, dt128, o, pr); };
+    auto sysv_cf2 = [&](float* o) { hipLaunchKernelGGL((k_sysv<false, 0, 2, false>), dim3(gsys), dim3(256), 0, 0, (const void*)dx, (int64_t)0, nstrips, dt, o, pr); };
     auto sysm_u8 = [&](float* o) { hipLaunchKernelGGL((k_sysv<true, 1, 0, true>), dim3(gsys), dim3(256), 0, 0, (const void*)du, (int64_t)0, nstrips, dt128, o, pr); };
     auto sysm_cf1 = [&](float* o) { hipLaunchKernelGGL((k_sysv<false, 0, 1, true>), dim3(gsys), dim3(256), 0, 0, (const void*)dx, (int64_t)0, nstrips, dt, o, pr); };
     auto sysv_cf0 = [&](float* o) { hipLaunchKernelGGL((k_sysv<false, 0, 0, false>), dim3(gsys), dim3(256), 0, 0, (const void*)dx, (int64_t)0, nstrips, dt, o, pr); };
@@ -400,6 +413,8 @@ int main(int argc, char** argv)
         check("cfloat systolic VALU direct");
         report("cfloat: systolic VALU, LDS transpose", tm.us([&] { sysv_cf1(dout); }, reps), 8);
         check("cfloat systolic VALU transposed");
+        report("cfloat: systolic, transposed, nt loads", tm.us([&] { sysv_cf2(dout); }, reps), 8);
+        check("cfloat systolic transposed nt");
         report("cfloat: systolic VALU, transposed, masked", tm.us([&] { sysm_cf1(dout); }, reps), 8);
         check("cfloat systolic VALU transposed masked");
     }
@@ -434,6 +449,7 @@ int main(int argc, char** argv)
             sustained("cfloat: production tile kernel", [&] { prod_cf(dref); }, 260);
             sustained("cfloat: systolic VALU, LDS transpose", [&] { sysv_cf1(dout); }, 260);
             sustained("cfloat: systolic VALU, transp, masked", [&] { sysm_cf1(dout); }, 260);
+            sustained("cfloat: systolic, transposed, nt loads", [&] { sysv_cf2(dout); }, 260);
         }
     }
     return 0;
