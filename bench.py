@@ -807,7 +807,8 @@ def main():
                                                                      ws_p.data_ptr(), wsb, stream=sptr), 1.05e-3 * args.blocks / 65536, S_p)
                 del buf_p, aud_p, ws_p
                 power = {"available": True, "device_bdf": bdf, "cap_w": smp.cap_watts(),
-                         "idle": {"mean_w": round(idle["mean_w"], 1), "mean_sclk_mhz": round(idle["mean_sclk_mhz"], 0)} if idle else None,
+                         "gpu_idle_for_1s_after_the_earlier_measurements": {"mean_w": round(idle["mean_w"], 1), "mean_sclk_mhz": round(idle["mean_sclk_mhz"], 0),
+                                                                            "note": "clocks still raised; a cold idle GPU reads 250-255 W at 95-160 MHz (profiles/k2lab/r04_power_series.txt)"} if idle else None,
                          "rows": rows,
                          "how": "tools/power_probe.py HwmonSampler (amdgpu hwmon power1_input / freq1_input / power1_cap of the device's own PCI "
                                 "address, 50 ms period), mean over the last 60 % of each ~2.5 s row of back-to-back launches"}
