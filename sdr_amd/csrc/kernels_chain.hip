@@ -28,6 +28,8 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
     const int64_t nquad = count >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += stride) {
+        // (round 4, measured and not kept: 16-byte loads for interior quads 0.164 ms against 0.159 for these five 8-byte loads per
+        // 2^26 samples, non-temporal 0.185 -- the decimator's output is still partly in the last-level cache when this kernel reads it)
         const float2 s0 = in2[4 * q], s1 = in2[4 * q + 1], s2 = in2[4 * q + 2], s3 = in2[4 * q + 3];
         float2 prev;
         if (q > 0 || has_prev) prev = in2[4 * q - 1];

@@ -15,7 +15,9 @@ def run(k):
     for _ in range(k): chain.run(u8.data_ptr(), 0, n + halo, out.data_ptr(), q0, q1, ws.data_ptr(), ws_bytes, stream=st)
 run(50); torch.cuda.synchronize()
 knob = sys.argv[1] if len(sys.argv) > 1 else "decim_demod"      # decim_demod | resamp_demod (fmDemod in the resampler's loader) | overlap-free knobs only
-setter = {"decim_demod": chain.set_decim_demod_fusion, "resamp_demod": chain.set_demod_fusion}[knob]
+setter = {"decim_demod": chain.set_decim_demod_fusion, "resamp_demod": chain.set_demod_fusion,
+          "nsub2": lambda on: chain.set_pipelining(2 if on else 1), "nsub4": lambda on: chain.set_pipelining(4 if on else 1),
+          "nsub8": lambda on: chain.set_pipelining(8 if on else 1)}[knob]
 print("knob:", knob)
 for rnd in range(3):
     for on in (1, 0):
