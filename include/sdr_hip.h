@@ -376,6 +376,9 @@ void sdrhip_debug_set_full_tiles(int on);
  * SDRHIP_SYSTOLIC=0/1 sets the initial value.  sdrhip_debug_systolic_launches: launches it has served, process-wide. */
 void sdrhip_debug_set_systolic(int on);
 long long sdrhip_debug_systolic_launches(void);
+/* the strip cut of a systolic launch of `count` outputs (host arithmetic only; demod: the fused decimate + fmDemod form): strips
+ * [0, nwhole) take the unguarded body */
+void sdrhip_debug_systolic_plan(int count, int demod, int *nstrips, int *nwhole);
 /* fmDemod inside the first stage's kernel (round 4; default OFF, SDRHIP_FUSE_K2K3=0/1): when the first stage is the FM receiver's
  * (decimate by 8, 128 taps, AVX order, u8 IQ in) and the run is not launch-bound, the register-resident systolic decimator
  * demodulates its outputs in place and stores the demodulated stream -- the decimated stream (8 B written + 8 B read per decimator

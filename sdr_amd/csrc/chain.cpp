@@ -654,6 +654,7 @@ long long sdrhip_debug_decimate_real16_launches(void) { return decimate_real16_l
 void sdrhip_debug_set_full_tiles(int on) { set_full_tiles(on); }
 void sdrhip_debug_set_systolic(int on) { set_systolic(on); }
 long long sdrhip_debug_systolic_launches(void) { return systolic_launch_count(); }
+void sdrhip_debug_systolic_plan(int count, int demod, int* nstrips, int* nwhole) { systolic_plan(count, demod != 0, nstrips, nwhole); }
 
 int sdrhip_fm_chain_set_decim_demod_fusion(sdrhip_fm_chain* c, int enable)
 {

@@ -192,6 +192,7 @@ bool launch_decimate_c4_systolic(hipStream_t s, const Geom& g, const float* d_ta
 bool launch_decimate_demod_systolic(hipStream_t s, const uint8_t* d_in, int64_t in_base, int64_t kd0, int64_t kd1, int64_t ky0,
                                     const float* d_scaled_taps, const float* d_plain_taps, int P, bool last_tap_zero, int64_t seam_block,
                                     float* d_y);
+void systolic_plan(int count, bool demod, int* nstrips, int* nwhole);   // host arithmetic of the strip cut (CPU-testable)
 void set_systolic(int on);          // A/B switch (SDRHIP_SYSTOLIC=0: the tile kernel everywhere)
 long long systolic_launch_count();  // diagnostics
 void set_full_tiles(int on);   // A/B switch of the FULL-tile instantiations of the AVX-order tiled decimator (decimate_tile.hpp)

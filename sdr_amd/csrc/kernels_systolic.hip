@@ -345,6 +345,24 @@ std::atomic<long long> g_systolic_launches{0};
 
 }  // namespace
 
+// How a launch of `count` outputs is cut into wave-strips (host arithmetic, testable without a GPU: sdrhip_debug_systolic_plan).
+// plain: strip t covers outputs 240 t .. 240 t + 239 and reads samples 1920 t .. 1920 t + 2047; demod: strips advance by 239
+// outputs (strip t covers 239 t .. 239 t + 239, its first output being only a predecessor).  Strips [0, nwhole) have all their
+// outputs wanted and all their samples inside the launch's (count - 1) * 8 + 128.
+void systolic_plan(int count, bool demod, int* nstrips, int* nwhole)
+{
+    if (demod) {
+        constexpr int kOuts = kStripOuts - 1;
+        *nstrips = count > 1 ? (count - 1 + kOuts - 1) / kOuts : 1;
+        *nwhole = count >= kStripOuts + 1 ? (count - 1 - kStripOuts) / kOuts + 1 : 0;
+    } else {
+        *nstrips = (count + kStripOuts - 1) / kStripOuts;
+        int w = count / kStripOuts;
+        while (w > 0 && (int64_t)kStripStep * (w - 1) + kStripSpan > (int64_t)(count - 1) * 8 + 128) w--;
+        *nwhole = w;
+    }
+}
+
 void set_systolic(int on) { systolic_flag().store(on); }
 long long systolic_launch_count() { return g_systolic_launches.load(); }
 
@@ -358,10 +376,9 @@ bool launch_decimate_c4_systolic(hipStream_t s, const Geom& g, const float* d_ta
     const int64_t x0 = g.k_begin * g.D - g.in_base;
     const uintptr_t base = reinterpret_cast<uintptr_t>(d_in);
     if (((base + (in_is_u8 ? 2 : 8) * (uintptr_t)x0) & 15) != 0 || (reinterpret_cast<uintptr_t>(d_out) & 15) != 0) return false;
-    const int nstrips = (g.count + kStripOuts - 1) / kStripOuts;
     // strip n is whole when its 240 outputs are wanted and its 2048 samples exist: 1920 n + 2048 <= (count - 1) * 8 + 128
-    int nwhole = g.count / kStripOuts;
-    while (nwhole > 0 && (int64_t)kStripStep * (nwhole - 1) + kStripSpan > (int64_t)(g.count - 1) * 8 + 128) nwhole--;
+    int nstrips, nwhole;
+    systolic_plan(g.count, false, &nstrips, &nwhole);
     const int nwg = (nstrips + kWavesPerWg - 1) / kWavesPerWg;
     const dim3 grid(((nwg + 63) / 64) * 64), block(64 * kWavesPerWg);
     if (in_is_u8) {
@@ -390,10 +407,9 @@ bool launch_decimate_demod_systolic(hipStream_t s, const uint8_t* d_in, int64_t 
     const int64_t x0 = kd0 * 8 - in_base;
     if (x0 < 0 || ((reinterpret_cast<uintptr_t>(d_in) + 2 * (uintptr_t)x0) & 15) != 0 || (reinterpret_cast<uintptr_t>(d_y) & 3) != 0) return false;
     const int count = (int)n, yshift = (int)(ky0 - kd0);
-    constexpr int kOuts = kStripOuts - 1;
-    const int nstrips = count > 1 ? (count - 1 + kOuts - 1) / kOuts : 1;
     // strip t is whole when all of its outputs 239 t .. 239 t + 239 exist (then so do its 2048 samples)
-    const int nwhole = count >= kStripOuts + 1 ? (count - 1 - kStripOuts) / kOuts + 1 : 0;
+    int nstrips, nwhole;
+    systolic_plan(count, true, &nstrips, &nwhole);
     const int nwg = (nstrips + kWavesPerWg - 1) / kWavesPerWg;
     const dim3 grid(((nwg + 63) / 64) * 64), block(64 * kWavesPerWg);
     if (last_tap_zero) hipLaunchKernelGGL((k_decimate_systolic<true, 1, true>), grid, block, 0, s, (const void*)d_in, x0, count, d_scaled_taps, d_y, nwhole, nstrips, yshift);

@@ -192,3 +192,36 @@ def test_drop_in_failures_reach_the_error_handler_instead_of_abort(L):
             assert len(seen) == 2 and seen[1][0] != 0
     finally:
         L.lib.sdrhip_set_error_handler(HANDLER())     # NULL: back to print + abort()
+
+
+def test_systolic_strip_plan_covers_every_launch_exactly(L):
+    """kernels_systolic.hip cuts a launch into wave-strips on the host: whole strips (unguarded loads and stores) must lie entirely
+    inside the launch's outputs AND samples, the strips together must cover every output, and the first strip that is not whole must
+    really be ragged -- for the plain decimator (240 outputs per strip) and the fused decimate + fmDemod form (239)."""
+    import random
+    lib = L.lib
+    lib.sdrhip_debug_systolic_plan.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.sdrhip_debug_systolic_plan.restype = None
+    rng = random.Random(4)
+    counts = list(range(1, 1500)) + [61440 + d for d in range(-3, 500)] + [rng.randrange(1, 1 << 27) for _ in range(3000)] + [(1 << 26) + d for d in (-1, 0, 1, 14)]
+    for demod in (0, 1):
+        step = 239 if demod else 240
+        for count in counts:
+            ns, nw = C.c_int(), C.c_int()
+            lib.sdrhip_debug_systolic_plan(count, demod, C.byref(ns), C.byref(nw))
+            ns, nw = ns.value, nw.value
+            avail = (count - 1) * 8 + 128                       # samples of the launch
+            assert 0 <= nw <= ns and ns >= 1
+            # coverage: the last strip reaches the last output (demod: outputs step*t + 1 .. step*t + 239 are a strip's own)
+            last_covered = step * (ns - 1) + 239
+            assert last_covered >= count - 1, (demod, count, ns)
+            if ns > 1:
+                assert step * (ns - 2) + 239 < count - 1 or demod, (demod, count, ns)      # no strip is superfluous
+            if nw > 0:
+                t = nw - 1
+                assert step * t + 239 <= count - 1, (demod, count, nw)                     # all 240 outputs of a whole strip exist
+                assert 8 * step * t + 2048 <= avail, (demod, count, nw)                    # and all 2048 samples it loads
+            if nw < ns:
+                t = nw
+                ragged = step * t + 239 > count - 1 or 8 * step * t + 2048 > avail
+                assert ragged, (demod, count, nw)
