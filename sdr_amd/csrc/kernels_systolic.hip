@@ -192,6 +192,13 @@ __device__ __forceinline__ void systolic_strip(const void* __restrict__ in, int6
     };
     for_each_m(std::make_integer_sequence<int, kM>{}, do_m);
 
+    // the last stage's arithmetic must not sink into the `lane >= 4` block below: its first additions carry the DPP move, which
+    // needs every lane -- sunk, each becomes a v_mov_dpp outside plus an addition inside (26 extra instructions per strip; measured
+    // in one process: decimate stage 0.681-0.683 ms with this fence against 0.689-0.693 without)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) asm volatile("" : "+v"(acc[i][k]));
     f2 res[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) res[i] = (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
