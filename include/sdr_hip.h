@@ -379,6 +379,12 @@ long long sdrhip_debug_systolic_launches(void);
 /* the strip cut of a systolic launch of `count` outputs (host arithmetic only; demod: the fused decimate + fmDemod form): strips
  * [0, nwhole) take the unguarded body */
 void sdrhip_debug_systolic_plan(int count, int demod, int *nstrips, int *nwhole);
+/* the 3/10 resampler's register-resident systolic kernel (kernels_resample_systolic.hip, round 4): OFF by default -- measured no faster
+ * than the LDS-tiled kernel (0.092 against 0.091 ms per 2^26 inputs) -- SDRHIP_RESAMP_SYSTOLIC=1 or the setter switch it on (same bits);
+ * launches it has served, and the strip cut of a launch of `ncycles` polyphase cycles whose inputs exist up to avail_total */
+void sdrhip_debug_set_resample_systolic(int on);
+long long sdrhip_debug_resample_systolic_launches(void);
+void sdrhip_debug_resample_systolic_plan(int ncycles, long long avail_total, int *nstrips, int *nwhole);
 /* fmDemod inside the first stage's kernel (round 4; default OFF, SDRHIP_FUSE_K2K3=0/1): when the first stage is the FM receiver's
  * (decimate by 8, 128 taps, AVX order, u8 IQ in) and the run is not launch-bound, the register-resident systolic decimator
  * demodulates its outputs in place and stores the demodulated stream -- the decimated stream (8 B written + 8 B read per decimator

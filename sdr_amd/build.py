@@ -29,7 +29,7 @@ FILE_FLAGS = {"kernels_chain.hip": ["-fno-slp-vectorize"], "kernels_split.hip": 
               "kernels_tail.hip": ["-fno-slp-vectorize"], "kernels_cplx.hip": ["-fno-slp-vectorize"],
               "kernels_resample_cycle.hip": ["-fno-slp-vectorize"], "kernels_decimate_real.hip": ["-fno-slp-vectorize"],
               # packed operations written out as 2-vectors; the vectoriser would undo the DPP-fused additions
-              "kernels_systolic.hip": ["-fno-slp-vectorize"]}
+              "kernels_systolic.hip": ["-fno-slp-vectorize"], "kernels_resample_systolic.hip": ["-fno-slp-vectorize"]}
 if os.environ.get("SDRHIP_SPLIT_DEFS"):   # tuning experiments, e.g. "-DSPLIT_CB=8 -DSPLIT_U=4"
     FILE_FLAGS["kernels_split.hip"] = FILE_FLAGS["kernels_split.hip"] + os.environ["SDRHIP_SPLIT_DEFS"].split()
 if os.environ.get("SDRHIP_NO_SLP_FAST"):

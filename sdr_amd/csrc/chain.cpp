@@ -655,6 +655,9 @@ void sdrhip_debug_set_full_tiles(int on) { set_full_tiles(on); }
 void sdrhip_debug_set_systolic(int on) { set_systolic(on); }
 long long sdrhip_debug_systolic_launches(void) { return systolic_launch_count(); }
 void sdrhip_debug_systolic_plan(int count, int demod, int* nstrips, int* nwhole) { systolic_plan(count, demod != 0, nstrips, nwhole); }
+long long sdrhip_debug_resample_systolic_launches(void) { return resample_systolic_launch_count(); }
+void sdrhip_debug_set_resample_systolic(int on) { set_resample_systolic(on); }
+void sdrhip_debug_resample_systolic_plan(int ncycles, long long avail_total, int* nstrips, int* nwhole) { resample_systolic_plan(ncycles, avail_total, nstrips, nwhole); }
 
 int sdrhip_fm_chain_set_decim_demod_fusion(sdrhip_fm_chain* c, int enable)
 {

@@ -154,6 +154,13 @@ bool launch_filter_cplx4_fast(hipStream_t s, const Geom& g, const float* d_dup_t
 // kernels_fast_filter.hip: complex filters of exactly 128 / 64 taps (AVX "RC" order, plain taps) on the tiled decimator with D = 1
 bool launch_filter_c4_tile(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps, const float* d_in,
                            float* d_out);
+// kernels_resample_systolic.hip (round 4): the whole cycles of a 3/10 launch (three 64-float groups, increments {4,3,3}, AVX order) by a
+// register-resident systolic walk; cycle c starts at d_in[pos + 10c] and yields d_out[3c .. 3c + 2].  false = not taken.
+bool launch_resample3_systolic(hipStream_t s, const float* d_in, int64_t pos, int ncycles, int64_t avail_total, const float* d_groups,
+                               int row_stride, float* d_out);
+void resample_systolic_plan(int ncycles, int64_t avail_total, int* nstrips, int* nwhole);
+long long resample_systolic_launch_count();
+void set_resample_systolic(int on);     // default 0: measured no faster than the tile kernel
 // kernels_cplx.hip: the same shape on complex data ("RC2" orders of resampleAVXRC / resampleSSERC)
 bool launch_resample3c_fast(hipStream_t s, const Geom& g, ComplexOrder order, const ResampTable& t, const int* increments, const float* d_groups,
                             const float* d_plain_taps, const float* d_in, float* d_out);

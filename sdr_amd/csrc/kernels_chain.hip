@@ -639,7 +639,10 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
         } else if (lanes == 4)
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, false, 4>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);
-        else if (t.nloop == 64 && resample_pk_enabled())
+        else if (t.nloop == 64 && lanes == 8 &&
+                 launch_resample3_systolic(s, d_in, pos, ncycles, avail_total, d_groups, t.row_stride, d_out + lead)) {
+            // round 4: the register-resident systolic walk took the whole cycles (16-byte aligned input, runs that are not launch-bound)
+        } else if (t.nloop == 64 && resample_pk_enabled())
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, false, 8, true>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);
         else if (t.nloop == 64)

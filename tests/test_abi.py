@@ -225,3 +225,22 @@ def test_systolic_strip_plan_covers_every_launch_exactly(L):
                 t = nw
                 ragged = step * t + 239 > count - 1 or 8 * step * t + 2048 > avail
                 assert ragged, (demod, count, nw)
+
+
+def test_resampler_systolic_strip_plan(L):
+    """The 3/10 systolic resampler's strips: 248 polyphase cycles each, 2560 inputs read, whole strips inside the cycles and inputs."""
+    import random
+    lib = L.lib
+    lib.sdrhip_debug_resample_systolic_plan.argtypes = [C.c_int, C.c_longlong, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.sdrhip_debug_resample_systolic_plan.restype = None
+    rng = random.Random(9)
+    for ncyc in list(range(1, 1200)) + [rng.randrange(1, 1 << 24) for _ in range(2000)]:
+        avail = (ncyc - 1) * 10 + 7 + 64
+        ns, nw = C.c_int(), C.c_int()
+        lib.sdrhip_debug_resample_systolic_plan(ncyc, avail, C.byref(ns), C.byref(nw))
+        ns, nw = ns.value, nw.value
+        assert 0 <= nw <= ns and 248 * ns >= ncyc > 248 * (ns - 1)
+        if nw:
+            assert 248 * nw <= ncyc and 2480 * (nw - 1) + 2560 <= avail
+        if nw < ns:
+            assert 248 * (nw + 1) > ncyc or 2480 * nw + 2560 > avail

@@ -731,3 +731,20 @@ def test_decimator_demod_fusion_on_equals_off(hip, kind):
         chain.set_decim_demod_fusion(False)
         assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (kind, a, cnt, qa_, qb_)
         assert not torch.isnan(outs[0][: qb_ - qa_]).any()
+
+
+def test_chain_with_the_systolic_resampler_equals_the_tile_kernel(hip):
+    """kernels_resample_systolic.hip inside the chain (optional, off by default): the same audio, bit for bit, on a full-size pass cut
+    at the places the chain cuts it (launch starts that are and are not 16-byte aligned)."""
+    n = (1 << 24) + 8 * 4099
+    u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda")
+    chain = _chain(hip)
+    q0, q1, _ = chain.plan(0, n, n)
+    outs = []
+    before = hip.lib.sdrhip_debug_resample_systolic_launches()
+    for on in (1, 0):
+        hip.lib.sdrhip_debug_set_resample_systolic(on)
+        outs.append(torch.from_numpy(_run(hip, chain, u8, 0, n, q0, q1)))
+    hip.lib.sdrhip_debug_set_resample_systolic(0)
+    assert hip.lib.sdrhip_debug_resample_systolic_launches() > before
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))

@@ -26,4 +26,5 @@ for rnd in range(3):
         chain.enable_timing(True)
         t0 = time.perf_counter(); run(300); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 300
         ms, _ = chain.read_timing(); chain.enable_timing(False)
+        if rnd == 0 and on == 0: print("systolic launches so far: decimator", L.lib.sdrhip_debug_systolic_launches(), "resampler", L.lib.sdrhip_debug_resample_systolic_launches())
         print(f"fusion {on}: {dt*1e3:.4f} ms/pass  {n/dt/1e9:.1f} Gsamples/s  stages {ms['decimate']:.4f} {ms['fm_demod']:.4f} {ms['resample']:.4f} {ms['filter']:.4f}")
