@@ -122,3 +122,41 @@ def test_resampler_3_10_systolic_matches_pipes(hip, oracle, nblk):
         assert np.isnan(got[K:]).all()
     hip.lib.sdrhip_debug_set_resample_systolic(0)
     assert hip.lib.sdrhip_debug_resample_systolic_launches() >= before + 2, "the systolic resampler never ran"
+
+
+def test_random_launch_geometry_equals_the_tile_kernel(hip):
+    """Seeded sweep: random first output, output count, seam block (0, 8192, other multiples of 8 above the filter length) and input
+    type -- the systolic kernel against the LDS-tiled kernel on the very same launch (the tile kernel is pinned to the oracle by the
+    rest of the suite).  Launch starts stay 16-byte aligned (even outputs), as both kernels require."""
+    import os
+    scale = max(1, int(os.environ.get("SDRHIP_SWEEP_SCALE", "1")))
+    rng = np.random.default_rng(20260928 + int(os.environ.get("SDRHIP_SWEEP_SEED", "0")))
+    n = 1 << 22
+    g = torch.Generator(device="cuda").manual_seed(3)
+    d_u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda", generator=g)
+    d_cf = torch.rand(2 * n, device="cuda", generator=g) * 2 - 1
+    taps = S.taps_decim127()
+    dec = hip.Decimator(8, taps, hip.ORDER_AVX, complex_=True)
+    kmax = (n - 128) // 8 + 1
+    took = 0
+    for trial in range(24 * scale):
+        u8 = bool(rng.integers(0, 2))
+        count = int(rng.integers(MIN, 4 * MIN))
+        k0 = 2 * int(rng.integers(0, (kmax - count) // 2))
+        seam = int(rng.choice([0, 0, B, B, 8 * int(rng.integers(40, 3000))]))
+        if seam and count <= 5 * 32768:
+            count = 5 * 32768 + 2 * int(rng.integers(1, 5000))        # seamed launches below that stay on the tile kernel by design
+            k0 = min(k0, (kmax - count) // 2 * 2)
+        outs = []
+        before = hip.lib.sdrhip_debug_systolic_launches()
+        for on in (1, 0):
+            hip.lib.sdrhip_debug_set_systolic(on)
+            out = torch.full((2 * count + 8,), float("nan"), device="cuda")
+            (dec.run_u8 if u8 else dec.run)(ptr(d_u8 if u8 else d_cf), 0, ptr(out), k0, k0 + count, seam)
+            torch.cuda.synchronize()
+            outs.append(out)
+        hip.lib.sdrhip_debug_set_systolic(1)
+        took += hip.lib.sdrhip_debug_systolic_launches() - before
+        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (trial, u8, count, k0, seam)
+        assert torch.isnan(outs[0][2 * count:]).all()
+    assert took == 24 * scale
