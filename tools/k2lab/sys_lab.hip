@@ -300,6 +300,79 @@ __global__ void __launch_bounds__(256, SYS_WPE) k_sysv(const void* __restrict__ 
     probe_end(pr, c0, r0);
 }
 
+// The same walk with NC * 8 samples and NC outputs per lane (NC = 4 is k_sysv): fewer stage transitions per output (8 (NS - 1) DPP
+// additions per output), fewer warm-up lanes (NS - 1 of 64), at the price of 24 NC registers (2 waves per SIMD for NC = 8).  u8 only.
+template <int NC, int PSKIP, int WPE>
+__global__ void __launch_bounds__(256, WPE) k_sysn(const void* __restrict__ in, int64_t x0, int nstrips, const float* __restrict__ taps,
+                                                  float* __restrict__ out, ClkProbe* pr)
+{
+    constexpr int MMAX = 15 + NC - 1, NS = MMAX / NC + 1, OUTS = (64 - (NS - 1)) * NC, STEP = OUTS * 8;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x;
+    const int wg = (b & ~63) + ((b & 7) << 3) + ((b >> 3) & 7);
+    const int strip = wg * 4 + (threadIdx.x >> 6);
+    if (strip >= nstrips) return;
+    unsigned long long c0, r0;
+    probe_begin(c0, r0);
+    f2 S[8 * NC];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(in) + 2 * (x0 + (int64_t)STEP * strip + 8 * NC * lane));
+        uint4 raw[NC];
+#pragma unroll
+        for (int q = 0; q < NC; q++) raw[q] = src[q];
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            const uint32_t w[4] = {raw[q].x ^ 0x80808080u, raw[q].y ^ 0x80808080u, raw[q].z ^ 0x80808080u, raw[q].w ^ 0x80808080u};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                S[8 * q + 2 * k] = f2{(float)(signed char)(w[k] & 0xff), (float)(signed char)((w[k] >> 8) & 0xff)};
+                S[8 * q + 2 * k + 1] = f2{(float)(signed char)((w[k] >> 16) & 0xff), (float)(signed char)(w[k] >> 24)};
+            }
+        }
+    }
+    f2 acc[NC][4];
+    typename TapVec<8>::type tc[16];
+    tc[0] = load_tap_chunk<8>(taps, 0);
+    auto do_m = [&](auto mc) {
+        constexpr int m = decltype(mc)::value, t = m / NC, c = m % NC;
+        if constexpr (m + 1 < 16) tc[m + 1] = load_tap_chunk<8>(taps, m + 1);
+        else asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int k = r & 3;
+#pragma unroll
+            for (int i = 0; i < NC; i++) {
+                const int bb = (m - i) & 15;
+                if (m - i < 0 || m - i > 15) continue;
+                if (PSKIP && 8 * bb + r >= 128 - PSKIP) continue;
+                const f2 p = S[8 * c + r] * tc[bb][r];
+                if (bb == 0 && r < 4) acc[i][k] = f2{0.f, 0.f} + p;
+                else if (t > 0 && c == 0 && r < 4) acc[i][k] = f2{dpp_shr1(acc[i][k].x) + p.x, dpp_shr1(acc[i][k].y) + p.y};
+                else acc[i][k] = acc[i][k] + p;
+            }
+        }
+    };
+    [&]<int... Ms>(std::integer_sequence<int, Ms...>) { (do_m(std::integral_constant<int, Ms>{}), ...); }(std::make_integer_sequence<int, MMAX + 1>{});
+#pragma unroll
+    for (int i = 0; i < NC; i++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) asm volatile("" : "+v"(acc[i][k]));
+    f2 res[NC];
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+        res[i] = (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
+        // output i is complete after stage (15 + i) / NC: the early ones sit one lane below the others
+        if ((15 + i) / NC < NS - 1) res[i] = f2{dpp_shr1(res[i].x), dpp_shr1(res[i].y)};
+    }
+    static_assert(NC == 4 || NC == 6 || NC == 8, "early outputs are exactly one stage early for these");
+    if (lane >= NS - 1) {
+        float2* dst = reinterpret_cast<float2*>(out + 2 * ((int64_t)OUTS * strip + NC * (lane - (NS - 1))));
+#pragma unroll
+        for (int i = 0; i < NC; i += 2) *reinterpret_cast<float4*>(dst + i) = make_float4(res[i].x, res[i].y, res[i + 1].x, res[i + 1].y);
+    }
+    probe_end(pr, c0, r0);
+}
+
 struct Timer {
     hipEvent_t a, b;
     Timer() { CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); }
@@ -374,6 +447,11 @@ int main(int argc, char** argv)
     auto sysv_cf2 = [&](float* o) { hipLaunchKernelGGL((k_sysv<false, 0, 2, false>), dim3(gsys), dim3(256), 0, 0, (const void*)dx, (int64_t)0, nstrips, dt, o, pr); };
     auto sysm_u8 = [&](float* o) { hipLaunchKernelGGL((k_sysv<true, 1, 0, true>), dim3(gsys), dim3(256), 0, 0, (const void*)du, (int64_t)0, nstrips, dt128, o, pr); };
     auto sysm_cf1 = [&](float* o) { hipLaunchKernelGGL((k_sysv<false, 0, 1, true>), dim3(gsys), dim3(256), 0, 0, (const void*)dx, (int64_t)0, nstrips, dt, o, pr); };
+    auto sysn = [&](auto kern, int outs_per_strip, float* o) {
+        const int ns = (int)(nout / outs_per_strip) / 4 * 4;
+        hipLaunchKernelGGL(kern, dim3(((ns / 4 + 63) / 64) * 64), dim3(256), 0, 0, (const void*)du, (int64_t)0, ns, dt128, o, pr);
+        return (int64_t)ns * outs_per_strip;
+    };
     auto sysv_cf0 = [&](float* o) { hipLaunchKernelGGL((k_sysv<false, 0, 0, false>), dim3(gsys), dim3(256), 0, 0, (const void*)dx, (int64_t)0, nstrips, dt, o, pr); };
     auto sysv_cf1 = [&](float* o) { hipLaunchKernelGGL((k_sysv<false, 0, 1, false>), dim3(gsys), dim3(256), 0, 0, (const void*)dx, (int64_t)0, nstrips, dt, o, pr); };
 
@@ -403,6 +481,17 @@ int main(int argc, char** argv)
         }
         report("u8: systolic, VALU products", tm.us([&] { sysv_u8(dout); }, reps), 2);
         check("u8 systolic VALU");
+        for (int nc : {6, 8}) {
+            CK(hipMemset(dout, 0xff, (size_t)nout * 8));
+            int64_t covered = 0;
+            const double us = tm.us([&] { covered = nc == 6 ? sysn(k_sysn<6, 1, 3>, 61 * 6, dout) : sysn(k_sysn<8, 1, 2>, 62 * 8, dout); }, reps);
+            report(nc == 6 ? "u8: systolic, 48 samples per lane (3 w/SIMD)" : "u8: systolic, 64 samples per lane (2 w/SIMD)", us * (double)nout / (double)covered, 2);
+            fetch(dout, hout);
+            size_t bad = 0;
+            for (int64_t q = 0; q < covered; q++) bad += hout[q] != href[q];
+            printf("    check NC=%d: %s (%zu of %lld outputs differ)\n", nc, bad ? "MISMATCH" : "bit-exact", bad, (long long)covered);
+        }
+        CK(hipMemset(dout, 0xff, (size_t)nout * 8));
         report("u8: systolic VALU, idle lanes masked", tm.us([&] { sysm_u8(dout); }, reps), 2);
         check("u8 systolic VALU masked");
         prod_cf(dref);
@@ -446,6 +535,8 @@ int main(int argc, char** argv)
             sustained("u8: production tile kernel", [&] { prod_u8(dref); }, 200);
             sustained("u8: systolic VALU", [&] { sysv_u8(dout); }, 200);
             sustained("u8: systolic VALU, masked", [&] { sysm_u8(dout); }, 200);
+            sustained("u8: systolic NC=6 (x covered/all)", [&] { sysn(k_sysn<6, 1, 3>, 61 * 6, dout); }, 200);
+            sustained("u8: systolic NC=8 (x covered/all)", [&] { sysn(k_sysn<8, 1, 2>, 62 * 8, dout); }, 200);
             sustained("cfloat: production tile kernel", [&] { prod_cf(dref); }, 260);
             sustained("cfloat: systolic VALU, LDS transpose", [&] { sysv_cf1(dout); }, 260);
             sustained("cfloat: systolic VALU, transp, masked", [&] { sysm_cf1(dout); }, 260);
