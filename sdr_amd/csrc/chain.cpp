@@ -56,7 +56,10 @@ struct sdrhip_fm_chain {
     // instead of eight.  mode 0 = never, 1 = always, 2 = auto (runs of at most one tile): sdrhip_fm_chain_set_fused_tail,
     // SDRHIP_FUSED_TAIL=0/1/2.
     int fused_tail = getenv("SDRHIP_FUSED_TAIL") ? atoi(getenv("SDRHIP_FUSED_TAIL")) : 2;
-    bool fuse_demod = getenv("SDRHIP_FUSE_DEMOD") ? atoi(getenv("SDRHIP_FUSE_DEMOD")) != 0 : false;   // fmDemod in the resampler's tile loader
+    // fmDemod in the resampler's tile loader: ON by default since round 4 (with the packed-pair resampler the pass gains 1.0 %,
+    // 1.005-1.011 against 1.017-1.019 ms, alternating in one process: the pair itself is slower, 0.269 against 0.159 + 0.089 ms, but
+    // 0.54 GB less traffic per pass leaves the power-capped decimator 4 % more clock)
+    bool fuse_demod = getenv("SDRHIP_FUSE_DEMOD") ? atoi(getenv("SDRHIP_FUSE_DEMOD")) != 0 : true;
     // fmDemod in the systolic decimator's epilogue (round 4, kernels_systolic.hip): the decimated stream -- the largest intermediate,
     // 8 B written and 8 B read per decimator output -- never reaches HBM.  OFF by default: measured on MI355X (2^29 samples per pass,
     // alternating A/B in one process, tools/k2k3_fusion_ab.py) the pair costs 0.908-0.911 ms fused against 0.688-0.691 + 0.159-0.160 ms
@@ -67,7 +70,7 @@ struct sdrhip_fm_chain {
     bool fuse_k2k3 = getenv("SDRHIP_FUSE_K2K3") ? atoi(getenv("SDRHIP_FUSE_K2K3")) != 0 : false;
     bool k2k3_shape_ok() const
     {
-        return fuse_k2k3 && !fuse_demod && fused_tail != 3 && fused_first_stage() && decim.corder == CO_L4 && decim.factor == 8 && decim.Lp == 128 &&
+        return fuse_k2k3 && fused_tail != 3 && fused_first_stage() && decim.corder == CO_L4 && decim.factor == 8 && decim.Lp == 128 &&
                block >= 0;
     }
     bool tail_shape_any() const { return !resamp.cplx && resamp.lanes == 8 && !audio.cplx && audio.sym && audio.lanes == 8 && audio.factor == 1; }
@@ -542,7 +545,7 @@ static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
             if ((rc = end_span(3, st, b)) != SDRHIP_OK) return rc;
             continue;
         }
-        if (c->fuse_demod) {
+        if (c->fuse_demod && !k2k3) {
             // K3+K4: fmDemod inside the resampler's tile loader on large batches (y never reaches HBM), a stand-alone fmDemod
             // launch first otherwise; timed as the resample stage
             if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;

@@ -634,7 +634,7 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
             dm.y_abs0 = g.in_base;
             dm.yseam = g.seamBI > 0 ? (int)(g.seamBI / g.I) : 0;
             dm.ykeep = kKeep;
-            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, true>), dim3(blocks), dim3(NT), 0, s, d_iq, pos, ncycles, avail_total,
+            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, true, 8, true>), dim3(blocks), dim3(NT), 0, s, d_iq, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);
         } else if (lanes == 4)
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, false, 4>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,

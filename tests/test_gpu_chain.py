@@ -739,6 +739,7 @@ def test_chain_with_the_systolic_resampler_equals_the_tile_kernel(hip):
     n = (1 << 24) + 8 * 4099
     u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda")
     chain = _chain(hip)
+    chain.set_demod_fusion(False)          # the systolic resampler reads the demodulated stream (no fmDemod in its loader)
     q0, q1, _ = chain.plan(0, n, n)
     outs = []
     before = hip.lib.sdrhip_debug_resample_systolic_launches()
