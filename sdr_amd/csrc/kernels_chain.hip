@@ -15,6 +15,10 @@
 #include "crossfix.hpp"
 #include "demod.hpp"
 
+#ifndef SDRHIP_LOADER_SEL
+#define SDRHIP_LOADER_SEL 1
+#endif
+
 namespace sdrhip {
 
 namespace {
@@ -371,7 +375,7 @@ __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restric
         for (int i = 0; i < NP; i++) {
             const int p = threadIdx.x + i * NT;
             if (p < SPAN) {
-                const float y = p < avail ? fm_phase_tern(cur[i], prv[i]) : 0.0f;
+                const float y = p < avail ? (SDRHIP_LOADER_SEL ? fm_phase_sel(cur[i], prv[i]) : fm_phase_tern(cur[i], prv[i])) : 0.0f;
                 lds[p] = y;
                 if (dm.yseam > 0 && p < avail) {
                     int m = m0 + p;                              // position inside the seam grid: SPAN <= yseam (launcher)

@@ -16,6 +16,7 @@ def run(k):
 run(50); torch.cuda.synchronize()
 knob = sys.argv[1] if len(sys.argv) > 1 else "decim_demod"      # decim_demod | resamp_demod (fmDemod in the resampler's loader) | overlap-free knobs only
 setter = {"decim_demod": chain.set_decim_demod_fusion, "resamp_demod": chain.set_demod_fusion,
+          "fused_tail1": lambda on: chain.set_fused_tail(1 if on else 2), "fused_tail3": lambda on: chain.set_fused_tail(3 if on else 2),
           "nsub2": lambda on: chain.set_pipelining(2 if on else 1), "nsub4": lambda on: chain.set_pipelining(4 if on else 1),
           "nsub8": lambda on: chain.set_pipelining(8 if on else 1)}[knob]
 print("knob:", knob)
@@ -27,4 +28,4 @@ for rnd in range(3):
         t0 = time.perf_counter(); run(300); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 300
         ms, _ = chain.read_timing(); chain.enable_timing(False)
         if rnd == 0 and on == 0: print("systolic launches so far: decimator", L.lib.sdrhip_debug_systolic_launches(), "resampler", L.lib.sdrhip_debug_resample_systolic_launches())
-        print(f"fusion {on}: {dt*1e3:.4f} ms/pass  {n/dt/1e9:.1f} Gsamples/s  stages {ms['decimate']:.4f} {ms['fm_demod']:.4f} {ms['resample']:.4f} {ms['filter']:.4f}")
+        print(f"fusion {on}: {dt*1e3:.4f} ms/pass  {n/dt/1e9:.1f} Gsamples/s  stages {ms['decimate']:.4f} {ms['fm_demod']:.4f} {ms['resample']:.4f} {ms['filter']:.4f} tail {ms.get('fused_tail', 0.0):.4f}")
