@@ -656,6 +656,7 @@ long long sdrhip_debug_resample_cycle_launches(void) { return resample_cycle_lau
 long long sdrhip_debug_decimate_real16_launches(void) { return decimate_real16_launch_count(); }
 void sdrhip_debug_set_full_tiles(int on) { set_full_tiles(on); }
 void sdrhip_debug_set_systolic(int on) { set_systolic(on); }
+void sdrhip_debug_set_demod_form(int form) { set_demod_form(form); }
 long long sdrhip_debug_systolic_launches(void) { return systolic_launch_count(); }
 void sdrhip_debug_systolic_plan(int count, int demod, int* nstrips, int* nwhole) { systolic_plan(count, demod != 0, nstrips, nwhole); }
 long long sdrhip_debug_resample_systolic_launches(void) { return resample_systolic_launch_count(); }

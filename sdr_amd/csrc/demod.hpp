@@ -152,4 +152,71 @@ __device__ __forceinline__ float fm_phase_tern(float2 cur, float2 prev)
 }
 
 
+// ---------------------------------------------------------------------------
+// Round 4: the COMMON case on its own.  Of the clauses above only two ever apply to a sample whose product re + i*im is finite
+// and off both axes -- atan2's clause 1 (re > 0) and clause 3 (re < 0, folded im > 0) -- and of atanf's argument ranges the two
+// outermost (|q| < 2^-29 and |q| >= 2^25, inf, NaN) need a ratio no FM signal produces.  One test on the RATIO q = yy / re
+// identifies everything else: q is +-0 or denormal when im is (or underflows against re), infinite when re is zero or im
+// infinite, NaN when either is NaN or 0/0 or inf/inf -- so "2^-29 <= |q| < 2^25" implies re and im finite, non-zero, non-NaN.
+// For such a sample this function performs exactly the operations ghc_atan2_sel / atanf_sel select (same operands, same order);
+// for any other it sets `rare` and its value is to be discarded -- the caller votes across the wave and re-evaluates with
+// fm_phase_sel (kernels_chain.hip's tile loader: the vote fails once in a blue moon; all-zero IQ takes the full form everywhere).
+// 94 VALU instructions per sample against 119: 20 of the 28 selects, the clause compares and the huge / tiny argument arms go.
+// The sign of atanf's reduced ranges is copysign(zz, q) (one v_bfi_b32): zz = hi - ((t - lo) - xr) lies in [0.41, 1.58].
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fm_phase_common(float2 cur, float2 prev, bool& rare)
+{
+    const float pi = 3.14159274101257324f;
+    const float nd = -prev.y;
+    const float re = cur.x * prev.x - cur.y * nd;
+    const float im = cur.x * nd + cur.y * prev.x;
+    const bool c1 = re > 0.0f;
+    const bool flip = !c1 & (im < 0.0f);                      // clause 4 (re < 0 here), undone at the end
+    const float nim = -im;
+    const float yy = sel(flip, nim, im);
+    const float q = yy / re;
+    const uint32_t ix = __float_as_uint(q) & 0x7fffffffu;
+    const float ax = __uint_as_float(ix);
+    rare = (ix - 0x31000000u) >= (0x4c000000u - 0x31000000u);
+    // atanf's argument reduction, innermost range last so that four plain thresholds serve all four select chains
+    const bool t0 = ix < 0x3ee00000u, t1 = ix < 0x3f300000u, t2 = ix < 0x3f980000u, t3 = ix < 0x401c0000u;
+    const float n0 = 2.0f * ax - 1.0f, n1 = ax - 1.0f, n2 = ax - 1.5f;
+    const float d0 = 2.0f + ax, d1 = ax + 1.0f, d2 = 1.0f + 1.5f * ax;
+    const float num = sel(t0, q, sel(t1, n0, sel(t2, n1, sel(t3, n2, -1.0f))));
+    const float den = sel(t0, 1.0f, sel(t1, d0, sel(t2, d1, sel(t3, d2, ax))));
+    const float xr = num / den;
+    const float hv = sel(t1, 4.6364760399e-01f, sel(t2, 7.8539812565e-01f, sel(t3, 9.8279368877e-01f, 1.5707962513e+00f)));
+    const float lv = sel(t1, 5.0121582440e-09f, sel(t2, 3.7748947079e-08f, sel(t3, 3.4473217170e-08f, 7.5497894159e-08f)));
+    const float z = xr * xr;
+    const float w = z * z;
+    const float s1 = z * (3.3333334327e-01f + w * (1.4285714924e-01f + w * (9.0908870101e-02f + w * (6.6610731184e-02f + w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
+    const float s2 = w * (-2.0000000298e-01f + w * (-1.1111110449e-01f + w * (-7.6918758452e-02f + w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
+    const float t = xr * (s1 + s2);
+    const float small = xr - t;
+    const float zz = hv - ((t - lv) - xr);
+    const float a = sel(t0, small, __builtin_copysignf(zz, q));
+    const float pa = pi + a;
+    const float r = sel(c1, a, pa);
+    const float nr = -r;
+    return sel(flip, nr, r);
+}
+
+// N consecutive phases y[e] = phase(v[e + 1] * conj v[e]) the voted way: the common case for every lane, the full select form for
+// the wave if any lane holds anything else (the vote is over the lanes active at the call, so it may sit inside divergent code).
+template <int N>
+__device__ __forceinline__ void fm_phase_voted(const float2 (&v)[N + 1], float (&y)[N])
+{
+    bool rare = false;
+#pragma unroll
+    for (int e = 0; e < N; e++) {
+        bool q;
+        y[e] = fm_phase_common(v[e + 1], v[e], q);
+        rare |= q;
+    }
+    if (__any(rare)) {
+#pragma unroll
+        for (int e = 0; e < N; e++) y[e] = fm_phase_sel(v[e + 1], v[e]);
+    }
+}
+
 }  // namespace sdrhip

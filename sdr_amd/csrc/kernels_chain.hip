@@ -11,6 +11,7 @@
 //
 // Arithmetic contract as in kernels_generic.hip (-ffp-contract=off, lane orders of the
 // AVX variants: resampleAVXRR resample.c:70-87, filterAVXSymmetricRR filter.c:60-68).
+#include <atomic>
 #include "kernels.hpp"
 #include "crossfix.hpp"
 #include "demod.hpp"
@@ -18,11 +19,42 @@
 #ifndef SDRHIP_LOADER_SEL
 #define SDRHIP_LOADER_SEL 1
 #endif
+#ifndef SDRHIP_LOADER_FLAT
+#define SDRHIP_LOADER_FLAT 1
+#endif
+#ifndef SDRHIP_LOADER_ILP
+#define SDRHIP_LOADER_ILP 1
+#endif
+#ifndef SDRHIP_LOADER_COMMON
+#define SDRHIP_LOADER_COMMON 1
+#endif
 
 namespace sdrhip {
 
 namespace {
 
+// FORM 0: nested ternaries (control flow per argument range; rounds 1-3's stand-alone form); 1: selects; 2: the common-case form
+// with a wave vote and the select form behind it (round 4; the default here and what the resampler's fused loader runs: per 2^26
+// samples 0.161 ms against 0.172 for the ternaries and 0.183 for the selects).  All three: same bits
+// (tests/test_gpu_stream.py::test_fm_demod_random_bit_patterns runs every form over arbitrary bit patterns).
+template <int FORM>
+__device__ __forceinline__ float4 fm_phase_quad(float2 prev, float2 s0, float2 s1, float2 s2, float2 s3)
+{
+    float4 r;
+    if constexpr (FORM == 0) {
+        r.x = fm_phase_tern(s0, prev); r.y = fm_phase_tern(s1, s0); r.z = fm_phase_tern(s2, s1); r.w = fm_phase_tern(s3, s2);
+    } else if constexpr (FORM == 1) {
+        r.x = fm_phase_sel(s0, prev); r.y = fm_phase_sel(s1, s0); r.z = fm_phase_sel(s2, s1); r.w = fm_phase_sel(s3, s2);
+    } else {
+        const float2 v[5] = {prev, s0, s1, s2, s3};
+        float y[4];
+        fm_phase_voted<4>(v, y);
+        r = make_float4(y[0], y[1], y[2], y[3]);
+    }
+    return r;
+}
+
+template <int FORM>
 __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__ in, float* __restrict__ out, int64_t count,
                                                         int has_prev, float last_re, float last_im, int out_vec)
 {
@@ -38,11 +70,7 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
         float2 prev;
         if (q > 0 || has_prev) prev = in2[4 * q - 1];
         else prev = make_float2(last_re, last_im);
-        float4 r;
-        r.x = fm_phase_tern(s0, prev);
-        r.y = fm_phase_tern(s1, s0);
-        r.z = fm_phase_tern(s2, s1);
-        r.w = fm_phase_tern(s3, s2);
+        const float4 r = fm_phase_quad<FORM>(prev, s0, s1, s2, s3);
         if (out_vec) {
             reinterpret_cast<float4*>(out)[q] = r;
         } else {
@@ -351,7 +379,8 @@ __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restric
         const float2* z = reinterpret_cast<const float2*>(in) + base;
         const int m0 = dm.yseam > 0 ? (int)((dm.y_abs0 + base) % dm.yseam) : 0;      // one 64-bit modulo per workgroup
         float2 cur[NP], prv[NP];
-        if (avail >= SPAN && (base > 0 || dm.has_prev)) {
+        const bool interior = avail >= SPAN && (base > 0 || dm.has_prev);
+        if (interior) {
             // interior tile: branch-free loads (a conditional load costs a wait at its join: eleven HBM round trips in a row)
 #pragma unroll
             for (int i = 0; i < NP; i++) {
@@ -371,16 +400,71 @@ __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restric
                 }
             }
         }
+        if (SDRHIP_LOADER_FLAT && interior) {
+            // ... and branch-free arithmetic: the phases of a thread's NP - 1 whole rounds as ONE basic block (fmDemod's constants
+            // stay in registers across the samples instead of being re-materialised inside eleven guarded blocks, and the samples'
+            // dependent chains interleave); only the last, partial round (SPAN - (NP - 1) * NT inputs: part of one wave) is guarded
+            static_assert((NP - 1) * NT <= SPAN, "rounds 0 .. NP - 2 are whole");
+            float y[NP];
+#if SDRHIP_LOADER_COMMON
+            // the common case of fmDemod (demod.hpp: fm_phase_common) for everyone; a sample that is not -- zero or non-finite
+            // product, a ratio outside [2^-29, 2^25) -- sends its WAVE through the full form
+            bool rare = false;
 #pragma unroll
-        for (int i = 0; i < NP; i++) {
-            const int p = threadIdx.x + i * NT;
-            if (p < SPAN) {
-                const float y = p < avail ? (SDRHIP_LOADER_SEL ? fm_phase_sel(cur[i], prv[i]) : fm_phase_tern(cur[i], prv[i])) : 0.0f;
-                lds[p] = y;
-                if (dm.yseam > 0 && p < avail) {
-                    int m = m0 + p;                              // position inside the seam grid: SPAN <= yseam (launcher)
+            for (int i = 0; i < NP - 1; i++) {
+                bool q;
+                y[i] = fm_phase_common(cur[i], prv[i], q);
+                rare |= q;
+                // sample after sample (SDRHIP_LOADER_ILP = 1), not ten interleaved: every sample keeps three lane masks (SGPR pairs)
+                // alive from its first compare to its last select, and the machine scheduler left alone mixes all ten (measured,
+                // fused kernel per pass: 0.231 ms one at a time, 0.238 in pairs, 0.244 all ten; 0.256 for the select form)
+                if (i % SDRHIP_LOADER_ILP == SDRHIP_LOADER_ILP - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            // stored before the vote: with the phases needed only after it, the compiler moves most of the arithmetic behind the
+            // branch and keeps thirty lane masks alive across it (48 v_writelane + as many v_readlane per thread)
+#pragma unroll
+            for (int i = 0; i < NP - 1; i++) lds[threadIdx.x + i * NT] = y[i];
+            if (__any(rare)) {
+#pragma unroll
+                for (int i = 0; i < NP - 1; i++) {
+                    y[i] = fm_phase_sel(cur[i], prv[i]);
+                    lds[threadIdx.x + i * NT] = y[i];
+                }
+            }
+#else
+#pragma unroll
+            for (int i = 0; i < NP - 1; i++) y[i] = fm_phase_sel(cur[i], prv[i]);
+#pragma unroll
+            for (int i = 0; i < NP - 1; i++) lds[threadIdx.x + i * NT] = y[i];
+#endif
+            y[NP - 1] = 0.0f;
+            if ((int)threadIdx.x + (NP - 1) * NT < SPAN) {
+                y[NP - 1] = fm_phase_sel(cur[NP - 1], prv[NP - 1]);
+                lds[threadIdx.x + (NP - 1) * NT] = y[NP - 1];
+            }
+            // the y other kernels still read: only a tile that touches a keep zone looks at positions at all (SPAN <= yseam, so
+            // the tile [m0, m0 + SPAN) either starts inside [0, ykeep) or reaches [yseam - ykeep, yseam + ykeep))
+            if (dm.yseam > 0 && (m0 < dm.ykeep || m0 + SPAN > dm.yseam - dm.ykeep)) {
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    const int p = threadIdx.x + i * NT;
+                    int m = m0 + p;
                     if (m >= dm.yseam) m -= dm.yseam;
-                    if (m < dm.ykeep || m >= dm.yseam - dm.ykeep) dm.y_out[base + p] = y;
+                    if (p < SPAN && (m < dm.ykeep || m >= dm.yseam - dm.ykeep)) dm.y_out[base + p] = y[i];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const int p = threadIdx.x + i * NT;
+                if (p < SPAN) {
+                    const float y = p < avail ? (SDRHIP_LOADER_SEL ? fm_phase_sel(cur[i], prv[i]) : fm_phase_tern(cur[i], prv[i])) : 0.0f;
+                    lds[p] = y;
+                    if (dm.yseam > 0 && p < avail) {
+                        int m = m0 + p;                              // position inside the seam grid: SPAN <= yseam (launcher)
+                        if (m >= dm.yseam) m -= dm.yseam;
+                        if (m < dm.ykeep || m >= dm.yseam - dm.ykeep) dm.y_out[base + p] = y;
+                    }
                 }
             }
         }
@@ -489,6 +573,9 @@ __global__ void __launch_bounds__(NT, 4) k_resample3_fast(const float* __restric
 }
 
 
+// which restatement of fmDemod's arithmetic the stand-alone kernel runs (SDRHIP_DEMOD_FORM / sdrhip_debug_set_demod_form)
+std::atomic<int> g_demod_form{getenv("SDRHIP_DEMOD_FORM") ? atoi(getenv("SDRHIP_DEMOD_FORM")) : 2};
+
 }  // namespace
 
 void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int64_t count, bool has_prev, float last_re,
@@ -502,9 +589,12 @@ void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int
     // 199 / 188 / 177 / 174 / 171 / 176 us)
     static const int64_t cap = getenv("SDRHIP_DEMOD_BLOCKS") ? atoll(getenv("SDRHIP_DEMOD_BLOCKS")) : 256 * 64;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_fm_demod_fast, dim3((int)blocks), dim3(256), 0, s, d_in_iq, d_out, count, has_prev ? 1 : 0, last_re,
-                       last_im, out_vec);
+    const int form = g_demod_form.load(std::memory_order_relaxed);
+    auto k = form == 2 ? k_fm_demod_fast<2> : form == 1 ? k_fm_demod_fast<1> : k_fm_demod_fast<0>;
+    hipLaunchKernelGGL(k, dim3((int)blocks), dim3(256), 0, s, d_in_iq, d_out, count, has_prev ? 1 : 0, last_re, last_im, out_vec);
 }
+
+void set_demod_form(int form) { g_demod_form.store(form < 0 || form > 2 ? 0 : form, std::memory_order_relaxed); }
 
 bool launch_fir_real8_fast(hipStream_t s, const Geom& g, bool sym, const float* d_taps, int nk, const float* d_cross_taps,
                           const float* d_in, float* d_out, float gain, bool apply_gain, int lanes)

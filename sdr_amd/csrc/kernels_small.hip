@@ -347,8 +347,10 @@ __global__ void __launch_bounds__(SM_NT, 2) k_fm_chain_small(const uint8_t* __re
         if (j < NY) {
             const float2 a = dl[j], b = dl[j + 1];
             const float2 c = j + 2 < SM_KD ? dl[j + 2] : make_float2(0.0f, 0.0f);
-            const float y_a = fm_phase_sel(b, a), y_b = fm_phase_sel(c, b);
-            *reinterpret_cast<float2*>(&ys[j]) = make_float2(y_a, y_b);
+            const float2 v[3] = {a, b, c};
+            float yv[2];
+            fm_phase_voted<2>(v, yv);                             // common case + vote among the lanes in here (demod.hpp)
+            *reinterpret_cast<float2*>(&ys[j]) = make_float2(yv[0], yv[1]);
         }
     }
     __syncthreads();

@@ -147,8 +147,9 @@ __global__ void __launch_bounds__(TAIL_NT, 4) k_fm_tail(const float* __restrict_
             const int64_t k = kq;
             // all four unconditionally (four independent dependency chains side by side; out-of-range inputs were loaded as
             // zeros), the range test is a select afterwards
-            const float a0 = fm_phase_sel(cur[1], cur[0]), a1 = fm_phase_sel(cur[2], cur[1]);
-            const float a2 = fm_phase_sel(cur[3], cur[2]), a3 = fm_phase_sel(cur[4], cur[3]);
+            float a[4];
+            fm_phase_voted<4>(cur, a);                            // common case + vote among the lanes in here (demod.hpp)
+            const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
             float4 r;
             r.x = (k + 0 >= klo && k + 0 < p.ky1) ? a0 : 0.0f;
             r.y = (k + 1 >= klo && k + 1 < p.ky1) ? a1 : 0.0f;

@@ -138,6 +138,8 @@ lib.sdrhip_debug_systolic_launches.restype = C.c_longlong
 lib.sdrhip_debug_resample_systolic_launches.restype = C.c_longlong
 lib.sdrhip_debug_set_resample_systolic.argtypes = [C.c_int]
 lib.sdrhip_debug_set_systolic.argtypes = [C.c_int]
+lib.sdrhip_debug_set_demod_form.argtypes = [C.c_int]
+lib.sdrhip_debug_set_demod_form.restype = None
 lib.sdrhip_fm_chain_enable_timing.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_read_timing.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 

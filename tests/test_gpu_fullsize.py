@@ -185,13 +185,27 @@ def test_chain_pipelining_is_invisible(hip):
         assert torch.equal(outs[0].view(torch.int32), o.view(torch.int32))
 
 
+@pytest.mark.parametrize("kind", ["noise", "patchy"])
 @pytest.mark.parametrize("start_blocks", [0, 37])
-def test_chain_demod_fusion_is_invisible(hip, start_blocks):
+def test_chain_demod_fusion_is_invisible(hip, start_blocks, kind):
     """fmDemod inside the resampler's tile loader (sdrhip_fm_chain_set_demod_fusion): the demodulated stream is then written
     only around seams and launch edges, and every audio sample must still be the stage kernels' -- from the stream start
-    (carried sample 0) and from the middle of a stream, with 8192-sample seams and without."""
+    (carried sample 0) and from the middle of a stream, with 8192-sample seams and without.  `patchy`: stretches of silence
+    (decimator output exactly 0: fmDemod's 0/0 clause), of DC (imaginary part of the product exactly 0: atan2's axis clauses)
+    and of noise, cut at odd places -- the fused loader evaluates fmDemod's common case and sends a wave with any other sample
+    through the full form (demod.hpp: fm_phase_common), so waves of both kinds and mixed ones must occur."""
     n = 1 << 25
     u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda")
+    if kind == "patchy":
+        rng = np.random.default_rng(99 + start_blocks)
+        edges = np.sort(rng.integers(0, n, 400)) * 2
+        for k in range(0, len(edges) - 1, 2):
+            a, b = int(edges[k]), int(edges[k + 1])
+            if k % 4 == 0:
+                u8[a:b] = 128                                      # silence
+            else:
+                u8[a:b:2] = int(rng.integers(0, 256))              # DC: one I and one Q value
+                u8[a + 1:b:2] = int(rng.integers(0, 256))
     for block in (B, 0):
         chain = hip.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, block)
         chain.set_fused_tail(0)                                    # the stage kernels, whatever the environment asks for

@@ -217,17 +217,52 @@ def test_fm_demod_random_bit_patterns(hip, oracle):
     x = bits.view(np.float32)
     exp = oracle.fm_demod(x)
     d_in = to_dev(x)
-    out = dev_empty_f32(n)
-    hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
-    got = to_host(out)
-    nan_e, nan_g = np.isnan(exp), np.isnan(got)
-    assert np.array_equal(nan_e, nan_g), f"NaN pattern differs at {np.nonzero(nan_e != nan_g)[0][:5]}"
+    nan_e = np.isnan(exp)
     ok = ~nan_e
     assert ok.sum() > n // 4
-    assert_bit_equal(got[ok], exp[ok], "fmDemod on random bit patterns")
+    # every restatement of the arithmetic the library holds (demod.hpp): ternaries, selects, common case + wave vote
+    try:
+        for form in (1, 0, 2):
+            hip.lib.sdrhip_debug_set_demod_form(form)
+            out = dev_empty_f32(n)
+            hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
+            got = to_host(out)
+            nan_g = np.isnan(got)
+            assert np.array_equal(nan_e, nan_g), f"form {form}: NaN pattern differs at {np.nonzero(nan_e != nan_g)[0][:5]}"
+            assert_bit_equal(got[ok], exp[ok], f"fmDemod on random bit patterns, form {form}")
+    finally:
+        hip.lib.sdrhip_debug_set_demod_form(2)
     got2 = hip.DropIn.fm_demod(x)
     assert np.array_equal(np.isnan(got2), nan_e)
     assert_bit_equal(got2[ok], exp[ok], "fmDemodF (drop-in) on random bit patterns")
+
+
+def test_fm_demod_forms_on_ordinary_and_awkward_signals(hip, oracle):
+    """The three restatements of fmDemod's arithmetic on what a receiver sees (an FM signal, noise) and on the inputs that
+    leave the common case: zeros of either sign, the axes, denormals, ratios beyond 2^25 and below 2^-29, repeated samples --
+    alone in a wave of ordinary samples and in runs longer than a wave."""
+    rng = np.random.default_rng(4242)
+    n = 1 << 17
+    x = rng.uniform(-1, 1, 2 * n).astype(np.float32)
+    x[: 2 * 50000] = oracle.convert_u8(S.iq_u8_fm(50000))
+    sp = np.array([0, 0, -0.0, 0, 0, -0.0, -0.0, -0.0, 1, 0, -1, 0, 0, 1, 0, -1, -1, -0.0, 1e-40, 1e-40, 1e-30, 1, 1, 1e-30,
+                   1e30, 1e-8, -1e-8, 1e30, 0.5, 0.5, 0.5, 0.5, -0.5, 0.5, 3, -4, 1, 1e-9, 1, -1e-9, -1, 1e-9, -1, -1e-9,
+                   1e-9, 1, 1e-9, -1, 3e7, 1, 1, 4e7, 1e-38, 1e-38, 1e-38, -1e-38, 1e-45, 0, 1, 1], np.float32)
+    for at in (0, 100001, 140000):                                  # lone awkward samples among ordinary ones
+        x[at: at + sp.size] = sp
+    x[2 * 60000: 2 * 60400] = 0.0                                   # runs longer than a wave
+    x[2 * 61000: 2 * 61400] = np.tile(np.array([0.25, -0.75], np.float32), 400)
+    x[2 * 62000: 2 * 62400: 2] = 0.0                                # on the imaginary axis
+    exp = oracle.fm_demod(x)
+    d_in = to_dev(x)
+    try:
+        for form in (0, 1, 2):
+            hip.lib.sdrhip_debug_set_demod_form(form)
+            out = dev_empty_f32(n)
+            hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
+            assert_bit_equal(to_host(out), exp, f"fmDemod, form {form}")
+    finally:
+        hip.lib.sdrhip_debug_set_demod_form(2)
 
 
 @pytest.mark.parametrize("factor", [8, 4, 16])
