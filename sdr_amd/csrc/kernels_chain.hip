@@ -91,6 +91,26 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
     }
 }
 
+// The two launch edges of the demod-fused resampler (launch_resample_3_10_fast) in ONE launch: block b demodulates segment b,
+// one sample per thread (two 4.9 us launches in a row became one: the kernels are pure launch latency).
+struct DemodEdges {
+    const float* in[2];
+    float* out[2];
+    int has_prev[2];
+    int count;
+};
+__global__ void __launch_bounds__(256) k_fm_demod_edges(DemodEdges e)
+{
+    const int b = blockIdx.y;
+    const float2* in2 = reinterpret_cast<const float2*>(e.in[b]);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < e.count; i += gridDim.x * blockDim.x) {
+        const float2 v[2] = {(i > 0 || e.has_prev[b]) ? in2[i - 1] : make_float2(0.0f, 0.0f), in2[i]};
+        float y[1];
+        fm_phase_voted<1>(v, y);
+        e.out[b][i] = y[0];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K5  real FIR filters (D = 1), 8 lanes:
 //   SYM  (filterAVXSymmetricRR, filter.c:60-68 -> avx_sym_dotprod_R common.h:181-201):
@@ -711,8 +731,11 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
         const int64_t tail_pos = t.pos0 + (lead > 0 ? t.pre[lead - 1] + increments[(t.group0 + lead - 1) % 3] : 0) + (int64_t)ncycles * 10;
         if (tail_pos < y_count - kEdge + 16 || ncycles < 1) return false;
         float* d_y = const_cast<float*>(d_in);
-        launch_fm_demod_fast(s, d_iq, d_y, kEdge, iq_has_prev, 0.0f, 0.0f);
-        launch_fm_demod_fast(s, d_iq + 2 * (y_count - kEdge), d_y + (y_count - kEdge), kEdge, true, 0.0f, 0.0f);
+        DemodEdges e;
+        e.in[0] = d_iq; e.out[0] = d_y; e.has_prev[0] = iq_has_prev ? 1 : 0;
+        e.in[1] = d_iq + 2 * (y_count - kEdge); e.out[1] = d_y + (y_count - kEdge); e.has_prev[1] = 1;
+        e.count = kEdge;
+        hipLaunchKernelGGL(k_fm_demod_edges, dim3(1, 2), dim3(256), 0, s, e);
     }
     if (lead > 0) {
         Geom gl = gs;
