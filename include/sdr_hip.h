@@ -339,6 +339,9 @@ int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain *c, int nsub);
  *   - when the call for run k returns, `stream` has been made to wait for run k-1 -- NOT for run k.  So consecutive runs
  *     must write different audio buffers (double-buffer them), and run k's audio may be consumed on `stream` after the call
  *     for run k+1, or after sdrhip_fm_chain_join(c, stream), which makes `stream` wait for every run still in flight;
+ *   - the same holds for run k's INPUT: work queued on `stream` between the calls for run k and run k+1 is ordered after run k-1
+ *     only, so the buffer run k reads may be overwritten on `stream` after the call for run k+1 (or after the join) -- double-buffer
+ *     the input like the audio;
  *   - results are bit-identical to on = 0 (the same kernels on the same ranges); hipGraph capture needs on = 0.
  * sdrhip_fm_chain_set_overlap drains the runs in flight (host-side wait) before it changes the mode. */
 int sdrhip_fm_chain_set_overlap(sdrhip_fm_chain *c, int on);
