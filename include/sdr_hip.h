@@ -378,8 +378,9 @@ void sdrhip_debug_set_full_tiles(int on);
  * launch-bound take the register-resident systolic kernel (kernels_systolic.hip, round 4), 0 = the LDS-tiled kernel everywhere.
  * SDRHIP_SYSTOLIC=0/1 sets the initial value.  sdrhip_debug_systolic_launches: launches it has served, process-wide. */
 void sdrhip_debug_set_systolic(int on);
-/* which restatement of fmDemod's arithmetic (Demod.hs:21-46) the stand-alone kernel runs: 0 nested ternaries, 1 selects, 2 (default) the
- * common case with a wave vote and the select form behind it (also what the resampler's fused loader runs).  Same bits. */
+/* which restatement of fmDemod's arithmetic (Demod.hs:21-46) the stand-alone kernel runs: 0 nested ternaries, 1 selects, 2 the
+ * common case with a wave vote and the select form behind it, 3 (default) the same with
+ * atanf's argument reduction looked up in an LDS table (what the resampler's fused loader runs).  Same bits. */
 void sdrhip_debug_set_demod_form(int form);
 long long sdrhip_debug_systolic_launches(void);
 /* the strip cut of a systolic launch of `count` outputs (host arithmetic only; demod: the fused decimate + fmDemod form): strips

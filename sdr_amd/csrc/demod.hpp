@@ -201,6 +201,104 @@ __device__ __forceinline__ float fm_phase_common(float2 cur, float2 prev, bool& 
     return sel(flip, nr, r);
 }
 
+// ---------------------------------------------------------------------------
+// The common case with atanf's argument reduction looked up instead of selected (round 4, the resampler's fused loader).
+// fdlibm's four reductions and the unreduced range are all of the shape  xr = (A*ax + B) / (C*ax + D),  result = hi - ((t - lo) - xr):
+//     |x| < 7/16      (1*ax + -0) / (0*ax + 1)        hi = lo = 0      [x/1; 0 - ((t - 0) - xr) = xr - t: the unreduced polynomial]
+//     < 11/16         (2*ax + -1) / (1*ax + 2)        atan(0.5)
+//     < 19/16         (1*ax + -1) / (1*ax + 1)        atan(1)
+//     < 39/16         (1*ax + -1.5) / (1.5*ax + 1)    atan(1.5)
+//     otherwise       (0*ax + -1) / (1*ax + -0)       atan(inf)
+// with every product by 0, 1, 2 exact and every sum the one fdlibm writes (a + b = b + a; x + -0 = x), so each row yields the bits of
+// the expression it replaces for finite ax > 0; the sign goes on last by copysign (the polynomial is odd: evaluating it on |x| and
+// negating is exact).  The range thresholds are multiples of 2^18 in the float's bit pattern, so the row is a direct index:
+// clamp(bits >> 18, 0xfb7, 0x1007) - 0xfb7, 81 rows of (A, B, C, D, hi, lo, -, -) in LDS, filled by the first 81 threads of a workgroup.
+// 9 VALU instructions + two LDS reads where the select chains take 26; 73 per sample all told.
+// ---------------------------------------------------------------------------
+
+// The compiler's IEEE f32 division is v_div_scale x 2, v_rcp, two Newton steps on the reciprocal, three fma steps on the quotient,
+// v_div_fmas, v_div_fixup.  For a denominator in [1, 2^26] and a numerator that is 0 or of magnitude in [2^-29, 2^25] -- atanf's
+// reduced fraction for an argument inside the common case -- neither v_div_scale rescales (no operand or quotient near the denormal
+// or overflow range: both return their input and clear VCC), v_div_fmas is then a plain fma and v_div_fixup returns the quotient
+// it is given (finite non-zero operands; a zero numerator gives the same +0 through the arithmetic): the same eight operations
+// without the three that do nothing.  Only called for lanes whose result is used when the wave's vote says "common".
+#ifndef SDRHIP_DEMOD_DIV2_PLAIN
+#define SDRHIP_DEMOD_DIV2_PLAIN 1
+#endif
+__device__ __forceinline__ float div_unscaled(float num, float den)
+{
+    const float r0 = __builtin_amdgcn_rcpf(den);
+    const float e0 = __builtin_fmaf(-den, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float q0 = num * r1;
+    const float e1 = __builtin_fmaf(-den, q0, num);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-den, q1, num);
+    return __builtin_fmaf(e2, r1, q1);
+}
+
+constexpr int kAtanRows = 0x1007 - 0xfb7 + 1;      // 81
+constexpr int kAtanRowFloats = 8;
+
+__device__ __forceinline__ void atan_table_fill(float* tbl, int row)
+{
+    if (row >= kAtanRows) return;
+    const uint32_t t = 0xfb7u + (uint32_t)row;
+    const int k = row == 0 ? 0 : t < 0xfccu ? 1 : t < 0xfe6u ? 2 : t < 0x1007u ? 3 : 4;
+    const float A[5] = {1.0f, 2.0f, 1.0f, 1.0f, 0.0f};
+    const float Bc[5] = {-0.0f, -1.0f, -1.0f, -1.5f, -1.0f};
+    const float C[5] = {0.0f, 1.0f, 1.0f, 1.5f, 1.0f};
+    const float D[5] = {1.0f, 2.0f, 1.0f, 1.0f, -0.0f};
+    const float H[5] = {0.0f, 4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float Lo[5] = {0.0f, 5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    float a = A[0], b = Bc[0], c = C[0], d = D[0], h = H[0], l = Lo[0];
+#pragma unroll
+    for (int i = 1; i < 5; i++)
+        if (k == i) { a = A[i]; b = Bc[i]; c = C[i]; d = D[i]; h = H[i]; l = Lo[i]; }
+    float4* r = reinterpret_cast<float4*>(tbl + row * kAtanRowFloats);
+    r[0] = make_float4(a, b, c, d);
+    r[1] = make_float4(h, l, 0.0f, 0.0f);
+}
+
+__device__ __forceinline__ float fm_phase_common_tbl(float2 cur, float2 prev, bool& rare, const float* tbl)
+{
+    const float pi = 3.14159274101257324f;
+    const float nd = -prev.y;
+    const float re = cur.x * prev.x - cur.y * nd;
+    const float im = cur.x * nd + cur.y * prev.x;
+    const bool c1 = re > 0.0f;
+    const bool flip = !c1 & (im < 0.0f);
+    const float nim = -im;
+    const float yy = sel(flip, nim, im);
+    const float q = yy / re;
+    const uint32_t ix = __float_as_uint(q) & 0x7fffffffu;
+    const float ax = __uint_as_float(ix);
+    rare = (ix - 0x31000000u) >= (0x4c000000u - 0x31000000u);
+    const uint32_t tq = ix >> 18;
+    const uint32_t tc = tq < 0xfb7u ? 0xfb7u : tq > 0x1007u ? 0x1007u : tq;      // v_med3_u32
+    const float* row = tbl + (tc - 0xfb7u) * kAtanRowFloats;
+    const float4 abcd = *reinterpret_cast<const float4*>(row);
+    const float2 hl = *reinterpret_cast<const float2*>(row + 4);
+    const float num = abcd.x * ax + abcd.y;
+    const float den = abcd.z * ax + abcd.w;
+#if SDRHIP_DEMOD_DIV2_PLAIN
+    const float xr = div_unscaled(num, den);
+#else
+    const float xr = num / den;
+#endif
+    const float z = xr * xr;
+    const float w = z * z;
+    const float s1 = z * (3.3333334327e-01f + w * (1.4285714924e-01f + w * (9.0908870101e-02f + w * (6.6610731184e-02f + w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
+    const float s2 = w * (-2.0000000298e-01f + w * (-1.1111110449e-01f + w * (-7.6918758452e-02f + w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
+    const float t = xr * (s1 + s2);
+    const float zz = hl.x - ((t - hl.y) - xr);
+    const float a = __builtin_copysignf(zz, q);
+    const float pa = pi + a;
+    const float r = sel(c1, a, pa);
+    const float nr = -r;
+    return sel(flip, nr, r);
+}
+
 // N consecutive phases y[e] = phase(v[e + 1] * conj v[e]) the voted way: the common case for every lane, the full select form for
 // the wave if any lane holds anything else (the vote is over the lanes active at the call, so it may sit inside divergent code).
 template <int N>

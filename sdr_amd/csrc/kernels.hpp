@@ -144,7 +144,7 @@ long long resample_cycle_launch_count();
 // kernels_chain.hip: fast paths of the low-rate stages
 void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int64_t count, bool has_prev,
                           float last_re, float last_im);
-void set_demod_form(int form);   // 0 ternaries, 1 selects, 2 common case + wave vote (default): same bits, for tests and A/B
+void set_demod_form(int form);   // 0 ternaries, 1 selects, 2 common case + wave vote, 3 (default) the same with the LDS table: same bits, for tests and A/B
 // real filters (D == 1), AVX order, nk taps walked (half-taps when sym), nk % 8 == 0
 // lanes: 8 = AVX order, 4 = SSE order (the same kernel with four lane partials per output)
 bool launch_fir_real8_fast(hipStream_t s, const Geom& g, bool sym, const float* d_taps, int nk, const float* d_cross_taps,

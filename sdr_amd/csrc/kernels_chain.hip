@@ -28,6 +28,9 @@
 #ifndef SDRHIP_LOADER_ILP
 #define SDRHIP_LOADER_ILP 1
 #endif
+#ifndef SDRHIP_LOADER_TABLE
+#define SDRHIP_LOADER_TABLE 1
+#endif
 #ifndef SDRHIP_LOADER_COMMON
 #define SDRHIP_LOADER_COMMON 1
 #endif
@@ -36,15 +39,32 @@ namespace sdrhip {
 
 namespace {
 
+// FORM 3 (the default): form 2 with atanf's argument reduction looked up in an LDS table (demod.hpp: fm_phase_common_tbl; the fused
+// loader's form): 0.141 ms per 2^26 samples against 0.164 for form 2.
 // FORM 0: nested ternaries (control flow per argument range; rounds 1-3's stand-alone form); 1: selects; 2: the common-case form
-// with a wave vote and the select form behind it (round 4; the default here and what the resampler's fused loader runs: per 2^26
+// with a wave vote and the select form behind it (round 4: per 2^26
 // samples 0.161 ms against 0.172 for the ternaries and 0.183 for the selects).  All three: same bits
 // (tests/test_gpu_stream.py::test_fm_demod_random_bit_patterns runs every form over arbitrary bit patterns).
 template <int FORM>
-__device__ __forceinline__ float4 fm_phase_quad(float2 prev, float2 s0, float2 s1, float2 s2, float2 s3)
+__device__ __forceinline__ float4 fm_phase_quad(float2 prev, float2 s0, float2 s1, float2 s2, float2 s3, const float* atbl)
 {
     float4 r;
-    if constexpr (FORM == 0) {
+    if constexpr (FORM == 3) {
+        const float2 v[5] = {prev, s0, s1, s2, s3};
+        float y[4];
+        bool rare = false;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            bool q;
+            y[e] = fm_phase_common_tbl(v[e + 1], v[e], q, atbl);
+            rare |= q;
+        }
+        if (__any(rare)) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) y[e] = fm_phase_sel(v[e + 1], v[e]);
+        }
+        r = make_float4(y[0], y[1], y[2], y[3]);
+    } else if constexpr (FORM == 0) {
         r.x = fm_phase_tern(s0, prev); r.y = fm_phase_tern(s1, s0); r.z = fm_phase_tern(s2, s1); r.w = fm_phase_tern(s3, s2);
     } else if constexpr (FORM == 1) {
         r.x = fm_phase_sel(s0, prev); r.y = fm_phase_sel(s1, s0); r.z = fm_phase_sel(s2, s1); r.w = fm_phase_sel(s3, s2);
@@ -66,6 +86,11 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
     const float2* in2 = reinterpret_cast<const float2*>(in);
     const int64_t nquad = count >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    __shared__ __attribute__((aligned(16))) float atbl[FORM == 3 ? kAtanRows * kAtanRowFloats : 4];
+    if constexpr (FORM == 3) {
+        atan_table_fill(atbl, threadIdx.x);
+        __syncthreads();
+    }
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += stride) {
         // (round 4, measured and not kept: 16-byte loads for interior quads 0.164 ms against 0.159 for these five 8-byte loads per
         // 2^26 samples, non-temporal 0.185 -- the decimator's output is still partly in the last-level cache when this kernel reads it)
@@ -73,7 +98,7 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
         float2 prev;
         if (q > 0 || has_prev) prev = in2[4 * q - 1];
         else prev = make_float2(last_re, last_im);
-        const float4 r = fm_phase_quad<FORM>(prev, s0, s1, s2, s3);
+        const float4 r = fm_phase_quad<FORM>(prev, s0, s1, s2, s3, atbl);
         if (out_vec) {
             reinterpret_cast<float4*>(out)[q] = r;
         } else {
@@ -403,6 +428,12 @@ __global__ void __launch_bounds__(NT, SDRHIP_RESAMP_MINB) k_resample3_fast(const
         const int m0 = dm.yseam > 0 ? (int)((dm.y_abs0 + base) % dm.yseam) : 0;      // one 64-bit modulo per workgroup
         float2 cur[NP], prv[NP];
         const bool interior = avail >= SPAN && (base > 0 || dm.has_prev);
+#if SDRHIP_LOADER_TABLE
+        // atanf's argument reduction as a table in LDS (demod.hpp: fm_phase_common_tbl): 81 rows written by the first 81 threads,
+        // visible after a barrier that waits for LDS only -- the global loads below stay in flight across it
+        __shared__ __attribute__((aligned(16))) float atbl[kAtanRows * kAtanRowFloats];
+        if (interior) atan_table_fill(atbl, threadIdx.x);
+#endif
         if (interior) {
             // interior tile: branch-free loads (a conditional load costs a wait at its join: eleven HBM round trips in a row)
 #pragma unroll
@@ -433,10 +464,17 @@ __global__ void __launch_bounds__(NT, SDRHIP_RESAMP_MINB) k_resample3_fast(const
             // the common case of fmDemod (demod.hpp: fm_phase_common) for everyone; a sample that is not -- zero or non-finite
             // product, a ratio outside [2^-29, 2^25) -- sends its WAVE through the full form
             bool rare = false;
+#if SDRHIP_LOADER_TABLE
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // `interior` is uniform over the workgroup
+#endif
 #pragma unroll
             for (int i = 0; i < NP - 1; i++) {
                 bool q;
+#if SDRHIP_LOADER_TABLE
+                y[i] = fm_phase_common_tbl(cur[i], prv[i], q, atbl);
+#else
                 y[i] = fm_phase_common(cur[i], prv[i], q);
+#endif
                 rare |= q;
                 // sample after sample (SDRHIP_LOADER_ILP = 1), not ten interleaved: every sample keeps three lane masks (SGPR pairs)
                 // alive from its first compare to its last select, and the machine scheduler left alone mixes all ten (measured,
@@ -597,7 +635,7 @@ __global__ void __launch_bounds__(NT, SDRHIP_RESAMP_MINB) k_resample3_fast(const
 
 
 // which restatement of fmDemod's arithmetic the stand-alone kernel runs (SDRHIP_DEMOD_FORM / sdrhip_debug_set_demod_form)
-std::atomic<int> g_demod_form{getenv("SDRHIP_DEMOD_FORM") ? atoi(getenv("SDRHIP_DEMOD_FORM")) : 2};
+std::atomic<int> g_demod_form{getenv("SDRHIP_DEMOD_FORM") ? atoi(getenv("SDRHIP_DEMOD_FORM")) : 3};
 
 }  // namespace
 
@@ -613,7 +651,7 @@ void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int
     static const int64_t cap = getenv("SDRHIP_DEMOD_BLOCKS") ? atoll(getenv("SDRHIP_DEMOD_BLOCKS")) : 256 * 64;
     if (blocks > cap) blocks = cap;
     const int form = g_demod_form.load(std::memory_order_relaxed);
-    auto k = form == 2 ? k_fm_demod_fast<2> : form == 1 ? k_fm_demod_fast<1> : k_fm_demod_fast<0>;
+    auto k = form == 3 ? k_fm_demod_fast<3> : form == 2 ? k_fm_demod_fast<2> : form == 1 ? k_fm_demod_fast<1> : k_fm_demod_fast<0>;
     hipLaunchKernelGGL(k, dim3((int)blocks), dim3(256), 0, s, d_in_iq, d_out, count, has_prev ? 1 : 0, last_re, last_im, out_vec);
 }
 

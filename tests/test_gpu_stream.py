@@ -222,7 +222,7 @@ def test_fm_demod_random_bit_patterns(hip, oracle):
     assert ok.sum() > n // 4
     # every restatement of the arithmetic the library holds (demod.hpp): ternaries, selects, common case + wave vote
     try:
-        for form in (1, 0, 2):
+        for form in (1, 0, 2, 3):
             hip.lib.sdrhip_debug_set_demod_form(form)
             out = dev_empty_f32(n)
             hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
@@ -231,7 +231,7 @@ def test_fm_demod_random_bit_patterns(hip, oracle):
             assert np.array_equal(nan_e, nan_g), f"form {form}: NaN pattern differs at {np.nonzero(nan_e != nan_g)[0][:5]}"
             assert_bit_equal(got[ok], exp[ok], f"fmDemod on random bit patterns, form {form}")
     finally:
-        hip.lib.sdrhip_debug_set_demod_form(2)
+        hip.lib.sdrhip_debug_set_demod_form(3)
     got2 = hip.DropIn.fm_demod(x)
     assert np.array_equal(np.isnan(got2), nan_e)
     assert_bit_equal(got2[ok], exp[ok], "fmDemodF (drop-in) on random bit patterns")
@@ -256,13 +256,56 @@ def test_fm_demod_forms_on_ordinary_and_awkward_signals(hip, oracle):
     exp = oracle.fm_demod(x)
     d_in = to_dev(x)
     try:
-        for form in (0, 1, 2):
+        for form in (0, 1, 2, 3):
             hip.lib.sdrhip_debug_set_demod_form(form)
             out = dev_empty_f32(n)
             hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
             assert_bit_equal(to_host(out), exp, f"fmDemod, form {form}")
     finally:
-        hip.lib.sdrhip_debug_set_demod_form(2)
+        hip.lib.sdrhip_debug_set_demod_form(3)
+
+
+def test_fm_demod_forms_on_dense_argument_ranges(hip, oracle):
+    """atan2's ratio swept on purpose: every second sample is 1 + 0i, so the phases are atan2(+-y, x) of the samples in between.
+    Ratios log-uniform over [2^-30, 2^26] (all five argument ranges of fdlibm's atanf, in every quadrant, with power-of-two and
+    with random-mantissa denominators), then every range threshold and every ratio that makes a reduced numerator vanish
+    (7/16, 1/2, 11/16, 1, 19/16, 3/2, 39/16, and the common case's own limits 2^-29 and 2^25) with their neighbours +-4 ulp --
+    kept in a stretch of their own so that the waves of the first part stay in the common case (the forms with a wave vote compute
+    those without the full form behind them)."""
+    rng = np.random.default_rng(90125)
+    m = 1 << 16
+    q = np.exp2(rng.uniform(-30, 26, m)).astype(np.float32)
+    x = np.where(rng.integers(0, 2, m) == 0, np.exp2(rng.integers(-20, 20, m)), rng.uniform(0.5, 2.0, m) * np.exp2(rng.integers(-20, 20, m))).astype(np.float32)
+    x *= rng.choice(np.array([-1.0, 1.0], np.float32), m)
+    y = (q * np.abs(x)).astype(np.float32) * rng.choice(np.array([-1.0, 1.0], np.float32), m)
+    marks = np.array([2.0 ** -29, 7 / 16, 0.5, 11 / 16, 1.0, 19 / 16, 1.5, 39 / 16, 2.0 ** 25], np.float32)
+    edge = []
+    for t in marks:
+        b = np.float32(t).view(np.uint32)
+        for d in range(-4, 5):
+            edge.append(np.uint32(int(b) + d).view(np.float32))
+    edge = np.array(edge, np.float32)
+    ex = np.concatenate([np.full(edge.size, s, np.float32) for s in (1.0, -1.0, 4.0, -0.125)])
+    ey = np.concatenate([edge * abs(s) for s in (1.0, -1.0, 4.0, -0.125)]).astype(np.float32)
+    ey = np.concatenate([ey, -ey]); ex = np.concatenate([ex, ex])
+    pad = (-ex.size) % 1024
+    xs = np.concatenate([x, ex, np.ones(pad, np.float32)])
+    ys = np.concatenate([y, ey, np.full(pad, 0.75, np.float32)])
+    iq = np.zeros(4 * xs.size, np.float32)
+    iq[0::4] = 1.0                                                   # d[2i] = 1 + 0i
+    iq[2::4] = xs
+    iq[3::4] = ys                                                    # d[2i + 1] = x + iy
+    exp = oracle.fm_demod(iq)
+    d_in = to_dev(iq)
+    n = iq.size // 2
+    try:
+        for form in (0, 1, 2, 3):
+            hip.lib.sdrhip_debug_set_demod_form(form)
+            out = dev_empty_f32(n)
+            hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
+            assert_bit_equal(to_host(out), exp, f"fmDemod on swept ratios, form {form}")
+    finally:
+        hip.lib.sdrhip_debug_set_demod_form(3)
 
 
 @pytest.mark.parametrize("factor", [8, 4, 16])
