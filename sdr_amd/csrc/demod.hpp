@@ -212,7 +212,7 @@ __device__ __forceinline__ float fm_phase_common(float2 cur, float2 prev, bool& 
 // with every product by 0, 1, 2 exact and every sum the one fdlibm writes (a + b = b + a; x + -0 = x), so each row yields the bits of
 // the expression it replaces for finite ax > 0; the sign goes on last by copysign (the polynomial is odd: evaluating it on |x| and
 // negating is exact).  The range thresholds are multiples of 2^18 in the float's bit pattern, so the row is a direct index:
-// clamp(bits >> 18, 0xfb7, 0x1007) - 0xfb7, 81 rows of (A, B, C, D, hi, lo, -, -) in LDS, filled by the first 81 threads of a workgroup.
+// clamp(bits >> 18, 0xfb7, 0x1007) - 0xfb7, 81 rows of (A, B, C, D) and 81 of (hi, lo) in LDS, filled by the first 81 threads of a workgroup.
 // 9 VALU instructions + two LDS reads where the select chains take 26; 73 per sample all told.
 // ---------------------------------------------------------------------------
 
@@ -238,7 +238,8 @@ __device__ __forceinline__ float div_unscaled(float num, float den)
 }
 
 constexpr int kAtanRows = 0x1007 - 0xfb7 + 1;      // 81
-constexpr int kAtanRowFloats = 8;
+constexpr int kAtanRowFloats = 6;                  // per row: a float4 (A, B, C, D) in the first part of the table, a float2 (hi, lo) in the second --
+                                                   // 16-byte rows use all 64 banks (16 bank classes), 32-byte rows only half of them (8)
 
 __device__ __forceinline__ void atan_table_fill(float* tbl, int row)
 {
@@ -255,9 +256,8 @@ __device__ __forceinline__ void atan_table_fill(float* tbl, int row)
 #pragma unroll
     for (int i = 1; i < 5; i++)
         if (k == i) { a = A[i]; b = Bc[i]; c = C[i]; d = D[i]; h = H[i]; l = Lo[i]; }
-    float4* r = reinterpret_cast<float4*>(tbl + row * kAtanRowFloats);
-    r[0] = make_float4(a, b, c, d);
-    r[1] = make_float4(h, l, 0.0f, 0.0f);
+    reinterpret_cast<float4*>(tbl)[row] = make_float4(a, b, c, d);
+    reinterpret_cast<float2*>(tbl + 4 * kAtanRows)[row] = make_float2(h, l);
 }
 
 __device__ __forceinline__ float fm_phase_common_tbl(float2 cur, float2 prev, bool& rare, const float* tbl)
@@ -276,9 +276,8 @@ __device__ __forceinline__ float fm_phase_common_tbl(float2 cur, float2 prev, bo
     rare = (ix - 0x31000000u) >= (0x4c000000u - 0x31000000u);
     const uint32_t tq = ix >> 18;
     const uint32_t tc = tq < 0xfb7u ? 0xfb7u : tq > 0x1007u ? 0x1007u : tq;      // v_med3_u32
-    const float* row = tbl + (tc - 0xfb7u) * kAtanRowFloats;
-    const float4 abcd = *reinterpret_cast<const float4*>(row);
-    const float2 hl = *reinterpret_cast<const float2*>(row + 4);
+    const float4 abcd = reinterpret_cast<const float4*>(tbl)[tc - 0xfb7u];
+    const float2 hl = reinterpret_cast<const float2*>(tbl + 4 * kAtanRows)[tc - 0xfb7u];
     const float num = abcd.x * ax + abcd.y;
     const float den = abcd.z * ax + abcd.w;
 #if SDRHIP_DEMOD_DIV2_PLAIN
