@@ -116,26 +116,6 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
     }
 }
 
-// The two launch edges of the demod-fused resampler (launch_resample_3_10_fast) in ONE launch: block b demodulates segment b,
-// one sample per thread (two 4.9 us launches in a row became one: the kernels are pure launch latency).
-struct DemodEdges {
-    const float* in[2];
-    float* out[2];
-    int has_prev[2];
-    int count;
-};
-__global__ void __launch_bounds__(256) k_fm_demod_edges(DemodEdges e)
-{
-    const int b = blockIdx.y;
-    const float2* in2 = reinterpret_cast<const float2*>(e.in[b]);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < e.count; i += gridDim.x * blockDim.x) {
-        const float2 v[2] = {(i > 0 || e.has_prev[b]) ? in2[i - 1] : make_float2(0.0f, 0.0f), in2[i]};
-        float y[1];
-        fm_phase_voted<1>(v, y);
-        e.out[b][i] = y[0];
-    }
-}
-
 // ---------------------------------------------------------------------------
 // K5  real FIR filters (D = 1), 8 lanes:
 //   SYM  (filterAVXSymmetricRR, filter.c:60-68 -> avx_sym_dotprod_R common.h:181-201):
@@ -397,7 +377,30 @@ struct DemodSide {
     float* y_out;          // y_out[p] for p relative to the launch's first input
     int64_t y_abs0;        // absolute stream index of p = 0 (seams sit at absolute multiples of yseam)
     int yseam, ykeep;      // yseam = 0: nothing to keep
+    // the launch's two edges: y[0, nedge) and y[y_count - nedge, y_count), which the lead / tail launches of the generic kernel and the
+    // seam fix-up read and the tiles do not cover; the first and the last workgroup write them on their way out (round 4: they were
+    // two launches, then one, of 4.8 us of pure launch latency in front of the tile kernel)
+    int nedge;
+    int64_t y_count;
 };
+
+// first workgroup: y[0, nedge); last workgroup: y[y_count - nedge, y_count) -- one sample per thread and round
+__device__ __forceinline__ void demod_edges(const float* __restrict__ in, const DemodSide& dm)
+{
+    if (dm.nedge <= 0 || (blockIdx.x != 0 && blockIdx.x != gridDim.x - 1)) return;
+    const float2* z = reinterpret_cast<const float2*>(in);
+    for (int seg = 0; seg < 2; seg++) {
+        if (blockIdx.x != (seg == 0 ? 0u : gridDim.x - 1)) continue;
+        const int64_t p0 = seg == 0 ? 0 : dm.y_count - dm.nedge;
+        for (int i = threadIdx.x; i < dm.nedge; i += blockDim.x) {
+            const int64_t p = p0 + i;
+            const float2 v[2] = {(p > 0 || dm.has_prev) ? z[p - 1] : make_float2(0.0f, 0.0f), z[p]};
+            float y[1];
+            fm_phase_voted<1>(v, y);
+            dm.y_out[p] = y[0];
+        }
+    }
+}
 
 // PK (round 4): the 8 lane partials as four packed pairs -- v_pk_mul_f32 by an SGPR pair of taps + v_pk_add_f32, half the VALU
 // instructions of the scalar walk.  A group whose window starts at an odd float (PRE = 7) pairs the partials (1,2) (3,4) (5,6) (7,0)
@@ -562,7 +565,10 @@ __global__ void __launch_bounds__(NT, SDRHIP_RESAMP_MINB) k_resample3_fast(const
     __syncthreads();
 
     const int cyc = cyc0 + threadIdx.x;
-    if (cyc >= ncycles) return;
+    if (cyc >= ncycles) {
+        if constexpr (DEMOD) demod_edges(in, dm);
+        return;
+    }
     // window start = 10*t floats: 8-byte aligned, and a 10-dword lane stride is conflict-free
     // for ds_read_b64 (distinct even banks within each 32-lane group)
     static_assert(PERIOD % 2 == 0, "8-byte aligned thread windows");
@@ -631,6 +637,7 @@ __global__ void __launch_bounds__(NT, SDRHIP_RESAMP_MINB) k_resample3_fast(const
     struct __attribute__((packed, aligned(4))) f3 { float a, b, c; };
     f3 v = {res[0], res[1], res[2]};
     *reinterpret_cast<f3*>(out + (int64_t)cyc * 3) = v;
+    if constexpr (DEMOD) demod_edges(in, dm);
 }
 
 
@@ -768,17 +775,6 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
         // the tail's windows must lie inside the last kEdge inputs
         const int64_t tail_pos = t.pos0 + (lead > 0 ? t.pre[lead - 1] + increments[(t.group0 + lead - 1) % 3] : 0) + (int64_t)ncycles * 10;
         if (tail_pos < y_count - kEdge + 16 || ncycles < 1) return false;
-        float* d_y = const_cast<float*>(d_in);
-        DemodEdges e;
-        e.in[0] = d_iq; e.out[0] = d_y; e.has_prev[0] = iq_has_prev ? 1 : 0;
-        e.in[1] = d_iq + 2 * (y_count - kEdge); e.out[1] = d_y + (y_count - kEdge); e.has_prev[1] = 1;
-        e.count = kEdge;
-        hipLaunchKernelGGL(k_fm_demod_edges, dim3(1, 2), dim3(256), 0, s, e);
-    }
-    if (lead > 0) {
-        Geom gl = gs;
-        gl.count = lead;
-        launch_resample_real(s, gl, lanes, t, d_groups, d_plain_taps, d_in, d_out);
     }
     if (ncycles > 0) {
         // position of the first group-0 output relative to d_in
@@ -792,6 +788,8 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
             dm.y_abs0 = g.in_base;
             dm.yseam = g.seamBI > 0 ? (int)(g.seamBI / g.I) : 0;
             dm.ykeep = kKeep;
+            dm.nedge = kEdge;
+            dm.y_count = y_count;
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, true, 8, true>), dim3(blocks), dim3(NT), 0, s, d_iq, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);
         } else if (lanes == 4)
@@ -809,6 +807,12 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
         else
             hipLaunchKernelGGL((k_resample3_fast<3, 16, 4, 3, 3, NT>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);
+    }
+    // (after the tile kernel: with fmDemod fused its first workgroup writes the y these few outputs read)
+    if (lead > 0) {
+        Geom gl = gs;
+        gl.count = lead;
+        launch_resample_real(s, gl, lanes, t, d_groups, d_plain_taps, d_in, d_out);
     }
     if (tail > 0) {
         const int done = lead + 3 * ncycles;
