@@ -689,7 +689,11 @@ def test_decimator_demod_fusion_matches_pipes(hip, oracle):
     total = nblk * B
     q0, q1, _ = chain.plan(0, total, total)
     before = hip.lib.sdrhip_debug_systolic_launches()
-    got = _run(hip, chain, to_dev(u8), 0, total, 0, q1)
+    hip.lib.sdrhip_debug_set_systolic(1)        # the fusion lives in the systolic kernel (SDRHIP_SYSTOLIC=0 soak runs switch it off)
+    try:
+        got = _run(hip, chain, to_dev(u8), 0, total, 0, q1)
+    finally:
+        hip.lib.sdrhip_debug_set_systolic(int(__import__("os").environ.get("SDRHIP_SYSTOLIC", "1")))
     assert hip.lib.sdrhip_debug_systolic_launches() == before + 1
     assert exp.size >= 8 * B
     assert_bit_equal(got[: exp.size], exp, "fused decimate + fmDemod vs pipes")

@@ -232,6 +232,7 @@ def test_chain_demod_fusion_is_invisible(hip, start_blocks, kind):
         # ... and the decimator-side fusion gives the same audio as all of them
         chain.set_demod_fusion(False)
         chain.set_decim_demod_fusion(True)
+        hip.lib.sdrhip_debug_set_systolic(1)                       # that fusion lives in the systolic kernel (soak runs may switch it off)
         ws.fill_(0x5A)
         out = torch.zeros(q1 - q0, dtype=torch.float32, device="cuda")
         chain.enable_timing(True)
@@ -242,3 +243,4 @@ def test_chain_demod_fusion_is_invisible(hip, start_blocks, kind):
         assert stage_ms["fm_demod"] == 0.0 and stage_ms["decimate"] > 0.0, "fmDemod in the decimator's epilogue is booked under `decimate`"
         assert torch.equal(outs[0].view(torch.int32), out.view(torch.int32)), f"block {block}: decimator-side fusion differs"
         chain.set_decim_demod_fusion(False)
+        hip.lib.sdrhip_debug_set_systolic(int(__import__("os").environ.get("SDRHIP_SYSTOLIC", "1")))
