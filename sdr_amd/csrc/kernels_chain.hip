@@ -22,8 +22,11 @@
 #ifndef SDRHIP_LOADER_FLAT
 #define SDRHIP_LOADER_FLAT 1
 #endif
+#ifndef SDRHIP_RESAMP_DEMOD_NT
+#define SDRHIP_RESAMP_DEMOD_NT 256
+#endif
 #ifndef SDRHIP_RESAMP_MINB
-#define SDRHIP_RESAMP_MINB 6   // 78 VGPRs, six waves per SIMD: fused kernel 0.232 -> 0.227 ms per pass (same-box A/B, 4 / 5 / 6)
+#define SDRHIP_RESAMP_MINB 6   // (HIP: minimum WAVES per SIMD) 78 VGPRs, six waves per SIMD: fused kernel 0.232 -> 0.227 ms per pass (same-box A/B, 4 / 5 / 6)
 #endif
 #ifndef SDRHIP_LOADER_ILP
 #define SDRHIP_LOADER_ILP 1
@@ -790,8 +793,9 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
             dm.ykeep = kKeep;
             dm.nedge = kEdge;
             dm.y_count = y_count;
-            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, true, 8, true>), dim3(blocks), dim3(NT), 0, s, d_iq, pos, ncycles, avail_total,
-                               d_groups, t.row_stride, d_out + lead, dm);
+            constexpr int NTD = SDRHIP_RESAMP_DEMOD_NT;          // workgroup size of the fused form (same-box A/B: 128 / 256 / 512 threads 0.197 / 0.196 / 0.2015 ms)
+            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NTD, true, 8, true>), dim3((ncycles + NTD - 1) / NTD), dim3(NTD), 0, s, d_iq, pos, ncycles,
+                               avail_total, d_groups, t.row_stride, d_out + lead, dm);
         } else if (lanes == 4)
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, false, 4>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);
