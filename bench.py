@@ -942,6 +942,8 @@ def main():
             },
             "roofline_config1_cfloat_decimate": cfg1,
             "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+            **({"stage_ms_note": "fm_demod 0: fmDemod runs inside the resampler's tile loader (the default since round 4) and is booked under `resample`"}
+               if stage_ms.get("fm_demod", 1.0) == 0.0 and stage_ms.get("resample", 0.0) > 0.0 else {}),
             **({"one_pass_at_a_time": {"value": round(world * single_pass["S_len"] * single_pass["passes"] * args.steps / single_pass["elapsed"] / 1e6, 1),
                                        "ms_per_pass": round(single_pass["elapsed"] / (args.steps * single_pass["passes"]) * 1e3, 4),
                                        "what": "the same passes one at a time on one stream, with the per-stage HIP events in the timed region: the run "
