@@ -40,6 +40,7 @@ module SDR.GPU (
 
 import           Control.Exception             (throwIO)
 import           Control.Monad
+import           Control.Concurrent.MVar (MVar, newMVar, withMVar)
 import           Data.IORef
 import           Control.Monad.Primitive       (RealWorld)
 import           Data.Complex
@@ -132,9 +133,16 @@ dropInFailure = unsafePerformIO $ do
     c_set_error_handler h
     return ref
 
+-- | One drop-in call at a time: the failure flag above is process-global (the C handler has no per-call argument), so with
+--   several Haskell threads calling drop-in symbols one thread's failure could be cleared or claimed by another.  The
+--   reference's pipeline is a single thread (fm.hs:30-41); for anything else the lock makes the flag per call.
+{-# NOINLINE dropInLock #-}
+dropInLock :: MVar ()
+dropInLock = unsafePerformIO (newMVar ())
+
 -- | Run a void drop-in call and raise if it reported a failure.
 dropIn :: IO () -> IO ()
-dropIn act = do
+dropIn act = withMVar dropInLock $ \_ -> do
     writeIORef dropInFailure Nothing
     act
     readIORef dropInFailure >>= maybe (return ()) (\msg -> throwIO (userError ("sdr_hip: " ++ msg)))

@@ -159,7 +159,8 @@ const char *sdrhip_last_error(void);
  * (process-wide; NULL restores the default) the failing call instead records the message (sdrhip_last_error), calls
  * handler(code, message) and -- when the handler comes back -- returns to ITS caller at once, outputs unspecified.  A Haskell
  * host sets a flag in the handler and raises after the foreign call (haskell/SDR/GPU.hs: the reference raises from its
- * Pipes too, Filter.hs:526-527); a C host may longjmp out of the handler instead. */
+ * Pipes too, Filter.hs:526-527).  The handler must RETURN: it runs with C++ objects of the library live on the stack (a leased
+ * scratch context among them), so a longjmp out of it is undefined behaviour and would strand that context. */
 void sdrhip_set_error_handler(void (*handler)(int code, const char *message));
 int sdrhip_device_count(void);
 int sdrhip_set_device(int dev);
@@ -380,8 +381,17 @@ void sdrhip_debug_set_full_tiles(int on);
 void sdrhip_debug_set_systolic(int on);
 /* which restatement of fmDemod's arithmetic (Demod.hs:21-46) the stand-alone kernel runs: 0 nested ternaries, 1 selects, 2 the
  * common case with a wave vote and the select form behind it, 3 (default) the same with
- * atanf's argument reduction looked up in an LDS table (what the resampler's fused loader runs).  Same bits. */
+ * atanf's argument reduction looked up in an LDS table (what the resampler's fused loader runs), 4 the table form on two samples at a
+ * time with packed arithmetic (round 5; measured slower).  Same bits. */
 void sdrhip_debug_set_demod_form(int form);
+int sdrhip_debug_demod_form(void);   /* the form the next stand-alone launch runs (what the setter accepted) */
+/* fmDemod + the 3/10 resampler as a streaming kernel (kernels_resample_stream.hip, round 5): a workgroup walks a run of tiles with the
+ * next tile's samples in flight behind the current tile's arithmetic.  0 (default: measured slower, 0.236 against 0.198 ms per 2^26 inputs;
+ * SDRHIP_RESAMP_STREAM sets the initial value) = off (the tile kernel with fmDemod in its loader), 1 = runs of at least four tiles per workgroup, 2 = every run it can take, n > 2 = every run, cut for n workgroups (tests).  Same bits.
+ * ..._launches: launches it has served; ..._plan: the cut of `ncycles` polyphase cycles over a device of `cus` compute units. */
+void sdrhip_debug_set_resample_demod_stream(int on);
+long long sdrhip_debug_resample_demod_stream_launches(void);
+void sdrhip_debug_resample_demod_stream_plan(int ncycles, int cus, int *ntiles, int *tiles_per_wg, int *grid);
 long long sdrhip_debug_systolic_launches(void);
 /* the strip cut of a systolic launch of `count` outputs (host arithmetic only; demod: the fused decimate + fmDemod form): strips
  * [0, nwhole) take the unguarded body */

@@ -326,9 +326,12 @@ int sdrhip_fm_chain_run(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
     SDRHIP_CHECK_HIP(hipStreamWaitEvent(c->lane[j], c->ev_in[j], 0));
     const size_t half = (workspace_bytes / 2) & ~(size_t)255;
     rc = chain_run_on(c, (void*)c->lane[j], d_in_iq, s0, n_in, d_audio, q0, q1, d_workspace ? (char*)d_workspace + (size_t)j * half : nullptr, half);
-    if (rc != SDRHIP_OK) return rc;
-    SDRHIP_CHECK_HIP(hipEventRecord(c->ev_out[j], c->lane[j]));
+    // (also when the run failed half way: kernels it did enqueue on the lane may still be reading the input and writing the
+    // audio and the workspace half, and a later run or join must be ordered behind them)
+    const hipError_t erec = hipEventRecord(c->ev_out[j], c->lane[j]);
     c->lane_busy[j] = true;
+    if (rc != SDRHIP_OK) return rc;
+    SDRHIP_CHECK_HIP(erec);
     if (c->lane_busy[1 - j]) SDRHIP_CHECK_HIP(hipStreamWaitEvent(s, c->ev_out[1 - j], 0));
     return SDRHIP_OK;
 }
@@ -657,6 +660,10 @@ long long sdrhip_debug_decimate_real16_launches(void) { return decimate_real16_l
 void sdrhip_debug_set_full_tiles(int on) { set_full_tiles(on); }
 void sdrhip_debug_set_systolic(int on) { set_systolic(on); }
 void sdrhip_debug_set_demod_form(int form) { set_demod_form(form); }
+int sdrhip_debug_demod_form(void) { return demod_form(); }
+void sdrhip_debug_set_resample_demod_stream(int on) { set_resample_demod_stream(on); }
+long long sdrhip_debug_resample_demod_stream_launches(void) { return resample_demod_stream_launch_count(); }
+void sdrhip_debug_resample_demod_stream_plan(int ncycles, int cus, int* ntiles, int* tiles_per_wg, int* grid) { resample_demod_stream_plan(ncycles, cus, ntiles, tiles_per_wg, grid); }
 long long sdrhip_debug_systolic_launches(void) { return systolic_launch_count(); }
 void sdrhip_debug_systolic_plan(int count, int demod, int* nstrips, int* nwhole) { systolic_plan(count, demod != 0, nstrips, nwhole); }
 long long sdrhip_debug_resample_systolic_launches(void) { return resample_systolic_launch_count(); }

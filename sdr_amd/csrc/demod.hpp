@@ -298,6 +298,100 @@ __device__ __forceinline__ float fm_phase_common_tbl(float2 cur, float2 prev, bo
     return sel(flip, nr, r);
 }
 
+// ---------------------------------------------------------------------------
+// Round 5: TWO samples per call, packed.  tools/k4lab/issue_bench.hip: a wave issues at most one VALU instruction every four cycles;
+// a scalar f32 operation occupies the SIMD for two, so a SIMD needs two READY waves to run scalar arithmetic at full rate (one
+// wave: 0.43-0.52 G instructions/s, two: 0.83-0.97), while a packed operation (v_pk_mul / add / fma_f32: two lanes' worth in four
+// cycles) keeps it busy from a single wave (0.44-0.48 of 0.55-0.57).  The fused loaders run few waves per SIMD and those wait on LDS
+// lookups and barriers, so fmDemod is issue-bound, not execution-bound: this form issues ~97 instructions per two samples
+// instead of 140 -- the complex product as three packed operations per sample ((cx,cx)*(px,-py), (cy,cy)*(-py,px), one add with the
+// low half negated: the same four products and the same two sums as fm_phase_common), the fma steps of both divisions and the whole
+// polynomial across the two samples.  The selects on sign conditions become bit operations, exact for every sample that does not
+// set `rare` (finite, non-zero re and im -- see fm_phase_common):
+//     yy = flip ? -im : im   =  im with its sign cleared when re is negative          (flip = re < 0 && im < 0)
+//     r  = re > 0 ? a : pi + a  =  a + (re < 0 ? pi : +0)                             (x + 0 = x exactly, a != 0; pi + a = a + pi)
+//     flip ? -r : r          =  r with its sign flipped when re and im are both negative
+// The IEEE division is the compiler's own sequence (v_div_scale x 2, v_rcp, fma x 2, mul, fma x 3, v_div_fmas, v_div_fixup) written
+// out so that its fma steps pack.  Same operations on the same operands in the same order: same bits
+// (tests/test_gpu_stream.py: every form on arbitrary bit patterns and dense argument ranges).
+// ---------------------------------------------------------------------------
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2v pk_fma(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ f2v div_ieee_pair(f2v num, f2v den)
+{
+    bool fdx, fdy, fnx, fny;
+    const f2v ds = f2v{__builtin_amdgcn_div_scalef(num.x, den.x, false, &fdx), __builtin_amdgcn_div_scalef(num.y, den.y, false, &fdy)};
+    const f2v ns = f2v{__builtin_amdgcn_div_scalef(num.x, den.x, true, &fnx), __builtin_amdgcn_div_scalef(num.y, den.y, true, &fny)};
+    const f2v r0 = f2v{__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y)};
+    const f2v one = f2v{1.0f, 1.0f};
+    const f2v e0 = pk_fma(-ds, r0, one);
+    const f2v r1 = pk_fma(e0, r0, r0);
+    const f2v q0 = ns * r1;
+    const f2v e1 = pk_fma(-ds, q0, ns);
+    const f2v q1 = pk_fma(e1, r1, q0);
+    const f2v e2 = pk_fma(-ds, q1, ns);
+    const float qx = __builtin_amdgcn_div_fmasf(e2.x, r1.x, q1.x, fnx), qy = __builtin_amdgcn_div_fmasf(e2.y, r1.y, q1.y, fny);
+    return f2v{__builtin_amdgcn_div_fixupf(qx, den.x, num.x), __builtin_amdgcn_div_fixupf(qy, den.y, num.y)};
+}
+
+__device__ __forceinline__ f2v div_unscaled_pair(f2v num, f2v den)
+{
+    const f2v r0 = f2v{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const f2v e0 = pk_fma(-den, r0, f2v{1.0f, 1.0f});
+    const f2v r1 = pk_fma(e0, r0, r0);
+    const f2v q0 = num * r1;
+    const f2v e1 = pk_fma(-den, q0, num);
+    const f2v q1 = pk_fma(e1, r1, q0);
+    const f2v e2 = pk_fma(-den, q1, num);
+    return pk_fma(e2, r1, q1);
+}
+
+// (re, im) of cur * conj(prev) with Data.Complex's operations (Demod.hs:28): re = cx*px - cy*(-py), im = cx*(-py) + cy*px
+__device__ __forceinline__ f2v conj_product(float2 cur, float2 prev)
+{
+    const f2v C = f2v{cur.x, cur.y}, P = f2v{prev.x, prev.y};
+    const f2v t1 = f2v{C.x, C.x} * f2v{P.x, -P.y};          // (cx*px, cx*nd)
+    const f2v t2 = f2v{C.y, C.y} * f2v{-P.y, P.x};          // (cy*nd, cy*px)
+    return t1 + f2v{-t2.x, t2.y};                           // (cx*px - cy*nd, cx*nd + cy*px)
+}
+
+__device__ __forceinline__ float2 fm_phase_common_tbl2(float2 cur0, float2 prev0, float2 cur1, float2 prev1, bool& rare, const float* tbl)
+{
+    const uint32_t pi_bits = 0x40490fdbu;                    // 3.14159274101257324f
+    const f2v z0 = conj_product(cur0, prev0), z1 = conj_product(cur1, prev1);
+    const uint32_t re0 = __float_as_uint(z0.x), im0 = __float_as_uint(z0.y), re1 = __float_as_uint(z1.x), im1 = __float_as_uint(z1.y);
+    const uint32_t s0 = re0 & 0x80000000u, s1 = re1 & 0x80000000u;                 // re negative
+    const f2v yy = f2v{__uint_as_float(im0 & ~s0), __uint_as_float(im1 & ~s1)};
+    const f2v q = div_ieee_pair(yy, f2v{z0.x, z1.x});
+    const uint32_t ix0 = __float_as_uint(q.x) & 0x7fffffffu, ix1 = __float_as_uint(q.y) & 0x7fffffffu;
+    rare = ((ix0 - 0x31000000u) >= (0x4c000000u - 0x31000000u)) | ((ix1 - 0x31000000u) >= (0x4c000000u - 0x31000000u));
+    const uint32_t tq0 = ix0 >> 18, tq1 = ix1 >> 18;
+    const uint32_t tc0 = tq0 < 0xfb7u ? 0xfb7u : tq0 > 0x1007u ? 0x1007u : tq0;    // v_med3_u32
+    const uint32_t tc1 = tq1 < 0xfb7u ? 0xfb7u : tq1 > 0x1007u ? 0x1007u : tq1;
+    const float4 abcd0 = reinterpret_cast<const float4*>(tbl)[tc0 - 0xfb7u], abcd1 = reinterpret_cast<const float4*>(tbl)[tc1 - 0xfb7u];
+    const float2 hl0 = reinterpret_cast<const float2*>(tbl + 4 * kAtanRows)[tc0 - 0xfb7u];
+    const float2 hl1 = reinterpret_cast<const float2*>(tbl + 4 * kAtanRows)[tc1 - 0xfb7u];
+    const float ax0 = __uint_as_float(ix0), ax1 = __uint_as_float(ix1);
+    // (the table values arrive in the registers their LDS reads name, so these stay scalar: a packed operand would need moves)
+    const f2v num = f2v{abcd0.x * ax0 + abcd0.y, abcd1.x * ax1 + abcd1.y};
+    const f2v den = f2v{abcd0.z * ax0 + abcd0.w, abcd1.z * ax1 + abcd1.w};
+    const f2v xr = div_unscaled_pair(num, den);
+    const f2v z = xr * xr;
+    const f2v w = z * z;
+    auto K = [](float c) { return f2v{c, c}; };
+    const f2v s1v = z * (K(3.3333334327e-01f) + w * (K(1.4285714924e-01f) + w * (K(9.0908870101e-02f) + w * (K(6.6610731184e-02f) + w * (K(4.9768779427e-02f) + w * K(1.6285819933e-02f))))));
+    const f2v s2v = w * (K(-2.0000000298e-01f) + w * (K(-1.1111110449e-01f) + w * (K(-7.6918758452e-02f) + w * (K(-5.8335702866e-02f) + w * K(-3.6531571299e-02f)))));
+    const f2v t = xr * (s1v + s2v);
+    const float zz0 = hl0.x - ((t.x - hl0.y) - xr.x), zz1 = hl1.x - ((t.y - hl1.y) - xr.y);
+    const f2v a = f2v{__builtin_copysignf(zz0, q.x), __builtin_copysignf(zz1, q.y)};
+    // pi where re is negative, +0 elsewhere: an arithmetic shift spreads re's sign over the word
+    const f2v piz = f2v{__uint_as_float((uint32_t)((int32_t)re0 >> 31) & pi_bits), __uint_as_float((uint32_t)((int32_t)re1 >> 31) & pi_bits)};
+    const f2v r = a + piz;
+    return make_float2(__uint_as_float(__float_as_uint(r.x) ^ (s0 & im0)), __uint_as_float(__float_as_uint(r.y) ^ (s1 & im1)));
+}
+
 // N consecutive phases y[e] = phase(v[e + 1] * conj v[e]) the voted way: the common case for every lane, the full select form for
 // the wave if any lane holds anything else (the vote is over the lanes active at the call, so it may sit inside divergent code).
 template <int N>

@@ -144,6 +144,7 @@ long long resample_cycle_launch_count();
 // kernels_chain.hip: fast paths of the low-rate stages
 void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int64_t count, bool has_prev,
                           float last_re, float last_im);
+int demod_form();                // the form the stand-alone kernel launches next
 void set_demod_form(int form);   // 0 ternaries, 1 selects, 2 common case + wave vote, 3 (default) the same with the LDS table: same bits, for tests and A/B
 // real filters (D == 1), AVX order, nk taps walked (half-taps when sym), nk % 8 == 0
 // lanes: 8 = AVX order, 4 = SSE order (the same kernel with four lane partials per output)
@@ -162,6 +163,18 @@ bool launch_resample3_systolic(hipStream_t s, const float* d_in, int64_t pos, in
 void resample_systolic_plan(int ncycles, int64_t avail_total, int* nstrips, int* nwhole);
 long long resample_systolic_launch_count();
 void set_resample_systolic(int on);     // default 0: measured no faster than the tile kernel
+// kernels_resample_stream.hip (round 5): fmDemod + the whole cycles of a 3/10 launch as a streaming kernel (a workgroup walks a run of
+// tiles, the next tile's complex samples in flight behind the current tile's arithmetic).  d_iq: decimator output, sample 0 = input 0 of
+// the launch (y_count of them; d_iq[-2..-1] exists when iq_has_prev); cycle c starts at input pos + 10 c; d_y receives the phases
+// other kernels still read (within ykeep of a multiple of yseam in absolute position y_abs0 + n, and the first / last nedge).
+// false = switched off or too short a run, nothing launched.
+bool launch_resample3_demod_stream(hipStream_t s, const float* d_iq, int64_t pos, int ncycles, bool iq_has_prev, int64_t y_count,
+                                   const float* d_groups, int row_stride, float* d_out, float* d_y, int64_t y_abs0, int yseam, int ykeep,
+                                   int nedge);
+void set_resample_demod_stream(int on);   // 0 (default) off, 1 runs long enough to stream, 2 every run it can take, n > 2 every run cut for n workgroups
+int resample_demod_stream_mode();
+long long resample_demod_stream_launch_count();
+void resample_demod_stream_plan(int ncycles, int cus, int* ntiles, int* tiles_per_wg, int* grid);
 // kernels_cplx.hip: the same shape on complex data ("RC2" orders of resampleAVXRC / resampleSSERC)
 bool launch_resample3c_fast(hipStream_t s, const Geom& g, ComplexOrder order, const ResampTable& t, const int* increments, const float* d_groups,
                             const float* d_plain_taps, const float* d_in, float* d_out);

@@ -34,6 +34,11 @@
 #ifndef SDRHIP_LOADER_TABLE
 #define SDRHIP_LOADER_TABLE 1
 #endif
+#ifndef SDRHIP_LOADER_PAIR
+#define SDRHIP_LOADER_PAIR 0   // round 5: two samples per step with packed arithmetic (demod.hpp: fm_phase_common_tbl2): same bits, 97 instructions
+                               // per pair instead of 140 -- and SLOWER (0.207 against 0.198 ms, five waves per SIMD instead of six): a scalar operation
+                               // issued next to a packed one costs a packed one's four cycles (tools/k4lab/issue_bench.hip)
+#endif
 #ifndef SDRHIP_LOADER_COMMON
 #define SDRHIP_LOADER_COMMON 1
 #endif
@@ -52,7 +57,13 @@ template <int FORM>
 __device__ __forceinline__ float4 fm_phase_quad(float2 prev, float2 s0, float2 s1, float2 s2, float2 s3, const float* atbl)
 {
     float4 r;
-    if constexpr (FORM == 3) {
+    if constexpr (FORM == 4) {
+        // the packed pair form (demod.hpp: fm_phase_common_tbl2; round 5, measured slower, kept under the same tests)
+        bool q0, q1;
+        const float2 a = fm_phase_common_tbl2(s0, prev, s1, s0, q0, atbl), b = fm_phase_common_tbl2(s2, s1, s3, s2, q1, atbl);
+        r = make_float4(a.x, a.y, b.x, b.y);
+        if (__any(q0 | q1)) r = make_float4(fm_phase_sel(s0, prev), fm_phase_sel(s1, s0), fm_phase_sel(s2, s1), fm_phase_sel(s3, s2));
+    } else if constexpr (FORM == 3) {
         const float2 v[5] = {prev, s0, s1, s2, s3};
         float y[4];
         bool rare = false;
@@ -89,8 +100,8 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
     const float2* in2 = reinterpret_cast<const float2*>(in);
     const int64_t nquad = count >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    __shared__ __attribute__((aligned(16))) float atbl[FORM == 3 ? kAtanRows * kAtanRowFloats : 4];
-    if constexpr (FORM == 3) {
+    __shared__ __attribute__((aligned(16))) float atbl[FORM >= 3 ? kAtanRows * kAtanRowFloats : 4];
+    if constexpr (FORM >= 3) {
         atan_table_fill(atbl, threadIdx.x);
         __syncthreads();
     }
@@ -427,6 +438,8 @@ __global__ void __launch_bounds__(NT, SDRHIP_RESAMP_MINB) k_resample3_fast(const
     const int64_t av64 = avail_total - (int64_t)cyc0 * PERIOD;
     const int avail = av64 > SPAN ? SPAN : (int)av64;
     if constexpr (DEMOD) {
+        // the keep-zone positions below wrap the seam grid at most once (`if (m >= yseam) m -= yseam`): the launcher admits yseam >= 4096
+        static_assert(SPAN <= 4096, "a tile of the fused loader must not be longer than the shortest seam block the launcher admits");
         // thread t demodulates inputs t, t + NT, ...: two 8-byte loads per input (the sample and its predecessor: the
         // same cache lines one lane over), all of them in flight before the first phase is computed
         constexpr int NP = (SPAN + NT - 1) / NT;
@@ -473,6 +486,23 @@ __global__ void __launch_bounds__(NT, SDRHIP_RESAMP_MINB) k_resample3_fast(const
 #if SDRHIP_LOADER_TABLE
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // `interior` is uniform over the workgroup
 #endif
+#if SDRHIP_LOADER_TABLE && SDRHIP_LOADER_PAIR
+            // round 5: two samples per step, packed (demod.hpp: fm_phase_common_tbl2) -- fmDemod here is issue-bound, and the pair
+            // form issues 97 instructions where two single samples issue 140
+#pragma unroll
+            for (int i = 0; i + 1 < NP - 1; i += 2) {
+                bool q;
+                const float2 yp = fm_phase_common_tbl2(cur[i], prv[i], cur[i + 1], prv[i + 1], q, atbl);
+                y[i] = yp.x; y[i + 1] = yp.y;
+                rare |= q;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if ((NP - 1) % 2) {
+                bool q;
+                y[NP - 2] = fm_phase_common_tbl(cur[NP - 2], prv[NP - 2], q, atbl);
+                rare |= q;
+            }
+#else
 #pragma unroll
             for (int i = 0; i < NP - 1; i++) {
                 bool q;
@@ -487,6 +517,7 @@ __global__ void __launch_bounds__(NT, SDRHIP_RESAMP_MINB) k_resample3_fast(const
                 // fused kernel per pass: 0.231 ms one at a time, 0.238 in pairs, 0.244 all ten; 0.256 for the select form)
                 if (i % SDRHIP_LOADER_ILP == SDRHIP_LOADER_ILP - 1) __builtin_amdgcn_sched_barrier(0);
             }
+#endif
             // stored before the vote: with the phases needed only after it, the compiler moves most of the arithmetic behind the
             // branch and keeps thirty lane masks alive across it (48 v_writelane + as many v_readlane per thread)
 #pragma unroll
@@ -661,11 +692,12 @@ void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int
     static const int64_t cap = getenv("SDRHIP_DEMOD_BLOCKS") ? atoll(getenv("SDRHIP_DEMOD_BLOCKS")) : 256 * 64;
     if (blocks > cap) blocks = cap;
     const int form = g_demod_form.load(std::memory_order_relaxed);
-    auto k = form == 3 ? k_fm_demod_fast<3> : form == 2 ? k_fm_demod_fast<2> : form == 1 ? k_fm_demod_fast<1> : k_fm_demod_fast<0>;
+    auto k = form == 4 ? k_fm_demod_fast<4> : form == 3 ? k_fm_demod_fast<3> : form == 2 ? k_fm_demod_fast<2> : form == 1 ? k_fm_demod_fast<1> : k_fm_demod_fast<0>;
     hipLaunchKernelGGL(k, dim3((int)blocks), dim3(256), 0, s, d_in_iq, d_out, count, has_prev ? 1 : 0, last_re, last_im, out_vec);
 }
 
-void set_demod_form(int form) { g_demod_form.store(form < 0 || form > 2 ? 0 : form, std::memory_order_relaxed); }
+void set_demod_form(int form) { g_demod_form.store(form < 0 || form > 4 ? 0 : form, std::memory_order_relaxed); }
+int demod_form() { return g_demod_form.load(std::memory_order_relaxed); }
 
 bool launch_fir_real8_fast(hipStream_t s, const Geom& g, bool sym, const float* d_taps, int nk, const float* d_cross_taps,
                           const float* d_in, float* d_out, float gain, bool apply_gain, int lanes)
@@ -793,9 +825,14 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
             dm.ykeep = kKeep;
             dm.nedge = kEdge;
             dm.y_count = y_count;
+            if (launch_resample3_demod_stream(s, d_iq, pos, ncycles, iq_has_prev, y_count, d_groups, t.row_stride, d_out + lead,
+                                              const_cast<float*>(d_in), g.in_base, dm.yseam, kKeep, kEdge)) {
+                // round 5: the streaming form took the whole cycles
+            } else {
             constexpr int NTD = SDRHIP_RESAMP_DEMOD_NT;          // workgroup size of the fused form (same-box A/B: 128 / 256 / 512 threads 0.197 / 0.196 / 0.2015 ms)
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NTD, true, 8, true>), dim3((ncycles + NTD - 1) / NTD), dim3(NTD), 0, s, d_iq, pos, ncycles,
                                avail_total, d_groups, t.row_stride, d_out + lead, dm);
+            }
         } else if (lanes == 4)
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, false, 4>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);

@@ -140,6 +140,14 @@ lib.sdrhip_debug_set_resample_systolic.argtypes = [C.c_int]
 lib.sdrhip_debug_set_systolic.argtypes = [C.c_int]
 lib.sdrhip_debug_set_demod_form.argtypes = [C.c_int]
 lib.sdrhip_debug_set_demod_form.restype = None
+lib.sdrhip_debug_demod_form.argtypes = []
+lib.sdrhip_debug_demod_form.restype = C.c_int
+lib.sdrhip_debug_set_resample_demod_stream.argtypes = [C.c_int]
+lib.sdrhip_debug_set_resample_demod_stream.restype = None
+lib.sdrhip_debug_resample_demod_stream_launches.argtypes = []
+lib.sdrhip_debug_resample_demod_stream_launches.restype = C.c_longlong
+lib.sdrhip_debug_resample_demod_stream_plan.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.sdrhip_debug_resample_demod_stream_plan.restype = None
 lib.sdrhip_fm_chain_enable_timing.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_read_timing.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
@@ -460,7 +468,8 @@ class FmChain(_Handle):
         check(lib.sdrhip_fm_chain_set_pipelining(self.h, nsub), "sdrhip_fm_chain_set_pipelining")
 
     def set_decim_demod_fusion(self, on):
-        """fmDemod in the systolic decimator's epilogue (default on): the decimated stream never reaches HBM."""
+        """fmDemod in the systolic decimator's epilogue (default OFF: measured slower than the two kernels, chain.cpp): the
+        decimated stream then never reaches HBM."""
         check(lib.sdrhip_fm_chain_set_decim_demod_fusion(self.h, 1 if on else 0), "sdrhip_fm_chain_set_decim_demod_fusion")
 
     def set_overlap(self, on):

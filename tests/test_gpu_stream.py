@@ -222,8 +222,9 @@ def test_fm_demod_random_bit_patterns(hip, oracle):
     assert ok.sum() > n // 4
     # every restatement of the arithmetic the library holds (demod.hpp): ternaries, selects, common case + wave vote
     try:
-        for form in (1, 0, 2, 3):
+        for form in (1, 0, 2, 3, 4):
             hip.lib.sdrhip_debug_set_demod_form(form)
+            assert hip.lib.sdrhip_debug_demod_form() == form, "the setter must select the form it is given (round 4 clamped 3 to 0)"
             out = dev_empty_f32(n)
             hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
             got = to_host(out)
@@ -256,8 +257,9 @@ def test_fm_demod_forms_on_ordinary_and_awkward_signals(hip, oracle):
     exp = oracle.fm_demod(x)
     d_in = to_dev(x)
     try:
-        for form in (0, 1, 2, 3):
+        for form in (0, 1, 2, 3, 4):
             hip.lib.sdrhip_debug_set_demod_form(form)
+            assert hip.lib.sdrhip_debug_demod_form() == form
             out = dev_empty_f32(n)
             hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
             assert_bit_equal(to_host(out), exp, f"fmDemod, form {form}")
@@ -299,8 +301,9 @@ def test_fm_demod_forms_on_dense_argument_ranges(hip, oracle):
     d_in = to_dev(iq)
     n = iq.size // 2
     try:
-        for form in (0, 1, 2, 3):
+        for form in (0, 1, 2, 3, 4):
             hip.lib.sdrhip_debug_set_demod_form(form)
+            assert hip.lib.sdrhip_debug_demod_form() == form
             out = dev_empty_f32(n)
             hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
             assert_bit_equal(to_host(out), exp, f"fmDemod on swept ratios, form {form}")

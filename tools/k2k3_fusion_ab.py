@@ -14,8 +14,9 @@ st = torch.cuda.current_stream().cuda_stream
 def run(k):
     for _ in range(k): chain.run(u8.data_ptr(), 0, n + halo, out.data_ptr(), q0, q1, ws.data_ptr(), ws_bytes, stream=st)
 run(50); torch.cuda.synchronize()
-knob = sys.argv[1] if len(sys.argv) > 1 else "decim_demod"      # decim_demod | resamp_demod (fmDemod in the resampler's loader) | overlap-free knobs only
+knob = sys.argv[1] if len(sys.argv) > 1 else "decim_demod"      # decim_demod | resamp_demod | resamp_stream (fmDemod in the resampler's loader) | overlap-free knobs only
 setter = {"decim_demod": chain.set_decim_demod_fusion, "resamp_demod": chain.set_demod_fusion,
+          "resamp_stream": lambda on: L.lib.sdrhip_debug_set_resample_demod_stream(1 if on else 0),   # round 5: streaming fmDemod + resampler vs the tile kernel
           "fused_tail1": lambda on: chain.set_fused_tail(1 if on else 2), "fused_tail3": lambda on: chain.set_fused_tail(3 if on else 2),
           "nsub2": lambda on: chain.set_pipelining(2 if on else 1), "nsub4": lambda on: chain.set_pipelining(4 if on else 1),
           "nsub8": lambda on: chain.set_pipelining(8 if on else 1)}[knob]
