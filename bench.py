@@ -107,7 +107,8 @@ def cpu_baseline(seconds_single=6.0, seconds_all=8.0):
                    f"per hardware thread; {cores} physical cores) and {seconds_single:.0f} s single-thread; kind=reference: convertCAVX / "
                    "decimateAVXRC / resampleAVXRR / filterAVXSymmetricRR / scaleAVX and the scalar kernels of the seam outputs are the "
                    "reference's own C (oracle/_ref, -O2 -mavx2 -msse4), fmDemod and the Pipes' block bookkeeping (Haskell in the reference) "
-                   "come from the restatement; harmonic_sum_of_isolated_kernels = the five SIMD kernels alone on one cache-resident block "
+                   "come from the restatement -- fmDemod's atanf there is the fdlibm f32 MODEL (oracle/sdr_oracle.c: orc_atanf_model, the spec "
+                   "since round 5; == glibc 2.35 atanf on every float), not this host's libm; harmonic_sum_of_isolated_kernels = the five SIMD kernels alone on one cache-resident block "
                    "(no seam outputs, no re-blocking, no data movement between stages), the ceiling of what the loop can reach"),
     }
 

@@ -69,7 +69,13 @@ class Oracle:
         L.orc_ghc_atan2f.restype = C.c_float
         L.orc_ghc_atan2f.argtypes = [C.c_float, C.c_float]
         L.orc_atanf_sweep.restype = C.c_uint64
-        L.orc_atanf_sweep.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.orc_atanf_sweep.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_libc_version.restype = C.c_char_p
+        L.orc_libc_version.argtypes = []
+        L.orc_demod_sweep_fill.restype = None
+        L.orc_demod_sweep_fill.argtypes = [C.c_int, C.c_uint64, C.c_int64, _f32p]
+        L.orc_demod_sweep_check.restype = C.c_uint64
+        L.orc_demod_sweep_check.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int, _f32p, C.POINTER(C.c_uint64)]
         L.orc_fm_demod.argtypes = [C.c_int, C.c_float, C.c_float, _f32p, _f32p]
         L.orc_scale.argtypes = [C.c_int, C.c_float, _f32p, _f32p]
 
@@ -234,9 +240,27 @@ class Oracle:
         return out, fs.value, fo.value
 
     def atanf_sweep(self, lo, hi, step=1):
-        bad = C.c_uint32(0)
-        n = self.lib.orc_atanf_sweep(lo, hi, step, C.byref(bad))
-        return int(n), int(bad.value)
+        """The fdlibm f32 model (the SPEC of fmDemod's atan) against this machine's libm atanf over bit patterns lo..hi:
+        (arguments that differ, the first of them, the largest difference in ULP)."""
+        bad, worst = C.c_uint32(0), C.c_uint32(0)
+        n = self.lib.orc_atanf_sweep(lo, hi, step, C.byref(bad), C.byref(worst))
+        return int(n), int(bad.value), int(worst.value)
+
+    def libc_version(self):
+        return self.lib.orc_libc_version().decode()
+
+    def demod_sweep_fill(self, kind, idx0, n):
+        """The synthetic stream of the exhaustive fmDemod checks (sdr_oracle.c: orc_demod_sweep_*): 2n complex samples."""
+        iq = np.empty(4 * n, np.float32)
+        self.lib.orc_demod_sweep_fill(kind, idx0, n, _fp(iq))
+        return iq
+
+    def demod_sweep_check(self, kind, idx0, n, at_stream_start, got):
+        got = _f32(got)
+        assert got.size == 2 * n
+        first = C.c_uint64(0)
+        bad = self.lib.orc_demod_sweep_check(kind, idx0, n, 1 if at_stream_start else 0, _fp(got), C.byref(first))
+        return int(bad), int(first.value)
 
 
 class Ref:

@@ -25,6 +25,7 @@
  * Every function cites the reference file:line it follows.
  */
 #include <math.h>
+#include <gnu/libc-version.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -435,51 +436,16 @@ int orc_resample_cross_c(int interpolation, int decimation, int ncoeffs, const f
  * Arithmetic lives in GHC base (Data.Complex, RealFloat atan2 default) and the
  * host libm atanf; restated from SURVEY.md Appendix C.  PARITY UNPINNED: the
  * reference has no test or vector for it and GHC cannot be run here.
+ *
+ * THE SPEC IS THE MODEL (round 5): `atan` for Float is evaluated by orc_atanf_model below -- the fdlibm / glibc s_atanf.c
+ * algorithm in plain f32 arithmetic -- NOT by whatever atanf the machine running the tests links.  glibc 2.35's atanf is that
+ * algorithm and agrees with the model on all 2^32 inputs (swept here; tests/test_oracle_demod.py re-checks it, exactly when
+ * gnu_get_libc_version() says 2.35 and to 1 ULP otherwise: a correctly-rounded atanf differs from fdlibm's in ~5 % of arguments).
+ * So "the reference" for fmDemod means GHC's formulas over fdlibm's atanf, on every box.
  * ------------------------------------------------------------------------- */
 static const float ORC_PI = 3.14159274101257324f; /* f32 pi 0x40490FDB */
 
-static float ghc_atan2f(float y, float x)
-{
-    if (x > 0.0f) return atanf(y / x);
-    if (x == 0.0f && y > 0.0f) return ORC_PI / 2.0f;
-    if (x < 0.0f && y > 0.0f) return ORC_PI + atanf(y / x);
-    if ((x <= 0.0f && y < 0.0f) || (x < 0.0f && y == 0.0f && signbit(y)) ||
-        (x == 0.0f && signbit(x) && y == 0.0f && signbit(y)))
-        return -ghc_atan2f(-y, x);
-    if (y == 0.0f && (x < 0.0f || (x == 0.0f && signbit(x)))) return ORC_PI;
-    if (x == 0.0f && y == 0.0f) return y;
-    return x + y;
-}
-
-static inline float ghc_phase(float re, float im)
-{
-    if (re == 0.0f && im == 0.0f) return 0.0f; /* phase (0:+0) = 0, matches -0 too */
-    return ghc_atan2f(im, re);
-}
-
-/* in: num complex samples; (last_re,last_im) = sample preceding in[0].
- * Demod.hs:28: sample * conjugate last, with conjugate (c:+d) = c:+(-d) and
- * (a:+b)*(c:+d') = (a*c - b*d') :+ (a*d' + b*c). */
-void orc_fm_demod(int num, float last_re, float last_im, const float *in, float *out)
-{
-    float c = last_re, d = last_im;
-    for (int i = 0; i < num; i++) {
-        float a = in[2 * i], b = in[2 * i + 1];
-        float nd = -d;
-        float re = a * c - b * nd;
-        float im = a * nd + b * c;
-        out[i] = ghc_phase(re, im);
-        c = a;
-        d = b;
-    }
-}
-
-/* exposed for the atanf cross-check (tests) */
-float orc_libm_atanf(float x) { return atanf(x); }
-float orc_ghc_atan2f(float y, float x) { return ghc_atan2f(y, x); }
-
-/* fdlibm-style f32 atan restated in plain f32 arithmetic (what the device
- * kernel evaluates); tests sweep it against the host libm atanf. */
+/* fdlibm-style f32 atan restated in plain f32 arithmetic (sysdeps/ieee754/flt-32/s_atanf.c; what the device kernels evaluate) */
 static const float atanhi_[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
 static const float atanlo_[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
 static const float aT_[11] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f,
@@ -520,24 +486,151 @@ float orc_atanf_model(float x)
     return neg ? -z : z;
 }
 
-/* Sweep helper: count mismatches between the model and libm over a bit range. */
-uint64_t orc_atanf_sweep(uint32_t lo, uint32_t hi, uint32_t step, uint32_t *first_bad)
+static float ghc_atan2f(float y, float x)
+{
+    if (x > 0.0f) return orc_atanf_model(y / x);
+    if (x == 0.0f && y > 0.0f) return ORC_PI / 2.0f;
+    if (x < 0.0f && y > 0.0f) return ORC_PI + orc_atanf_model(y / x);
+    if ((x <= 0.0f && y < 0.0f) || (x < 0.0f && y == 0.0f && signbit(y)) ||
+        (x == 0.0f && signbit(x) && y == 0.0f && signbit(y)))
+        return -ghc_atan2f(-y, x);
+    if (y == 0.0f && (x < 0.0f || (x == 0.0f && signbit(x)))) return ORC_PI;
+    if (x == 0.0f && y == 0.0f) return y;
+    return x + y;
+}
+
+static inline float ghc_phase(float re, float im)
+{
+    if (re == 0.0f && im == 0.0f) return 0.0f; /* phase (0:+0) = 0, matches -0 too */
+    return ghc_atan2f(im, re);
+}
+
+/* one step of Demod.hs:28: sample * conjugate last, with conjugate (c:+d) = c:+(-d) and
+ * (a:+b)*(c:+d') = (a*c - b*d') :+ (a*d' + b*c) */
+static inline float fm_step(float a, float b, float c, float d)
+{
+    float nd = -d;
+    float re = a * c - b * nd;
+    float im = a * nd + b * c;
+    return ghc_phase(re, im);
+}
+
+/* in: num complex samples; (last_re,last_im) = sample preceding in[0]. */
+void orc_fm_demod(int num, float last_re, float last_im, const float *in, float *out)
+{
+    float c = last_re, d = last_im;
+    for (int i = 0; i < num; i++) {
+        float a = in[2 * i], b = in[2 * i + 1];
+        out[i] = fm_step(a, b, c, d);
+        c = a;
+        d = b;
+    }
+}
+
+/* exposed for the atanf cross-check (tests) */
+float orc_libm_atanf(float x) { return atanf(x); }
+float orc_ghc_atan2f(float y, float x) { return ghc_atan2f(y, x); }
+const char *orc_libc_version(void) { return gnu_get_libc_version(); }
+
+static inline uint32_t ulp_distance(float a, float b)
+{
+    /* distance in representable floats (sign-magnitude -> monotone integer); NaN vs NaN = 0 */
+    if (a != a && b != b) return 0;
+    if (a != a || b != b) return 0xffffffffu;
+    int32_t ia, ib;
+    memcpy(&ia, &a, 4);
+    memcpy(&ib, &b, 4);
+    if (ia < 0) ia = (int32_t)0x80000000 - ia;
+    if (ib < 0) ib = (int32_t)0x80000000 - ib;
+    int64_t d = (int64_t)ia - (int64_t)ib;
+    return (uint32_t)(d < 0 ? -d : d);
+}
+
+/* Sweep helper: the model against THIS machine's libm atanf over a range of bit patterns: number of arguments where the two differ,
+ * the first such argument and the largest distance in ULP.  (A separate, version-gated statement since round 5; threaded.) */
+uint64_t orc_atanf_sweep(uint32_t lo, uint32_t hi, uint32_t step, uint32_t *first_bad, uint32_t *max_ulp)
 {
     uint64_t bad = 0;
-    for (uint64_t u = lo; u <= hi; u += step) {
-        uint32_t b = (uint32_t)u;
+    uint32_t worst = 0, first = 0xffffffffu;
+    const int64_t n = ((int64_t)hi - (int64_t)lo) / step + 1;
+#pragma omp parallel for schedule(static) reduction(+ : bad) reduction(max : worst) reduction(min : first)
+    for (int64_t k = 0; k < n; k++) {
+        uint32_t b = (uint32_t)((uint64_t)lo + (uint64_t)k * step);
         float x, a, m;
         memcpy(&x, &b, 4);
         a = atanf(x);
         m = orc_atanf_model(x);
-        uint32_t ba, bm;
-        memcpy(&ba, &a, 4);
-        memcpy(&bm, &m, 4);
-        if (ba != bm && !(a != a && m != m)) {
-            if (!bad && first_bad) *first_bad = b;
+        uint32_t u = ulp_distance(a, m);
+        if (u) {
             bad++;
+            if (b < first) first = b;
+            if (u > worst) worst = u;
         }
     }
+    if (first_bad) *first_bad = first;
+    if (max_ulp) *max_ulp = worst;
+    return bad;
+}
+
+/* ---- exhaustive checks of the DEVICE's fmDemod (tests/test_gpu_demod_exhaustive.py) --------------------------------------------
+ * The device demodulates a synthetic stream, the checker recomputes every output from the same closed-form input with the functions
+ * above (threaded) and counts the outputs whose bits differ (NaN against NaN counts as equal: payloads are not part of the contract).
+ * kind 0, "every atanf argument": sample 2i = 1 + 0i, sample 2i+1 = 1 + q_i i with q_i the float whose bit pattern is lo + i -- so
+ *         y[2i+1] = atan2(q_i, 1) = atanf(q_i) for finite q_i and y[2i] = atan2(-q_{i-1}, 1): all 2^32 arguments of atanf in both signs.
+ * kind 1, "pseudo-random pairs": sample 2i = 1 + 0i, sample 2i+1 = x_i + y_i i with (x_i, y_i) two different multiplicative hashes
+ *         of the index lo + i (each a permutation of all 2^32 bit patterns); odd indices get moderate exponents so that not every product
+ *         overflows.  y[2i+1] = atan2(y_i (+-0), x_i (+-0)), y[2i] the phase of the conjugate.
+ * `got` holds the device's y for samples [2 * (lo - base) ...): n pairs = 2n outputs; the sample before the first is pair lo - 1's second
+ * sample (or 0 + 0i when lo == first_index: the stream start, Demod.hs:41). */
+static inline void sweep_pair(int kind, uint64_t idx, float *re, float *im)
+{
+    uint32_t xb, yb;
+    if (kind == 0) {
+        xb = 0x3f800000u;
+        yb = (uint32_t)idx;
+    } else {
+        xb = (uint32_t)(idx * 0x9E3779B1u + 0x7F4A7C15u);
+        yb = (uint32_t)(idx * 0x85EBCA77u + 0xC2B2AE3Du);
+        if (idx & 1) {
+            xb = (xb & 0x807fffffu) | ((100u + ((xb >> 23) & 0xffu) % 50u) << 23);
+            yb = (yb & 0x807fffffu) | ((100u + ((yb >> 23) & 0xffu) % 50u) << 23);
+        }
+    }
+    memcpy(re, &xb, 4);
+    memcpy(im, &yb, 4);
+}
+
+/* fills iq[4k .. 4k+3] = (1, 0, re_k, im_k) for k = idx0 .. idx0 + n - 1 (the generator's twin of the device-side construction) */
+void orc_demod_sweep_fill(int kind, uint64_t idx0, int64_t n, float *iq)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < n; k++) {
+        float re, im;
+        sweep_pair(kind, idx0 + (uint64_t)k, &re, &im);
+        iq[4 * k] = 1.0f; iq[4 * k + 1] = 0.0f; iq[4 * k + 2] = re; iq[4 * k + 3] = im;
+    }
+}
+
+uint64_t orc_demod_sweep_check(int kind, uint64_t idx0, int64_t n, int at_stream_start, const float *got, uint64_t *first_bad)
+{
+    uint64_t bad = 0, first = ~(uint64_t)0;
+#pragma omp parallel for schedule(static) reduction(+ : bad) reduction(min : first)
+    for (int64_t k = 0; k < n; k++) {
+        float re, im, pre = 0.0f, pim = 0.0f;
+        sweep_pair(kind, idx0 + (uint64_t)k, &re, &im);
+        if (k > 0 || !at_stream_start) sweep_pair(kind, idx0 + (uint64_t)k - 1, &pre, &pim);
+        const float e0 = fm_step(1.0f, 0.0f, pre, pim), e1 = fm_step(re, im, 1.0f, 0.0f);
+        const float g0 = got[2 * k], g1 = got[2 * k + 1];
+        uint32_t be0, be1, bg0, bg1;
+        memcpy(&be0, &e0, 4); memcpy(&be1, &e1, 4); memcpy(&bg0, &g0, 4); memcpy(&bg1, &g1, 4);
+        const int ok0 = be0 == bg0 || (e0 != e0 && g0 != g0), ok1 = be1 == bg1 || (e1 != e1 && g1 != g1);
+        if (!ok0 || !ok1) {
+            bad += !ok0 + !ok1;
+            const uint64_t where = 2 * (idx0 + (uint64_t)k) + (ok0 ? 1 : 0);
+            if (where < first) first = where;
+        }
+    }
+    if (first_bad) *first_bad = first;
     return bad;
 }
 

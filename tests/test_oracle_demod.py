@@ -9,17 +9,43 @@ import numpy as np
 import signals as S
 
 
-def test_atanf_model_matches_libm_on_a_dense_sweep(oracle):
-    """The f32 fdlibm evaluation the GPU kernels use == the host libm atanf.
-    (All 2^32 inputs were swept once when this was written: 0 mismatches; here every
-    97th float plus the neighbourhoods of the range boundaries.)"""
-    bad, first = oracle.atanf_sweep(0, 0xFFFFFFFF, 97)
-    assert bad == 0, f"first mismatch at {first:#x}"
+SWEPT_LIBC = "2.35"        # the glibc whose atanf was compared with the model on all 2^32 inputs: 0 differences
+
+
+def check_model_against_this_libm(oracle, stride=97):
+    """The SPEC of fmDemod's `atan` is the fdlibm f32 model (oracle/sdr_oracle.c: orc_atanf_model; the device evaluates the same
+    operations, demod.hpp).  Its agreement with the libm of the machine running the tests is a SEPARATE statement: exact on the
+    glibc it was swept against, within 1 ULP on any other (a correctly-rounded atanf differs from fdlibm's in ~5 % of arguments) --
+    so a different libm on the GPU box moves neither the test suite nor what `the reference` means."""
+    exact = oracle.libc_version() == SWEPT_LIBC
+    bad, first, worst = oracle.atanf_sweep(0, 0xFFFFFFFF, stride)
+    if exact:
+        assert bad == 0, f"glibc {SWEPT_LIBC}: first mismatch at {first:#x}, up to {worst} ULP"
+    else:
+        assert worst <= 1, f"glibc {oracle.libc_version()}: the model is {worst} ULP from atanf at {first:#x}"
     for edge in (0x31000000, 0x3ee00000, 0x3f300000, 0x3f980000, 0x401c0000, 0x4c000000, 0x7f800000):
         for sign in (0, 0x80000000):
             lo = (edge | sign) - 4096
-            bad, first = oracle.atanf_sweep(lo, lo + 8192, 1)
-            assert bad == 0, f"first mismatch at {first:#x}"
+            bad, first, worst = oracle.atanf_sweep(lo, lo + 8192, 1)
+            assert (bad == 0) if exact else (worst <= 1), f"first mismatch at {first:#x} ({worst} ULP)"
+    return exact
+
+
+def test_atanf_model_matches_libm_on_a_dense_sweep(oracle):
+    """(All 2^32 inputs were swept when this was written: 0 mismatches; here every 97th float plus the neighbourhoods of the
+    range boundaries.  tests/test_gpu_demod_exhaustive.py runs the same statement, over every float, on the GPU box's host.)"""
+    check_model_against_this_libm(oracle, 97)
+
+
+def test_the_oracle_does_not_call_libm_for_fm_demod(oracle):
+    """orc_fm_demod / orc_ghc_atan2f must give the model's bits whatever libm says: the arguments where a correctly-rounded atanf
+    and fdlibm's differ are not rare (about one in twenty), so equality with the model on a few thousand ratios pins the wiring."""
+    rng = np.random.default_rng(11)
+    q = np.exp2(rng.uniform(-28, 24, 4000)).astype(np.float32) * rng.choice(np.array([-1.0, 1.0], np.float32), 4000)
+    for v in q:
+        a = oracle.lib.orc_ghc_atan2f(float(v), 1.0)
+        m = oracle.lib.orc_atanf_model(float(v))
+        assert np.float32(a).view(np.uint32) == np.float32(m).view(np.uint32)
 
 
 def test_ghc_atan2_quadrants(oracle):
