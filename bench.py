@@ -148,16 +148,22 @@ def plumbing_check(args, rank, world):
     S_len = min(args.blocks, 128) * BLOCK                            # up to BASELINE configs[4]'s shard: 2^20 samples per rank
     plan = sharding.ShardPlan(chain, rank, world, S_len)
     stream = S.iq_u8(world * S_len + plan.halo_cap)                # the same global stream on every rank
-    buf = torch.zeros(2 * plan.n_in, dtype=torch.uint8)
-    buf[:2 * S_len] = torch.from_numpy(stream[2 * plan.s0:2 * plan.s1].copy())
+    K = max(1, args.passes_per_exchange)
+    # row k: this rank's shard of super-block k (the stream with k added to every byte, so that a halo in the wrong row shows)
+    rows = torch.zeros(K, 2 * plan.n_in, dtype=torch.uint8)
+    for k in range(K):
+        rows[k, :2 * S_len] = torch.from_numpy((stream[2 * plan.s0:2 * plan.s1] + np.uint8(k)).copy())
     t0 = time.perf_counter()
     for _ in range(args.warmup + args.steps):
-        sharding.halo_exchange(buf, plan, dist)
+        if K == 1:
+            sharding.halo_exchange(rows[0], plan, dist)
+        else:
+            sharding.halo_exchange_batch(rows, plan, dist)
     if world > 1:
         dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     right0 = ((rank + 1) % world) * S_len
-    ok = bool(np.array_equal(buf[2 * S_len:].numpy(), stream[2 * right0:2 * (right0 + plan.halo_cap)])) or world == 1
+    ok = world == 1 or all(np.array_equal(rows[k, 2 * S_len:].numpy(), stream[2 * right0:2 * (right0 + plan.halo_cap)] + np.uint8(k)) for k in range(K))
     mine = (plan.q0, plan.q1, ok, float(el.item()))
     plans = [mine]
     if world > 1:
@@ -169,7 +175,7 @@ def plumbing_check(args, rank, world):
         print(json.dumps({"plumbing_only": True, "metric": "none (BENCH_PLUMBING=1: launch, plans and halo exchange only, no device work)",
                           "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks_seen": len(plans),
                           "halo_ok_on_every_rank": all(p[2] for p in plans), "owned_outputs_tile_the_stream": tiles,
-                          "halo_transport": "host memory through gloo", "seconds": round(float(el.item()), 4),
+                          "halo_transport": "host memory through gloo", "seconds": round(float(el.item()), 4), "passes_per_exchange": K,
                           "samples_per_rank": S_len, "halo_samples": plan.halo_cap,
                           # a shard's first audio output rarely starts a polyphase cycle: the resampler's group (phase) of q0
                           "resampler_group_of_first_output_per_rank": [p[0] % 3 for p in plans],
@@ -202,6 +208,9 @@ def main():
     ap.add_argument("--passes-per-step", type=int, default=0,
                     help="passes of the chain over the batch that make one step (0 = auto: ~50 ms of GPU time per step, so that "
                          "the default 20 steps keep the GPU busy for ~1 s and an outside utilisation sampler can see the run)")
+    ap.add_argument("--passes-per-exchange", type=int, default=1,
+                    help="N > 1 ranks: exchange the halos of this many consecutive super-blocks in ONE send/recv pair, then run that many "
+                         "passes (sdrhip_fm_chain_halo_exchange_batch): a launch-bound shard cannot hide a point-to-point round trip per pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the contract line (profiling runs)")
     ap.add_argument("--cpu-worker", type=float, default=None, help="only the compiled CPU receiver loop, single thread, for this many seconds")
@@ -308,7 +317,7 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
 
-    def measure(blocks, steps, warmup, passes, ramp_s, timing, graph=False, do_exchange=True, data="uniform", lib_overlap=False):
+    def measure(blocks, steps, warmup, passes, ramp_s, timing, graph=False, do_exchange=True, data="uniform", lib_overlap=False, ppe=1):
         """One configuration: `blocks` 8192-sample blocks per GPU per pass.  Returns the max-over-ranks wall time of
         `steps` steps of `passes` passes each, the per-stage HIP-event times and the plan.  graph: the chain's kernels of
         one pass replayed from a hipGraph captured once (sdrhip_fm_chain_graph_*): one launch per pass instead of one per kernel."""
@@ -330,6 +339,15 @@ def main():
             del t, ph, nz
         else:
             buf = torch.randint(0, 256, (2 * (S_len + plan.halo_cap),), dtype=torch.uint8, device="cuda", generator=gen)
+        # ppe > 1 (N > 1): the rank's shards of ppe consecutive super-blocks as rows of one buffer; their halos travel in one message pair
+        ppe = ppe if (world > 1 and not graph and data == "uniform") else 1
+        rows = staging = None
+        row_bytes = 2 * (S_len + plan.halo_cap)
+        if ppe > 1:
+            rows = torch.randint(0, 256, (ppe, row_bytes), dtype=torch.uint8, device="cuda", generator=gen)
+            staging = torch.empty(max(1, chain.halo_staging_bytes(ppe)), dtype=torch.uint8, device="cuda")
+            buf = rows[0]
+        pidx = [0]
         audio = torch.empty(plan.q1 - plan.q0, dtype=torch.float32, device="cuda")
         # lib_overlap (N = 1): two passes in flight INSIDE the library (sdrhip_fm_chain_set_overlap): consecutive runs alternate
         # between two internal streams and workspace halves; the audio is double-buffered as that contract asks
@@ -352,6 +370,14 @@ def main():
         def exchange(on_stream):
             if not do_exchange:          # "replicas only": the same passes with the halo left as it is (upper bound of the scaling)
                 return
+            if ppe > 1:
+                if pidx[0] % ppe != 0:   # the halos of this super-block arrived with the batch
+                    return
+                if comm is not None:
+                    comm.chain_halo_exchange_batch(chain, rows.data_ptr(), S_len, row_bytes, ppe, staging.data_ptr(), stream=on_stream.cuda_stream)
+                else:
+                    sharding.halo_exchange_batch(rows, plan, dist, via_host=True)
+                return
             if comm is not None:
                 comm.chain_halo_exchange(chain, buf.data_ptr(), S_len, stream=on_stream.cuda_stream)   # ncclSend/ncclRecv on that stream
             else:
@@ -368,6 +394,13 @@ def main():
                                     plan.q1, ws_b.data_ptr(), ws_bytes)
 
         def one_pass():
+            in_ptr = buf.data_ptr() if ppe == 1 else rows.data_ptr() + (pidx[0] % ppe) * row_bytes
+            try:
+                _one_pass(in_ptr)
+            finally:
+                pidx[0] += 1
+
+        def _one_pass(in_ptr):
             if lib_overlap:
                 flip[0] ^= 1
                 chain.run(buf.data_ptr(), plan.s0, plan.n_in, (audio_b if flip[0] else audio).data_ptr(), plan.q0, plan.q1, ws.data_ptr(), ws_bytes, stream=sptr)
@@ -378,7 +411,7 @@ def main():
                 if g_all is not None:
                     g_all.launch(sptr)
                 else:
-                    chain.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q1, ws.data_ptr(), ws_bytes, stream=sptr)
+                    chain.run(in_ptr, plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q1, ws.data_ptr(), ws_bytes, stream=sptr)
                 return
             aux.wait_stream(stream)                      # the previous pass's readers of the halo region are done
             with torch.cuda.stream(aux):
@@ -387,12 +420,12 @@ def main():
                     if g_b is not None:
                         g_b.launch(aux.cuda_stream)
                     else:
-                        chain_b.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr() + 4 * (plan.q_mid - plan.q0), plan.q_mid, plan.q1,
+                        chain_b.run(in_ptr, plan.s0, plan.n_in, audio.data_ptr() + 4 * (plan.q_mid - plan.q0), plan.q_mid, plan.q1,
                                     ws_b.data_ptr(), ws_bytes, stream=aux.cuda_stream)
             if g_a is not None:
                 g_a.launch(sptr)
             else:
-                chain.run(buf.data_ptr(), plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q_mid, ws.data_ptr(), ws_bytes, stream=sptr)
+                chain.run(in_ptr, plan.s0, plan.n_in, audio.data_ptr(), plan.q0, plan.q_mid, ws.data_ptr(), ws_bytes, stream=sptr)
             stream.wait_stream(aux)
 
         # Clock / power-state ramp: the first ~15 ms of sustained work of a fresh process run 10 % slow; spin for ramp_s first.
@@ -466,10 +499,25 @@ def main():
                 gathered = [None] * world
                 dist.all_gather_object(gathered, crc[0])
                 crc = gathered
+        # what one exchange costs on its own: back-to-back exchanges on the compute stream, nothing else queued (N > 1, RCCL only)
+        exch_us = None
+        if world > 1 and do_exchange and comm is not None:
+            pidx[0] = 0
+            torch.cuda.synchronize()
+            dist.barrier()
+            nex = 50
+            tq = time.perf_counter()
+            for _ in range(nex):
+                pidx[0] = 0
+                exchange(stream)
+            torch.cuda.synchronize()
+            te = torch.tensor([(time.perf_counter() - tq) / nex * 1e6], dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            exch_us = float(te.item())
         del g_all, g_a, g_b
-        del buf, audio, ws
+        del buf, audio, ws, rows, staging
         return {"elapsed": elapsed, "passes": passes, "stage_ms": stage_ms, "plan": plan, "S_len": S_len, "overlap": overlap, "crc": crc,
-                "lib_overlap": lib_overlap, "same_audio": same_audio, "rank_elapsed": rank_elapsed}
+                "lib_overlap": lib_overlap, "same_audio": same_audio, "rank_elapsed": rank_elapsed, "ppe": ppe, "exchange_us": exch_us}
 
     def measure_in_flight(blocks, steps, warmup, nflight, do_exchange=True):
         """Launch-bound shards: `nflight` passes in flight, pass i on HIP stream i % nflight with its own input / audio
@@ -664,7 +712,7 @@ def main():
     # per-kernel durations are not blurred by co-resident kernels (BENCH_NO_LIB_OVERLAP=1: one pass at a time throughout).
     want_overlap = world == 1 and os.environ.get("BENCH_NO_LIB_OVERLAP") != "1" and args.blocks >= 2048
     events_in_region = args.blocks >= 2048 and not want_overlap
-    main_run = measure(args.blocks, args.steps, args.warmup, args.passes_per_step, 0.3, events_in_region, lib_overlap=want_overlap)
+    main_run = measure(args.blocks, args.steps, args.warmup, args.passes_per_step, 0.3, events_in_region, lib_overlap=want_overlap, ppe=max(1, args.passes_per_exchange))
     single_pass = None
     if want_overlap:
         single_pass = measure(args.blocks, args.steps, 1, main_run["passes"], 0.05, True)
@@ -704,10 +752,11 @@ def main():
     shard_1m = None
     if extras and args.blocks != 128:
         st1 = max(2, args.steps // 4)
-        r1 = measure(128, st1, 1, 0, 0.05, False)
+        r1 = measure(128, st1, 1, 0, 0.05, False, ppe=max(1, args.passes_per_exchange))
         shard_1m = {"samples_per_gpu_per_pass": r1["S_len"], "passes_per_step": r1["passes"],
                     "value": round(world * r1["S_len"] * r1["passes"] * st1 / r1["elapsed"] / 1e6, 1), "unit": "Msamples/s",
                     "us_per_pass": round(r1["elapsed"] / (r1["passes"] * st1) * 1e6, 2),
+                    "passes_per_exchange": r1["ppe"], "exchange_us_per_pass": None if r1["exchange_us"] is None else round(r1["exchange_us"] / r1["ppe"], 2),
                     "note": "BASELINE configs[4] shard size (1M-sample block per GPU per pass): launch/latency-bound"}
         try:
             el2, p2, sl2, same2 = measure_in_flight(128, st1, 1, 2)
@@ -916,6 +965,9 @@ def main():
                 "sharding": "none" if world == 1 else f"contiguous shards x{world}, halo exchange of {plan.halo_cap} samples per pass"
                             + (", overlapped with the outputs that need no halo" if main_run["overlap"] else ""),
                 "ranks_seen_by_rccl": None if comm is None else comm.size,
+                "passes_per_exchange": main_run["ppe"],
+                "exchange_us_per_pass": None if main_run["exchange_us"] is None else round(main_run["exchange_us"] / main_run["ppe"], 2),
+                "exchange_us_what": "one halo exchange alone on the compute stream (50 back to back, maximum over ranks) divided by the passes it serves",
                 "devices_visible": ndev,
                 **({"ranks_share_devices": True} if world > ndev else {}),
                 "halo_transport": None if world == 1 else ("rccl: ncclSend/ncclRecv inside libsdr_hip.so (sdrhip_fm_chain_halo_exchange) on the compute stream"

@@ -462,6 +462,16 @@ int sdrhip_halo_exchange_all(sdrhip_comm *const *comms, int ndev, void *const *s
 int64_t sdrhip_fm_chain_halo_samples(const sdrhip_fm_chain *c);
 int sdrhip_fm_chain_halo_exchange(const sdrhip_fm_chain *chain, sdrhip_comm *comm, void *stream, uint8_t *d_buf,
                                   int64_t shard_samples);
+/* The halos of `count` consecutive super-blocks in ONE message pair (round 5): the rank's shard of super-block k lies at
+ * d_buf + k * row_bytes (head at +0, halo region at + 2 * shard_samples, as above).  The heads are gathered into d_staging
+ * (hipMemcpy2DAsync), one ncclSend / ncclRecv of count * 2 * halo bytes moves them, and the received ones are scattered into the
+ * halo regions -- all on `stream`.  A launch-bound shard (2^20 samples: ~11 us per pass) cannot hide a point-to-point round trip
+ * per pass; with count passes per exchange the round trip is paid once per count passes at the price of count super-blocks
+ * being resident before the first is processed.  d_staging:
+ * sdrhip_fm_chain_halo_staging_bytes(chain, count) bytes of device memory (a send and a receive half). */
+size_t sdrhip_fm_chain_halo_staging_bytes(const sdrhip_fm_chain *chain, int count);
+int sdrhip_fm_chain_halo_exchange_batch(const sdrhip_fm_chain *chain, sdrhip_comm *comm, void *stream, uint8_t *d_buf,
+                                        int64_t shard_samples, size_t row_bytes, int count, void *d_staging);
 
 /* Host-block streaming front end of the chain: u8 IQ source blocks in (host memory, `block` samples
  * each or a whole multiple), audio blocks of exactly block_size_out floats out -- the five middle

@@ -289,6 +289,31 @@ int sdrhip_fm_chain_halo_exchange(const sdrhip_fm_chain* chain, sdrhip_comm* com
     return sdrhip_halo_exchange(comm, stream, d_buf, d_buf + 2 * shard_samples, (size_t)(2 * halo));
 }
 
+size_t sdrhip_fm_chain_halo_staging_bytes(const sdrhip_fm_chain* chain, int count)
+{
+    if (!chain || count < 1) return 0;
+    return 2 * (size_t)count * (size_t)(2 * sdrhip_fm_chain_halo_samples(chain));
+}
+
+int sdrhip_fm_chain_halo_exchange_batch(const sdrhip_fm_chain* chain, sdrhip_comm* comm, void* stream, uint8_t* d_buf, int64_t shard_samples,
+                                        size_t row_bytes, int count, void* d_staging)
+{
+    SDRHIP_REQUIRE(chain != nullptr && comm != nullptr && d_buf != nullptr && shard_samples > 0 && count >= 1, "sdrhip_fm_chain_halo_exchange_batch");
+    const size_t hb = (size_t)(2 * sdrhip_fm_chain_halo_samples(chain));            // bytes of one halo
+    SDRHIP_REQUIRE((int64_t)hb <= 2 * shard_samples, "sdrhip_fm_chain_halo_exchange_batch: shard shorter than the halo");
+    if (count == 1) return sdrhip_halo_exchange(comm, stream, d_buf, d_buf + 2 * shard_samples, hb);
+    SDRHIP_REQUIRE(d_staging != nullptr && row_bytes >= (size_t)(2 * shard_samples) + hb, "sdrhip_fm_chain_halo_exchange_batch: rows hold a shard and its halo");
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t* send = (uint8_t*)d_staging;
+    uint8_t* recv = send + (size_t)count * hb;
+    // heads of the count rows -> one contiguous message; the received message -> the count halo regions
+    SDRHIP_CHECK_HIP(hipMemcpy2DAsync(send, hb, d_buf, row_bytes, hb, (size_t)count, hipMemcpyDeviceToDevice, s));
+    const int rc = sdrhip_halo_exchange(comm, stream, send, recv, (size_t)count * hb);
+    if (rc != SDRHIP_OK) return rc;
+    SDRHIP_CHECK_HIP(hipMemcpy2DAsync(d_buf + 2 * shard_samples, row_bytes, recv, hb, hb, (size_t)count, hipMemcpyDeviceToDevice, s));
+    return SDRHIP_OK;
+}
+
 size_t sdrhip_fm_chain_workspace_bytes(const sdrhip_fm_chain* c, int64_t n_in)
 {
     if (!c || n_in < 0) return 0;

@@ -154,6 +154,9 @@ lib.sdrhip_fm_chain_read_timing.argtypes = [_vp, C.POINTER(C.c_double), C.POINTE
 lib.sdrhip_fm_chain_halo_samples.argtypes = [_vp]
 lib.sdrhip_fm_chain_halo_samples.restype = _i64
 lib.sdrhip_fm_chain_halo_exchange.argtypes = [_vp, _vp, _vp, _vp, _i64]
+lib.sdrhip_fm_chain_halo_staging_bytes.argtypes = [_vp, C.c_int]
+lib.sdrhip_fm_chain_halo_staging_bytes.restype = C.c_size_t
+lib.sdrhip_fm_chain_halo_exchange_batch.argtypes = [_vp, _vp, _vp, _vp, _i64, C.c_size_t, C.c_int, _vp]
 lib.sdrhip_comm_get_unique_id.argtypes = [C.c_char_p]
 lib.sdrhip_comm_init_rank.argtypes = [C.POINTER(_vp), C.c_int, C.c_int, C.c_char_p]
 lib.sdrhip_comm_init_local.argtypes = [C.POINTER(_vp), C.c_int, C.POINTER(C.c_int), C.c_int]
@@ -455,6 +458,9 @@ class FmChain(_Handle):
     def max_halo(self):
         return lib.sdrhip_fm_chain_max_halo(self.h)
 
+    def halo_staging_bytes(self, count):
+        return int(lib.sdrhip_fm_chain_halo_staging_bytes(self.h, count))
+
     def halo_samples(self):
         """max_halo rounded up to whole 16-byte vectors: the size of the halo message, the same on every rank."""
         return int(lib.sdrhip_fm_chain_halo_samples(self.h))
@@ -575,6 +581,11 @@ class Comm(_Handle):
 
     def chain_halo_exchange(self, chain, d_buf, shard_samples, stream=None):
         check(lib.sdrhip_fm_chain_halo_exchange(chain.h, self.h, stream, d_buf, shard_samples), "sdrhip_fm_chain_halo_exchange")
+
+    def chain_halo_exchange_batch(self, chain, d_buf, shard_samples, row_bytes, count, d_staging, stream=None):
+        """The halos of `count` consecutive super-blocks (rows of row_bytes at d_buf) in one message pair."""
+        check(lib.sdrhip_fm_chain_halo_exchange_batch(chain.h, self.h, stream, d_buf, shard_samples, row_bytes, count, d_staging),
+              "sdrhip_fm_chain_halo_exchange_batch")
 
 
 def halo_exchange_all(comms, streams, d_send, d_recv, nbytes):

@@ -72,3 +72,26 @@ def halo_exchange(buf_u8, plan, dist, via_host=False):
     ops = [dist.P2POp(dist.isend, head, plan.left), dist.P2POp(dist.irecv, tail, plan.right)]
     for req in dist.batch_isend_irecv(ops):
         req.wait()
+
+
+def halo_exchange_batch(rows_u8, plan, dist, via_host=False):
+    """The halos of K consecutive super-blocks in ONE message pair (the twin of sdrhip_fm_chain_halo_exchange_batch):
+    rows_u8 is a 2-D uint8 tensor [K, 2*(shard_len + halo_cap)], row k = this rank's shard of super-block k followed by its halo
+    region.  Sends the K heads to the LEFT neighbour as one message and receives the RIGHT neighbour's K heads into the K halo
+    regions.  For the last rank the right neighbour is rank 0, whose row k then stands for the head of super-block k + 1's first
+    shard (a stream cut into super-blocks hands that over as carried state; the synthetic benchmark re-reads the same rows)."""
+    if plan.world == 1:
+        return
+    nb = 2 * plan.halo_cap
+    heads = rows_u8[:, :nb].contiguous()                       # gather (the library: hipMemcpy2DAsync)
+    if via_host or heads.is_cuda and dist.get_backend() == "gloo":
+        h = heads.cpu()
+        r = h.new_empty(h.shape)
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, h, plan.left), dist.P2POp(dist.irecv, r, plan.right)]):
+            req.wait()
+        rows_u8[:, 2 * plan.shard_len: 2 * plan.shard_len + nb] = r.to(rows_u8.device)
+        return
+    recv = heads.new_empty(heads.shape)
+    for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, heads, plan.left), dist.P2POp(dist.irecv, recv, plan.right)]):
+        req.wait()
+    rows_u8[:, 2 * plan.shard_len: 2 * plan.shard_len + nb] = recv      # scatter

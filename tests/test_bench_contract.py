@@ -68,6 +68,21 @@ def test_eight_ranks_at_the_shard_size_of_baseline_config_4():
     assert sum(1 for g in r["resampler_group_of_first_output_per_rank"] if g != 0) >= 4, r["resampler_group_of_first_output_per_rank"]
 
 
+def test_eight_ranks_sixteen_super_blocks_per_exchange():
+    """--passes-per-exchange 16 (VERDICT r04 "next" 7): the halos of 16 consecutive super-blocks travel in ONE message pair per rank;
+    every row's halo region must hold the right neighbour's head of THAT super-block (rows differ by construction)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["BENCH_PLUMBING"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--blocks", "128", "--steps", "2", "--warmup", "1", "--no-extras",
+                          "--passes-per-exchange", "16"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["ranks_seen"] == 8 and r["passes_per_exchange"] == 16
+    assert r["halo_ok_on_every_rank"] and r["owned_outputs_tile_the_stream"]
+
+
 def test_world_size_that_disagrees_with_gpus_is_refused():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BENCH_PLUMBING="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-extras"],

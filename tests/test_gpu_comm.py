@@ -52,6 +52,33 @@ def test_rccl_ring_of_one_process_per_gpu(hip):
     comm.close()
 
 
+@pytest.mark.parametrize("count", [1, 2, 16])
+def test_rccl_halos_of_several_super_blocks_in_one_message(hip, count):
+    """sdrhip_fm_chain_halo_exchange_batch (round 5): `count` rows, each a shard and its halo region; one gather, one send / recv pair,
+    one scatter.  Ring of one: every row's halo region must end up holding THAT row's head; guard bytes behind every row stay."""
+    import torch
+    L = hip
+    ch = _chain(L)
+    shard, halo = 1 << 16, ch.halo_samples()
+    comm = L.Comm(1, 0, L.comm_unique_id())
+    row_bytes = 2 * (shard + halo) + 64                       # 64 guard bytes behind every row
+    rows = torch.full((count, row_bytes), 0xEE, dtype=torch.uint8, device="cuda")
+    for k in range(count):
+        rows[k, : 2 * shard] = torch.from_numpy(_pattern(k + 1, 2 * shard)).cuda()
+    staging = torch.empty(max(1, ch.halo_staging_bytes(count)), dtype=torch.uint8, device="cuda")
+    assert ch.halo_staging_bytes(count) == 2 * count * 2 * halo
+    st = torch.cuda.current_stream()
+    for _ in range(2):
+        comm.chain_halo_exchange_batch(ch, rows.data_ptr(), shard, row_bytes, count, staging.data_ptr(), stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    got = rows.cpu().numpy()
+    for k in range(count):
+        assert np.array_equal(got[k, 2 * shard: 2 * (shard + halo)], _pattern(k + 1, 2 * halo)), f"row {k}: halo"
+        assert np.array_equal(got[k, : 2 * shard], _pattern(k + 1, 2 * shard)), f"row {k}: the shard itself changed"
+        assert (got[k, 2 * (shard + halo):] == 0xEE).all(), f"row {k}: wrote past the halo region"
+    comm.close()
+
+
 @pytest.mark.parametrize("transport", ["rccl", "peer-copy"])
 def test_single_process_ring_over_all_devices(hip, transport):
     """sdrhip_comm_init_local + sdrhip_halo_exchange_all over every visible device (1 on the test box, 8 on a node)."""

@@ -44,6 +44,16 @@ def _worker(rank, world, port, shard_len, q):
         right0 = ((rank + 1) % world) * shard_len
         exp = stream[2 * right0: 2 * (right0 + plan.halo_cap)]
         ok_halo = bool(np.array_equal(got, exp))
+        # the same for K super-blocks in one message pair (sdrhip_fm_chain_halo_exchange_batch's twin): row k = the shard of super-block
+        # k, marked by adding k to every byte, so a halo that lands in the wrong row (or the wrong rank's) is seen
+        for K in (2, 5):
+            rows = torch.zeros(K, 2 * plan.n_in, dtype=torch.uint8)
+            for k in range(K):
+                rows[k, : 2 * shard_len] = torch.from_numpy((stream[2 * plan.s0: 2 * plan.s1] + np.uint8(17 * k)).copy())
+            sharding.halo_exchange_batch(rows, plan, dist)
+            for k in range(K):
+                ok_halo = ok_halo and bool(np.array_equal(rows[k, 2 * shard_len:].numpy(), exp + np.uint8(17 * k)))
+                ok_halo = ok_halo and bool(np.array_equal(rows[k, : 2 * shard_len].numpy(), stream[2 * plan.s0: 2 * plan.s1] + np.uint8(17 * k)))
         # planned outputs read only [s0, s1 + halo) and halo <= halo_cap
         ok_range = plan.halo <= plan.halo_cap and plan.q1 >= plan.q0
         gathered = [None] * world
