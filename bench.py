@@ -880,16 +880,94 @@ def main():
                         "(and cpu_single_thread_chain) includes"}
         host["note_adaptive"] = ("pushes are submitted at once while the GPU keeps up and pile up in the pinned staging buffer while it is busy "
                                  "(sdrhip_fm_stream_set_adaptive, on by default): *_every_push_its_own_launch is the same run with that off")
+        # The link ceiling of THIS process (SURVEY 8(d) "Host-link ceiling"): pinned hipMemcpyAsync both ways and a kernel reading
+        # pinned host memory in place (what the zero-copy pushes do), each over 256 MiB, best of three
+        link = None
+        try:
+            nb = 256 << 20
+            hp = torch.empty(nb, dtype=torch.uint8).pin_memory()
+            dv = torch.empty(nb, dtype=torch.uint8, device="cuda")
+            so = torch.empty(nb // 8 // 4 + 64, device="cuda")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def gbps(fn, reps=4):
+                best = 0.0
+                for _ in range(3):
+                    fn()
+                    torch.cuda.synchronize()
+                    e0.record(stream)
+                    for _ in range(reps):
+                        fn()
+                    e1.record(stream)
+                    torch.cuda.synchronize()
+                    best = max(best, reps * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+                return round(best, 1)
+            link = {"pinned_h2d_GBps": gbps(lambda: dv.copy_(hp, non_blocking=True)),
+                    "pinned_d2h_GBps": gbps(lambda: hp.copy_(dv, non_blocking=True)),
+                    "kernel_reads_pinned_host_GBps": gbps(lambda: L.check(L.lib.sdrhip_bench_stream_8to1(sptr, hp.data_ptr(), so.data_ptr(), nb, 1))),
+                    "what": "256 MiB each, best of three rounds of four, HIP events on the stream: hipMemcpyAsync from / to pinned memory, and a "
+                            "kernel streaming pinned host memory through 16-byte loads (sdrhip_bench_stream_8to1) -- the ceiling of the zero-copy pushes"}
+            del hp, dv, so
+        except Exception as e:                          # noqa: BLE001
+            link = {"error": repr(e)}
+        host["link"] = link
+        # bytes on the link per input sample: 2 B of u8 IQ up, 4 * 3/80 B of audio down
+        LINK_B = 2.0 + 4.0 * 3.0 / 80.0
+        dev_rate = None                                  # device-resident rate of the same chain: what `compute` is in the overlap figure
+
+        def annotate(sps, zero_copy):
+            d = {"Msamples_per_s": round(sps / 1e6, 1), "link_GBps": round(sps * LINK_B / 1e9, 2)}
+            if isinstance(link, dict) and "pinned_h2d_GBps" in link:
+                ceil_ = link["kernel_reads_pinned_host_GBps"] if zero_copy else link["pinned_h2d_GBps"]
+                d["link_ceiling_GBps"] = ceil_
+                d["frac"] = round(d["link_GBps"] / ceil_, 3) if ceil_ else None
+            return d
         for name, bpp, pushes, zc, co in (("fm_stream_1_block_per_push", 1, 20000, True, 0), ("fm_stream_1_block_per_push_memcpy", 1, 20000, False, 0),
                                           ("fm_stream_1_block_per_push_memcpy_every_push_its_own_launch", 1, 4000, False, 1),
                                           ("fm_stream_16_blocks_per_push", 16, 1000, True, 0),
-                                          ("fm_stream_4096_blocks_per_push_zero_copy", 4096, 12, True, 0)):
+                                          ("fm_stream_4096_blocks_per_push_zero_copy", 4096, 12, True, 0),
+                                          ("fm_stream_4096_blocks_per_push_memcpy", 4096, 12, False, 0)):
             try:
                 sps, _ = H.fm_stream_rate(L, chain, bpp * BLOCK, pushes, zc, co)
                 host[name] = round(sps / 1e6, 1)
+                host.setdefault("link_roofline", {})[name] = annotate(sps, zc and bpp * BLOCK <= 33 * BLOCK)
                 dbg(f"host {name} done")
             except Exception as e:                      # noqa: BLE001
                 host[name] = f"failed: {e!r}"
+        host["link_roofline_what"] = ("per host-streamed line: the bytes it moves over the link per second (2 B of u8 IQ up + 0.15 B of audio down per "
+                                      "input sample) against the ceiling measured above -- the in-place read rate for pushes the kernels read in place "
+                                      "(up to 33 source blocks), the pinned hipMemcpyAsync rate for the ones that go through the copy engines.  Small "
+                                      "pushes are bound by launch latency, not by the link: their frac says how far")
+        # the double-buffered path (4096-block pushes: upload of push i over compute of i-1 over download of i-2): what overlaps
+        try:
+            big = host["link_roofline"].get("fm_stream_4096_blocks_per_push_memcpy")
+            if big and isinstance(link, dict) and link.get("pinned_h2d_GBps"):
+                n_push = 4096 * BLOCK
+                wall = n_push / (big["Msamples_per_s"] * 1e6)
+                copy_t = n_push * 2.0 / (link["pinned_h2d_GBps"] * 1e9)
+                planb = sharding.ShardPlan(chain, 0, 1, n_push)
+                bufb = torch.randint(0, 256, (2 * (n_push + planb.halo_cap),), dtype=torch.uint8, device="cuda")
+                audb = torch.empty(planb.q1 - planb.q0, dtype=torch.float32, device="cuda")
+                wsbb = chain.workspace_bytes(n_push + planb.halo_cap)
+                wsb_ = torch.empty(wsbb, dtype=torch.uint8, device="cuda")
+                runb = lambda: chain.run(bufb.data_ptr(), planb.s0, planb.n_in, audb.data_ptr(), planb.q0, planb.q1, wsb_.data_ptr(), wsbb, stream=sptr)
+                for _ in range(5):
+                    runb()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    runb()
+                torch.cuda.synchronize()
+                comp_t = (time.perf_counter() - t0) / 20
+                del bufb, audb, wsb_
+                host["overlap_efficiency_4096_block_pushes"] = {
+                    "value": round(max(copy_t, comp_t) / wall, 3), "wall_ms_per_push": round(wall * 1e3, 3), "copy_ms": round(copy_t * 1e3, 3),
+                    "compute_ms": round(comp_t * 1e3, 3),
+                    "what": "max(copy, compute) / wall for the copying push of 4096 source blocks: copy = its 64 MiB at the measured pinned H2D rate, "
+                            "compute = the same samples device-resident, wall = per push as measured (the caller's copy into the pinned staging "
+                            "buffer -- split over SDRHIP_COPY_THREADS helper threads since round 5 -- is the third stage of that pipeline)"}
+        except Exception as e:                          # noqa: BLE001
+            host["overlap_efficiency_4096_block_pushes"] = f"failed: {e!r}"
         # latency, which is what a real-time 1.28 MS/s source cares about (examples/fm/fm.hs:24; the reference plays the audio through
         # pulse, Pulse.hs:28): one 8192-sample block per push, the time from the push call to the pop of the audio it completed
         try:
@@ -913,6 +991,16 @@ def main():
             host["config1_firDecimator_pipe_8192_cfloat_blocks_Melements_per_s"] = round(H.pipe_rate(L, pd.h, BLOCK, 2, BLOCK, 20000, True) / 1e6, 1)
         except Exception as e:                          # noqa: BLE001
             host["pipes"] = f"failed: {e!r}"
+
+    launch_sweep = None
+    if rank == 0 and world == 1 and extras and os.environ.get("BENCH_NO_SWEEP") != "1":
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import launch_sweep as LS
+            launch_sweep = LS.sweep(L, S, 0.08)
+        except Exception as e:                          # noqa: BLE001
+            launch_sweep = f"failed: {e!r}"
+        dbg("launch sweep done")
 
     if rank == 0:
         plan, S_len, passes, stage_ms = main_run["plan"], main_run["S_len"], main_run["passes"], main_run["stage_ms"]
@@ -1014,6 +1102,7 @@ def main():
                 "scaling_efficiency_what": "value / without_halo_exchange.value: 1.0 = the halo exchange costs nothing; the driver's own "
                                            "efficiency (value at N over N x value at 1) needs the N = 1 run"} if world > 1 else {}),
             "host_streamed": host,
+            "launch_size_sweep": launch_sweep,
             "power": power,
             "cpu_baseline": cpu,
         }

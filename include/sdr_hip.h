@@ -361,7 +361,7 @@ int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain *c, int mode);
  * aligned input whose first sample index is a multiple of 8).  Nothing goes through the workspace; every workgroup recomputes
  * the overlap of its tile (the first stage is computed ~1.9 times over), which pays exactly while a run is bound by launch
  * latency, not by arithmetic.  mode 0 = never, 1 = always, 2 = auto (default): runs of at most max_outputs audio outputs
- * (0 = the built-in bound, 159 * 512 = 2^21 input samples).  tile_outputs: audio outputs per workgroup (multiple of 3, at most
+ * (0 = the built-in bound, 159 * 1728 outputs = ~7.3 M input samples, where the stage kernels catch up: tools/launch_sweep.py).  tile_outputs: audio outputs per workgroup (multiple of 3, at most
  * 159; 0 = chosen from the size of the run: about one workgroup per CU).  Same bits as the stage kernels
  * (examples/fm/fm.hs:34-41; c_sources/decimate.c:105-113, resample.c:70-87, filter.c:60-68; Demod.hs:21-46). */
 int sdrhip_fm_chain_set_small_chain(sdrhip_fm_chain *c, int mode, int64_t max_outputs, int tile_outputs);

@@ -12,6 +12,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "descriptors.hpp"
@@ -20,9 +24,11 @@ using namespace sdrhip;
 
 static const int kFusedTailAutoOutputs = 768;   // fused tail in auto mode: runs of at most this many audio outputs
 static const int kStages = 6;  // decimate(+seam fix-up), fmDemod, resample, filter, fused tail (fmDemod+resample+filter+gain in one kernel), whole chain in one kernel
-// the whole chain as ONE kernel (kernels_small.hip) in auto mode: runs of at most this many audio outputs -- 2^21 input samples;
+// the whole chain as ONE kernel (kernels_small.hip) in auto mode: runs of at most this many audio outputs (~7.3 M input samples);
 // measured on MI355X (tools/shard_pass_probe.py): see DESIGN.md 5 "one-kernel chain"
-static const int64_t kSmallChainAutoOutputs = 159 * 512;
+static const int64_t kSmallChainAutoOutputs = 159 * 1728;   // round 5 (tools/launch_sweep.py): the crossover with the stage kernels sits at ~900
+                                                            // source blocks (43 us either way); the old bound of 256 blocks left runs of 384 .. 768
+                                                            // blocks on the stage kernels, 1.2 .. 1.6 times slower than this kernel
 
 struct sdrhip_fm_chain {
     FirDesc decim;     // complex, factor D1
@@ -759,8 +765,83 @@ int sdrhip_fm_chain_read_timing(sdrhip_fm_chain* c, double* ms_sum, int* runs)
 // Results lag at most nslots - 1 submissions (sdrhip_fm_stream_flush drains); with adaptive submission (the default for
 // operators that run in place) a push that finds the next slot still busy is staged behind the earlier ones and leaves with them.
 // ---------------------------------------------------------------------------
+// Round 5: the caller-side copy of a LARGE push into the pinned staging buffer, split over a few threads.  A push of 4096 source
+// blocks is a 64 MiB memcpy: one thread moves ~23 GB/s while the link behind it takes ~45 (profiles/r04_host_stream.txt: 11.4
+// against 22.5 Gsample/s with the source writing the staging buffer itself) -- the copying push lost half the link to a
+// single-threaded memcpy.  Helpers are started by the first large push and live as long as the operator; the caller copies its
+// own share, so small pushes never touch them (SDRHIP_COPY_THREADS: helpers, default 3; 0 = plain memcpy).
+namespace {
+struct CopyPool {
+    static constexpr size_t kMinBytes = 4u << 20;          // below this a push is one memcpy
+    static constexpr size_t kPiece = 1u << 20;
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    uint8_t* dst = nullptr;
+    const uint8_t* src = nullptr;
+    size_t bytes = 0;
+    std::atomic<size_t> next{0};
+    int generation = 0, active = 0;
+    bool stop = false;
+    int helpers = getenv("SDRHIP_COPY_THREADS") ? atoi(getenv("SDRHIP_COPY_THREADS")) : 3;
+
+    void drain()
+    {
+        for (;;) {
+            const size_t o = next.fetch_add(kPiece, std::memory_order_relaxed);
+            if (o >= bytes) return;
+            memcpy(dst + o, src + o, bytes - o < kPiece ? bytes - o : kPiece);
+        }
+    }
+    void worker()
+    {
+        int seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv_job.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            lk.unlock();
+            drain();
+            lk.lock();
+            if (--active == 0) cv_done.notify_one();
+        }
+    }
+    void copy(uint8_t* d, const uint8_t* s, size_t n)
+    {
+        if (n < kMinBytes || helpers <= 0) {
+            memcpy(d, s, n);
+            return;
+        }
+        if (workers.empty())
+            for (int i = 0; i < helpers; i++) workers.emplace_back([this] { worker(); });
+        {
+            std::lock_guard<std::mutex> lk(m);
+            dst = d; src = s; bytes = n;
+            next.store(0, std::memory_order_relaxed);
+            active = (int)workers.size();
+            generation++;
+        }
+        cv_job.notify_all();
+        drain();                                            // the caller's own share
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return active == 0; });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_job.notify_all();
+        for (auto& t : workers) t.join();
+    }
+};
+}  // namespace
+
 struct sdrhip_fm_stream {
     sdrhip_fm_chain* c = nullptr;
+    CopyPool copier;
     int max_block = 0;
     int block_out = 0;
     // Slots: submissions in flight.  Two for operators that take large pushes (upload of block i over compute of i-1 over
@@ -1043,7 +1124,7 @@ int sdrhip_fm_stream_push(sdrhip_fm_stream* st, const uint8_t* iq, int n)
     if (st->staged + n > st->capacity() && (rc = stream_submit(st)) != SDRHIP_OK) return rc;
     if ((rc = stream_open_slot(st)) != SDRHIP_OK) return rc;
     uint8_t* dst = st->staged_base(st->slot[st->cur()]) + (size_t)st->staged * 2;
-    if (iq != dst) memcpy(dst, iq, (size_t)n * 2);   // else: the caller filled our staging buffer in place
+    if (iq != dst) st->copier.copy(dst, iq, (size_t)n * 2);   // else: the caller filled our staging buffer in place
     st->staged += n;
     bool submit = st->staged >= st->coalesce;
     if (st->adaptive > 0 && st->coalesce == 0 && submit) {     // an explicit set_coalesce takes precedence: fixed batches
