@@ -107,13 +107,82 @@ def build_examples():
         src, exe = os.path.join(EXAMPLES, f), os.path.join(bindir, f[:-2])
         if not _stale(exe, [src, LIB, os.path.join(INCLUDE, "sdr_hip.h")]):
             continue
-        cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-O2", f"-I{INCLUDE}", src, "-o", exe, f"-L{LIBDIR}", "-lsdr_hip",
+        cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-O2", f"-I{INCLUDE}", src, "-o", exe, f"-L{LIBDIR}", "-lsdr_hip", "-lm",
                "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,$ORIGIN/../../sdr_amd/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"gcc failed on {src}:\n{r.stdout}\n{r.stderr}")
 
 
+# ---- sanitizer variant (round 5) -------------------------------------------------------------------------------------------
+# `SDRHIP_ASAN=1 python -m sdr_amd.build` (or --asan): the same sources with AddressSanitizer + UndefinedBehaviorSanitizer on the HOST
+# code only (-Xarch_host: the device code is compiled as always) -> sdr_amd/lib/libsdr_hip_asan.so, and the plain-C programs of
+# examples/ linked against it with clang's shared sanitizer runtime -> examples/bin/<name>_asan.  tests/test_gpu_sanitizers.py runs
+# them on the GPU box; a clean log is kept under profiles/.  Not part of the product: nothing loads the _asan library by default.
+OBJ_ASAN = os.path.join(HERE, "_obj_asan")
+LIB_ASAN = os.path.join(LIBDIR, "libsdr_hip_asan.so")
+ASAN_FLAGS = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer", "-Xarch_host", "-fno-sanitize-recover=undefined", "-g"]
+
+
+def _clang_rt_dir():
+    import glob
+    hits = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    return os.path.dirname(hits[0]) if hits else None
+
+
+def build_asan(force=False):
+    os.makedirs(OBJ_ASAN, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdrs = headers()
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(OBJ_ASAN, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src, os.path.abspath(__file__)] + hdrs):
+            jobs.append((src, obj))
+    if jobs:
+        # -O1 instead of -O3 for the host side would change the device code too (one flag set per translation unit): keep -O3, the
+        # sanitizers instrument what is left
+        with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(lambda j: _compile(j[0], j[1], ASAN_FLAGS), jobs))
+    if jobs or force or _stale(LIB_ASAN, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan", "-o", LIB_ASAN] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    rt = _clang_rt_dir()
+    bindir = os.path.join(EXAMPLES, "bin")
+    os.makedirs(bindir, exist_ok=True)
+    clang = os.path.join(os.path.dirname(os.path.dirname(rt)), "..", "..", "..", "bin", "clang") if rt else "clang"
+    clang = os.path.normpath(clang) if os.path.exists(os.path.normpath(clang)) else "/opt/rocm/lib/llvm/bin/clang"
+    for f in sorted(os.listdir(EXAMPLES)):
+        if not f.endswith(".c"):
+            continue
+        src, exe = os.path.join(EXAMPLES, f), os.path.join(bindir, f[:-2] + "_asan")
+        if not (force or _stale(exe, [src, LIB_ASAN, os.path.join(INCLUDE, "sdr_hip.h")])):
+            continue
+        cmd = [clang, "-std=c99", "-Wall", "-Wextra", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared-libsan", "-DSDRHIP_FAST_EXIT",
+               f"-I{INCLUDE}", src, "-o", exe, f"-L{LIBDIR}", "-lsdr_hip_asan", "-lm", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,$ORIGIN/../../sdr_amd/lib"]
+        if rt:
+            cmd.append("-Wl,-rpath," + rt)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"clang failed on {src}:\n{r.stdout}\n{r.stderr}")
+    return LIB_ASAN
+
+
+def sha256_of(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True)
-    print(path)
+    if "--asan" in sys.argv or os.environ.get("SDRHIP_ASAN") == "1":
+        print(build_asan(force="--force" in sys.argv))
+    else:
+        path = build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True)
+        print(path, "sha256", sha256_of(path))

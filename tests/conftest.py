@@ -46,6 +46,16 @@ def hip():
     return L
 
 
+@pytest.fixture(autouse=True)
+def _output_guard_bands(request):
+    """After every GPU test: the NaN canaries around each output buffer the test got from gpu_util.dev_empty_f32 are intact."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import gpu_util
+        if gpu_util._live:
+            gpu_util.check_guards()
+
+
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 

@@ -174,7 +174,7 @@ def test_chain_pipelining_is_invisible(hip):
     st = torch.cuda.Stream()
     for nsub in (1, 8, 3, 16):
         chain.set_pipelining(nsub)
-        out = torch.zeros(q1, dtype=torch.float32, device="cuda")
+        out = dev_empty_f32(q1)
         with torch.cuda.stream(st):
             for _ in range(3):     # back-to-back runs reuse the workspace: exercises the cross-run ordering
                 chain.run(ptr(u8), 0, n, ptr(out), 0, q1, ptr(ws), ws.numel(), stream=st.cuda_stream)
@@ -219,7 +219,7 @@ def test_chain_demod_fusion_is_invisible(hip, start_blocks, kind):
         for fused in (False, True, False):
             chain.set_demod_fusion(fused)
             ws.fill_(0xA5)                                         # stale workspace contents must not matter
-            out = torch.zeros(q1 - q0, dtype=torch.float32, device="cuda")
+            out = dev_empty_f32(q1 - q0)
             chain.enable_timing(True)
             chain.run(ptr(u8), s0, n, ptr(out), q0, q1, ptr(ws), ws.numel())
             torch.cuda.synchronize()
@@ -234,7 +234,7 @@ def test_chain_demod_fusion_is_invisible(hip, start_blocks, kind):
         chain.set_decim_demod_fusion(True)
         hip.lib.sdrhip_debug_set_systolic(1)                       # that fusion lives in the systolic kernel (soak runs may switch it off)
         ws.fill_(0x5A)
-        out = torch.zeros(q1 - q0, dtype=torch.float32, device="cuda")
+        out = dev_empty_f32(q1 - q0)
         chain.enable_timing(True)
         chain.run(ptr(u8), s0, n, ptr(out), q0, q1, ptr(ws), ws.numel())
         torch.cuda.synchronize()
