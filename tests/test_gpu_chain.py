@@ -142,6 +142,31 @@ def test_fm_stream_matches_pipes(hip, oracle, blocks_per_push):
         st.push(u8[: 2 * (B - 8)])          # not a whole source block: the seams would be somewhere else
 
 
+def test_fm_stream_large_copying_pushes_equal_small_ones(hip):
+    """Round 5: a push of 8 MiB or more from caller memory is copied into the pinned staging buffer by the caller and three helper
+    threads (chain.cpp: CopyPool); the audio must be what 16-block pushes give -- including a push whose length is not a multiple of
+    the helpers' 1 MiB pieces, from an unaligned address, and a last short one."""
+    nblk = 1536 + 700 + 37
+    raw = np.empty(2 * nblk * B + 3, np.uint8)
+    u8 = raw[3:]                                   # unaligned caller memory
+    u8[:] = S.iq_u8(nblk * B)
+    chain = _chain(hip)
+    ref_st = hip.FmStream(chain, 16 * B, B)
+    ref = []
+    for i in range(0, nblk, 16):
+        ref += ref_st.push(u8[2 * i * B: 2 * min(nblk, i + 16) * B])
+    ref += ref_st.flush()
+    st = hip.FmStream(chain, 1536 * B, B)
+    got = []
+    at = 0
+    for n in (1536, 700, 37):                      # 24 MiB, 10.9 MiB (pieces do not divide it), 0.6 MiB (plain memcpy)
+        got += st.push(u8[2 * at * B: 2 * (at + n) * B])
+        at += n
+    got += st.flush()
+    assert len(got) == len(ref) and len(got) > 60
+    assert_bit_equal(np.concatenate(got), np.concatenate(ref), "large copying pushes vs 16-block pushes")
+
+
 def test_fm_stream_long_run_equals_chain(hip, oracle):
     """Many pushes: the streamed audio equals one device-resident chain run over the same samples."""
     nblk = 512
