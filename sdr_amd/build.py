@@ -37,6 +37,8 @@ if os.environ.get("SDRHIP_NO_SLP_FAST"):
     FILE_FLAGS["kernels_fast.hip"] = ["-fno-slp-vectorize"]
 if os.environ.get("SDRHIP_CHAIN_DEFS"):   # tuning experiments on the tail kernels
     FILE_FLAGS["kernels_chain.hip"] = FILE_FLAGS["kernels_chain.hip"] + os.environ["SDRHIP_CHAIN_DEFS"].split()
+if os.environ.get("SDRHIP_SYSTOLIC_DEFS"):  # measurements on the systolic decimator, e.g. "-DSDRHIP_SYSTOLIC_ROTCOST=1"
+    FILE_FLAGS["kernels_systolic.hip"] = FILE_FLAGS["kernels_systolic.hip"] + os.environ["SDRHIP_SYSTOLIC_DEFS"].split()
 if os.environ.get("SDRHIP_RSTREAM_DEFS"):  # tuning experiments on the streaming fmDemod + resampler, e.g. "-DSDRHIP_RSTREAM_MINW=5"
     FILE_FLAGS["kernels_resample_stream.hip"] = FILE_FLAGS["kernels_resample_stream.hip"] + os.environ["SDRHIP_RSTREAM_DEFS"].split()
 if os.environ.get("SDRHIP_FAST_DEFS"):    # tuning experiments on the tiled decimator, e.g. "-DSDRHIP_INL_STEP=8"

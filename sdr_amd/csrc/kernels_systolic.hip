@@ -37,6 +37,10 @@
 #include "demod.hpp"
 #include "kernels.hpp"
 
+#ifndef SDRHIP_SYSTOLIC_ROTCOST
+#define SDRHIP_SYSTOLIC_ROTCOST 0
+#endif
+
 namespace sdrhip {
 namespace {
 
@@ -183,6 +187,17 @@ __device__ __forceinline__ void systolic_strip(const void* __restrict__ in, int6
                 if (b == 0 && r < 4) {
                     acc[i][k] = f2{0.f, 0.f} + p;                  // the first addition of the partial: +0 + product
                 } else if (t > 0 && c == 0 && r < 4) {
+#if SDRHIP_SYSTOLIC_ROTCOST
+                    // MEASUREMENT ONLY (LABNOTES round 5, VERDICT r04 "next" 4): what a rotating walk would have to add -- the partial sums
+                    // that leave lane 63 entering lane 0 of the next strip -- costs at least one lane-0 patch per value and stage boundary:
+                    // a v_mov_b32_dpp wave_ror:1 of the value (here of the accumulator itself; the result is thrown away, the
+                    // instruction is not)
+                    {
+                        float rx, ry;
+                        asm volatile("v_mov_b32_dpp %0, %2 wave_ror:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %3 wave_ror:1 row_mask:0xf bank_mask:0xf"
+                                     : "=&v"(rx), "=&v"(ry) : "v"(acc[i][k].x), "v"(acc[i][k].y));
+                    }
+#endif
                     acc[i][k] = f2{dpp_shr1(acc[i][k].x) + p.x, dpp_shr1(acc[i][k].y) + p.y};   // the group enters the stage one lane up
                 } else {
                     acc[i][k] = acc[i][k] + p;
