@@ -387,7 +387,8 @@ void sdrhip_debug_set_demod_form(int form);
 int sdrhip_debug_demod_form(void);   /* the form the next stand-alone launch runs (what the setter accepted) */
 /* fmDemod + the 3/10 resampler as a streaming kernel (kernels_resample_stream.hip, round 5): a workgroup walks a run of tiles with the
  * next tile's samples in flight behind the current tile's arithmetic.  0 (default: measured slower, 0.236 against 0.198 ms per 2^26 inputs;
- * SDRHIP_RESAMP_STREAM sets the initial value) = off (the tile kernel with fmDemod in its loader), 1 = runs of at least four tiles per workgroup, 2 = every run it can take, n > 2 = every run, cut for n workgroups (tests).  Same bits.
+ * SDRHIP_RESAMP_STREAM sets the initial value) = off (the tile kernel with fmDemod in its loader), 1 = runs of at least four tiles per workgroup, 2 = every run it can take, n > 2 = every run, cut for n workgroups (tests);
+ * 1000 + m = the same in mode m with the prefetch in LDS (global_load_lds_dwordx4 into per-wave slots) instead of registers.  Same bits.
  * ..._launches: launches it has served; ..._plan: the cut of `ncycles` polyphase cycles over a device of `cus` compute units. */
 void sdrhip_debug_set_resample_demod_stream(int on);
 long long sdrhip_debug_resample_demod_stream_launches(void);

@@ -17,8 +17,14 @@
 // Arithmetic: fm_phase_common_tbl + wave vote + fm_phase_sel (demod.hpp) and the packed-pair walk of k_resample3_fast --
 // the same operations in the same order, so the same bits (tests/test_gpu_chain.py::test_chain_demod_fusion_is_invisible,
 // tests/test_gpu_stream.py, tests/test_gpu_resample_stream.py).
+//
+// MEASURED (round 5, LABNOTES.md): both variants in this file -- prefetch in registers (three waves per SIMD) and in LDS by
+// global_load_lds (four) -- take 0.233-0.236 ms per 2^26 inputs where the tile kernel takes 0.189-0.198.  The loads are hidden (the
+// ablation shows it); what loses is the lock step of demodulator and resampler phases inside a persistent workgroup.  Kept, switched
+// off (sdrhip_debug_set_resample_demod_stream), under test.
 #include <atomic>
 #include <stdlib.h>
+#include <type_traits>
 #include "kernels.hpp"
 #include "demod.hpp"
 
@@ -426,6 +432,198 @@ __global__ void __launch_bounds__(kNT, SDRHIP_RSTREAM_MINW) k_resample3_demod_st
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same streaming kernel with the prefetch in LDS instead of registers (VERDICT r04 "next" 1 named it: global_load_lds_dwordx4).
+// Every wave owns kRounds slots of 1 KiB (one round of 64 pairs each) and one 16-byte slot for the pair in front of its first one
+// (the predecessor of its first sample).  A slot is refilled with the NEXT tile's round as soon as the current tile's round has
+// been read out of it, so the loads are in flight for a whole tile and cost no VGPR: 128 registers suffice, four workgroups per CU
+// (an even four waves per SIMD: tools/k4lab/issue_bench.hip).  The phases y have ONE segment here (LDS: 20.5 KB of slots + 10.5 KB
+// + the table = 33 KB per workgroup), hence two barriers per tile: D | R | next D.
+// The compiler knows nothing about LDS-DMA: the waits are counted by hand.  vmcnt returns in order, so "at most N outstanding" means
+// everything but the newest N is done; N = the MINIMUM number of operations issued after the one waited for (conditional stores count
+// as absent: if they were issued the wait is merely longer).  In a tile's round i the wave needs DMA(T, i), issued in round i of tile
+// T - 1; after it came DMA(T, i+1 .. 4), the output store of T - 1, DMA(T+1, pred), DMA(T+1, 0 .. i-1): 6 operations (round 0: the
+// predecessor slot too, issued just before DMA(T, 0): 5).  The run's first streaming tile has no output store before it: 5 / 4.
+// The refills are issued unconditionally (on the run's last tile: to a harmless address) so that those counts hold.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int E>
+__global__ void __launch_bounds__(kNT, 4) k_resample3_demod_stream_dma(const float* __restrict__ in, const float* __restrict__ groups,
+                                                                       float* __restrict__ out, float* __restrict__ y_out, StreamArgs a)
+{
+    constexpr int kSlot = 64 * kRounds + 1;                                    // uint4 per wave: kRounds rounds + the predecessor pair
+    __shared__ __attribute__((aligned(16))) float seg[kSeg];
+    __shared__ __attribute__((aligned(16))) uint4 raw[kNT / 64][kSlot];
+    __shared__ __attribute__((aligned(16))) float atbl[kAtanRows * kAtanRowFloats];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const int wave_t0 = wave * 64;
+    atan_table_fill(atbl, tid);
+
+    const int t_begin = blockIdx.x * a.tiles_per_wg;
+    const int t_end = t_begin + a.tiles_per_wg < a.ntiles ? t_begin + a.tiles_per_wg : a.ntiles;
+    const float2* __restrict__ z = reinterpret_cast<const float2*>(in);
+    auto fast = [&](int T) { return T < t_end && (T + 1) * kNT <= a.ncycles && a.origin + (int64_t)T * kTileIn + kSeg <= a.y_count; };
+    int m_new = 0;
+    if (a.yseam > 0) m_new = (int)((a.y_abs0 + a.origin + (int64_t)t_begin * kTileIn + kCarry) % a.yseam);
+    auto advance = [&]() {
+        if (a.yseam > 0) {
+            m_new += kTileIn;
+            if (m_new >= a.yseam) m_new -= a.yseam;
+        }
+    };
+    float2* seg2 = reinterpret_cast<float2*>(seg);
+    int T = t_begin;
+    lds_barrier();                                                             // the table
+    bool carried = false;
+    {
+        const int64_t tile0 = a.origin + (int64_t)T * kTileIn;
+        if (T < t_end && !(tile0 >= 1 || (tile0 == 0 && a.has_prev))) {
+            guarded_tile(a, in, y_out, tile0, seg, tid);
+            lds_barrier();
+            resample_tile<E, false>(a, groups, out, T, seg, tid);
+            const float2 c = tid < kCarry / 2 ? seg2[kTileIn / 2 + tid] : make_float2(0.0f, 0.0f);
+            lds_barrier();                                                     // everybody has read the segment
+            if (tid < kCarry / 2) seg2[tid] = c;
+            advance();
+            T++, carried = true;
+        }
+    }
+    const int lp0 = kRounds * wave_t0 + lane;                                  // this thread's pair in round 0, relative to the tile's first new pair
+    const unsigned off8 = (unsigned)lp0 * 8u;
+    // refill slot i (-1: the predecessor pair, lane 0 only) with tile Tn's data; `live` false: a harmless valid address
+    auto refill = [&](int Tn, bool live, int i) {
+        const int64_t n0 = a.origin + (int64_t)Tn * kTileIn + kCarry;         // even offset from `origin`: 16-byte aligned
+        const uint4* src = reinterpret_cast<const uint4*>(in + 2 * n0);
+        if (i >= 0) {
+            const uint4* g = src + (live ? lp0 + 64 * i : 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)&raw[wave][64 * i], 16, 0, 0);
+        } else {
+            // the pair that ends right before the wave's first one: samples n0 + 2 * kRounds * wave_t0 - 2, - 1 (for tile 0 of a
+            // stream that starts at sample 0 this run is never `live`: the guarded tile took it)
+            const uint4* g = src + (live ? kRounds * wave_t0 - 1 : 0);
+            if (lane == 0) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)&raw[wave][64 * kRounds], 16, 0, 0);
+        }
+    };
+    // one streaming tile; FIRST: the run's first (no output store of a previous tile in the queue)
+    auto tile = [&](auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const int64_t tile0 = a.origin + (int64_t)T * kTileIn;
+        const bool more = fast(T + 1);
+        const int Tn = more ? T + 1 : T;
+        if (!carried && tid < kCarry / 2) {
+            const int64_t n = tile0 + 2 * tid;
+            const float2 pv = z[n - 1], A = z[n], B = z[n + 1];
+            const float2 y = make_float2(fm_phase_sel(A, pv), fm_phase_sel(B, A));
+            seg2[tid] = y;
+            if (a.yseam > 0) {
+                const int m0 = (int)((a.y_abs0 + n) % a.yseam), m1 = m0 + 1 == a.yseam ? 0 : m0 + 1;
+                if (keep_pos(m0, a.yseam, a.ykeep)) y_out[n] = y.x;
+                if (keep_pos(m1, a.yseam, a.ykeep)) y_out[n + 1] = y.y;
+            }
+        }
+        carried = true;
+        float2 y[kRounds];
+        float4 cur[kRounds];
+        float2 pl = make_float2(0.0f, 0.0f);
+        bool rare = false;
+#pragma unroll
+        for (int i = 0; i < kRounds; i++) {
+            if (i == 0) wait_vm<FIRST ? 4 : 5>(); else wait_vm<FIRST ? 5 : 6>();
+            const uint4 r = raw[wave][64 * i + lane];
+            uint4 pr = make_uint4(0u, 0u, 0u, 0u);
+            if (i == 0) pr = raw[wave][64 * kRounds];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // in registers before the slot is refilled
+            if (i == 0) {
+                refill(Tn, more, -1);
+                pl = make_float2(__uint_as_float(pr.z), __uint_as_float(pr.w));
+            }
+            refill(Tn, more, i);
+            cur[i] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+            const float2 A = make_float2(cur[i].x, cur[i].y), B = make_float2(cur[i].z, cur[i].w);
+            float2 o = pl;
+            if (i > 0) o = make_float2(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur[i - 1].z), 63)),
+                                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur[i - 1].w), 63)));
+            const float2 pv = make_float2(dpp_shr1_or(o.x, cur[i].z), dpp_shr1_or(o.y, cur[i].w));
+            bool q0, q1;
+            y[i].x = fm_phase_common_tbl(A, pv, q0, atbl);
+            __builtin_amdgcn_sched_barrier(0);
+            y[i].y = fm_phase_common_tbl(B, A, q1, atbl);
+            rare |= q0 | q1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < kRounds; i++) seg2[kCarry / 2 + lp0 + 64 * i] = y[i];
+        if (__any(rare)) {
+#pragma unroll
+            for (int i = 0; i < kRounds; i++) {
+                const float2 A = make_float2(cur[i].x, cur[i].y), B = make_float2(cur[i].z, cur[i].w);
+                float2 o = pl;
+                if (i > 0) o = make_float2(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur[i - 1].z), 63)),
+                                           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur[i - 1].w), 63)));
+                const float2 pv = make_float2(dpp_shr1_or(o.x, cur[i].z), dpp_shr1_or(o.y, cur[i].w));
+                y[i] = make_float2(fm_phase_sel(A, pv), fm_phase_sel(B, A));
+                seg2[kCarry / 2 + lp0 + 64 * i] = y[i];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (a.yseam > 0 && (m_new < a.ykeep || m_new + kTileIn > a.yseam - a.ykeep)) {
+            char* yb = reinterpret_cast<char*>(y_out + tile0 + kCarry);
+#pragma unroll
+            for (int i = 0; i < kRounds; i++) {
+                int m0 = m_new + 2 * (lp0 + 64 * i);
+                if (m0 >= a.yseam) m0 -= a.yseam;
+                const int m1 = m0 + 1 == a.yseam ? 0 : m0 + 1;
+                float* yo = reinterpret_cast<float*>(yb + (off8 + 512u * i));
+                if (keep_pos(m0, a.yseam, a.ykeep)) yo[0] = y[i].x;
+                if (keep_pos(m1, a.yseam, a.ykeep)) yo[1] = y[i].y;
+            }
+        }
+        const float2 ylast = y[kRounds - 1];
+        lds_barrier();                                                         // D | R
+        resample_tile<E, true>(a, groups, out, T, seg, tid);
+        lds_barrier();                                                         // R | the next tile's D (and the carry below)
+        if (tid >= kNT - kCarry / 2) seg2[tid - (kNT - kCarry / 2)] = ylast;  // the segment's last 64 positions are the next tile's first 64
+        advance();
+        T++;
+    };
+    if (fast(T)) {
+        // prologue: the first tile's slots (the predecessor pair first: the counts above assume that order)
+        refill(T, true, -1);
+#pragma unroll
+        for (int i = 0; i < kRounds; i++) refill(T, true, i);
+        tile(std::true_type{});
+        while (fast(T)) tile(std::false_type{});
+        wait_vm<0>();                                                          // the last tile's harmless refills
+    }
+    for (; T < t_end; T++) {
+        guarded_tile(a, in, y_out, a.origin + (int64_t)T * kTileIn, seg, tid);
+        lds_barrier();
+        resample_tile<E, false>(a, groups, out, T, seg, tid);
+        lds_barrier();
+    }
+    if (a.nedge > 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) {
+        for (int sg = 0; sg < 2; sg++) {
+            if (blockIdx.x != (sg == 0 ? 0u : gridDim.x - 1)) continue;
+            const int64_t p0 = sg == 0 ? 0 : a.y_count - a.nedge;
+            for (int i = tid; i < a.nedge; i += kNT) {
+                const int64_t p = p0 + i;
+                const float2 v[2] = {(p > 0 || a.has_prev) ? z[p - 1] : make_float2(0.0f, 0.0f), z[p]};
+                float y[1];
+                fm_phase_voted<1>(v, y);
+                y_out[p] = y[0];
+            }
+        }
+    }
+}
+
 // OFF by default: measured 0.236 ms per 2^26 inputs against 0.198 for the tile kernel with fmDemod in its loader (header comment)
 std::atomic<int> g_stream_on{getenv("SDRHIP_RESAMP_STREAM") ? atoi(getenv("SDRHIP_RESAMP_STREAM")) : 0};
 std::atomic<long long> g_stream_launches{0};
@@ -462,11 +660,18 @@ bool launch_resample3_demod_stream(hipStream_t s, const float* d_iq, int64_t pos
                                    const float* d_groups, int row_stride, float* d_out, float* d_y, int64_t y_abs0, int yseam, int ykeep,
                                    int nedge)
 {
-    const int mode = g_stream_on.load(std::memory_order_relaxed);
+    int mode = g_stream_on.load(std::memory_order_relaxed);
+    const bool dma = mode >= 1000;                               // 1000 + m: the LDS-DMA variant in mode m
+    if (dma) mode -= 1000;
     if (mode == 0 || ncycles < 1 || pos < 0) return false;
     if (yseam > 0 && yseam < kSeg + 2 * ykeep) return false;     // a tile's new samples wrap the seam grid at most once
     int ntiles, per, grid;
     resample_demod_stream_plan(ncycles, device_cus(), &ntiles, &per, &grid);
+    if (dma) {                                                   // four workgroups per CU
+        const int slots = device_cus() * 4;
+        per = ntiles > 0 ? (ntiles + slots - 1) / slots : 1;
+        grid = ntiles > 0 ? (ntiles + per - 1) / per : 0;
+    }
     // a run of fewer than a handful of tiles per workgroup has nothing to stream behind: the tile kernel serves it
     if (mode == 1 && per < 4) return false;
     if (mode > 2) {                                              // tests: every run, cut for `mode` workgroups (long runs of tiles at small sizes)
@@ -480,7 +685,10 @@ bool launch_resample3_demod_stream(hipStream_t s, const float* d_iq, int64_t pos
     a.y_count = y_count;
     a.row_stride = row_stride;
     a.y_abs0 = y_abs0; a.yseam = yseam; a.ykeep = ykeep; a.nedge = nedge;
-    if (e) hipLaunchKernelGGL(k_resample3_demod_stream<1>, dim3(grid), dim3(kNT), 0, s, d_iq, d_groups, d_out, d_y, a);
+    if (dma) {
+        if (e) hipLaunchKernelGGL(k_resample3_demod_stream_dma<1>, dim3(grid), dim3(kNT), 0, s, d_iq, d_groups, d_out, d_y, a);
+        else hipLaunchKernelGGL(k_resample3_demod_stream_dma<0>, dim3(grid), dim3(kNT), 0, s, d_iq, d_groups, d_out, d_y, a);
+    } else if (e) hipLaunchKernelGGL(k_resample3_demod_stream<1>, dim3(grid), dim3(kNT), 0, s, d_iq, d_groups, d_out, d_y, a);
     else hipLaunchKernelGGL(k_resample3_demod_stream<0>, dim3(grid), dim3(kNT), 0, s, d_iq, d_groups, d_out, d_y, a);
     g_stream_launches.fetch_add(1, std::memory_order_relaxed);
     return true;

@@ -46,9 +46,15 @@ def restore(hip):
     hip.lib.sdrhip_debug_set_resample_demod_stream(int(os.environ.get("SDRHIP_RESAMP_STREAM", "0")))
 
 
+# prefetch in registers (mode = workgroups) and in LDS by global_load_lds (mode = 1000 + workgroups)
+DMA = [0, 1000]
+
+
+@pytest.mark.parametrize("dma", DMA)
 @pytest.mark.parametrize("block", [B, 0])
 @pytest.mark.parametrize("s0_blocks, log2n, slots", [(0, 21, 2), (0, 22, 7), (0, 23, 64), (37, 23, 5), (3, 24, 3), (1, 25, 1024)])
-def test_stream_equals_tile_kernel(hip, restore, block, s0_blocks, log2n, slots):
+def test_stream_equals_tile_kernel(hip, restore, block, s0_blocks, log2n, slots, dma):
+    slots += dma
     n = (1 << log2n) + 8 * 1237          # not a multiple of anything convenient
     u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda")
     chain = _chain(hip, block)
@@ -65,8 +71,9 @@ def test_stream_equals_tile_kernel(hip, restore, block, s0_blocks, log2n, slots)
     assert bad.numel() == 0, f"{bad.numel()} audio samples differ, first at {int(bad[0])} of {ref.numel()}"
 
 
+@pytest.mark.parametrize("dma", DMA)
 @pytest.mark.parametrize("offset", [0, 1, 2, 3, 5, 8])
-def test_stream_both_phases_of_the_complex_stream(hip, restore, offset):
+def test_stream_both_phases_of_the_complex_stream(hip, restore, offset, dma):
     """The run's first input sits at an even or an odd complex sample of the decimator's buffer depending on where the pass starts:
     both instantiations (E = 0, 1) must occur; starts that are not block multiples move the seams through the tiles."""
     n = (1 << 22) + 80 * 977
@@ -74,7 +81,7 @@ def test_stream_both_phases_of_the_complex_stream(hip, restore, offset):
     chain = _chain(hip, B)
     s0 = 11 * B + 8 * offset
     ref, _ = _run(hip, chain, u8, s0, n, 0)
-    for slots in (3, 200):
+    for slots in (3 + dma, 200 + dma):
         got, took = _run(hip, chain, u8, s0, n, slots)
         assert took >= 1
         assert torch.equal(ref.view(torch.int32), got.view(torch.int32)), f"offset {offset}, {slots} workgroups"
@@ -96,7 +103,7 @@ def test_stream_patchy_signal_takes_the_full_form(hip, restore):
     for block in (B, 0):
         chain = _chain(hip, block)
         ref, _ = _run(hip, chain, u8, 0, n, 0, fused=False)
-        for slots in (2, 33):
+        for slots in (2, 33, 1002, 1033):
             got, took = _run(hip, chain, u8, 0, n, slots)
             assert took >= 1
             assert torch.equal(ref.view(torch.int32), got.view(torch.int32))
@@ -111,9 +118,10 @@ def test_stream_against_the_oracle(hip, restore, oracle):
     exp = np.concatenate(PM.fm_receiver(oracle, blocks, S.taps_decim127(), 8, S.taps_resamp191(), 3, 10, S.taps_audio_half64(), 0.2, B))
     chain = _chain(hip, B)
     d = torch.from_numpy(u8).cuda()
-    got, took = _run(hip, chain, d, 0, nblk * B, 6)
-    assert took >= 1
-    assert_bit_equal(got.cpu().numpy()[: exp.size], exp, "streaming fmDemod + resampler vs the oracle")
+    for mode in (6, 1006):
+        got, took = _run(hip, chain, d, 0, nblk * B, mode)
+        assert took >= 1
+        assert_bit_equal(got.cpu().numpy()[: exp.size], exp, f"streaming fmDemod + resampler (mode {mode}) vs the oracle")
 
 
 def test_stream_plan_covers_every_cycle(hip):
