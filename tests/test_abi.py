@@ -244,3 +244,20 @@ def test_resampler_systolic_strip_plan(L):
             assert 248 * nw <= ncyc and 2480 * (nw - 1) + 2560 <= avail
         if nw < ns:
             assert 248 * (nw + 1) > ncyc or 2480 * nw + 2560 > avail
+
+
+def test_stream_kernel_plan_covers_every_cycle():
+    """Host arithmetic of the streaming fmDemod + resampler's cut (kernels_resample_stream.hip; no device call): every tile belongs to
+    exactly one workgroup, for any run length and CU count; and the staging size of the batched halo exchange (round 5)."""
+    import ctypes as C
+    import sdr_amd.lib as L
+    for ncycles in (1, 255, 256, 257, 1000, 419431, 6710886, 20132659):
+        for cus in (1, 8, 256, 304):
+            nt, per, grid = C.c_int(), C.c_int(), C.c_int()
+            L.lib.sdrhip_debug_resample_demod_stream_plan(ncycles, cus, C.byref(nt), C.byref(per), C.byref(grid))
+            assert nt.value == (ncycles + 255) // 256
+            assert per.value * grid.value >= nt.value > per.value * (grid.value - 1)
+    import signals as S
+    ch = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, 8192)
+    h = ch.halo_samples()
+    assert ch.halo_staging_bytes(1) == 4 * h and ch.halo_staging_bytes(16) == 64 * h and ch.halo_staging_bytes(0) == 0
