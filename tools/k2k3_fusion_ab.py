@@ -17,7 +17,8 @@ run(50); torch.cuda.synchronize()
 knob = sys.argv[1] if len(sys.argv) > 1 else "decim_demod"      # decim_demod | resamp_demod | resamp_stream (fmDemod in the resampler's loader) | overlap-free knobs only
 setter = {"decim_demod": chain.set_decim_demod_fusion, "resamp_demod": chain.set_demod_fusion,
           "resamp_stream": lambda on: L.lib.sdrhip_debug_set_resample_demod_stream(1 if on else 0),
-          "resamp_stream_dma": lambda on: L.lib.sdrhip_debug_set_resample_demod_stream(1001 if on else 0),   # the LDS-DMA variant   # round 5: streaming fmDemod + resampler vs the tile kernel
+          "resamp_stream_dma": lambda on: L.lib.sdrhip_debug_set_resample_demod_stream(1001 if on else 0),   # the LDS-DMA variant
+          "resamp_stream_dma3": lambda on: L.lib.sdrhip_debug_set_resample_demod_stream(2001 if on else 0),   # round 5: streaming fmDemod + resampler vs the tile kernel
           "fused_tail1": lambda on: chain.set_fused_tail(1 if on else 2), "fused_tail3": lambda on: chain.set_fused_tail(3 if on else 2),
           "nsub2": lambda on: chain.set_pipelining(2 if on else 1), "nsub4": lambda on: chain.set_pipelining(4 if on else 1),
           "nsub8": lambda on: chain.set_pipelining(8 if on else 1)}[knob]
