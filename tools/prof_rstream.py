@@ -12,7 +12,7 @@ q0, q1, halo = chain.plan(0, n, -1)
 ws_bytes = chain.workspace_bytes(n + 8192); ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
 out = torch.empty(q1 - q0, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
-for mode in (1, 0):
+for mode in (1, 1001, 0):          # streaming kernel with the prefetch in registers / in LDS (global_load_lds) / the tile kernel
     L.lib.sdrhip_debug_set_resample_demod_stream(mode)
     for _ in range(passes):
         chain.run(u8.data_ptr(), 0, n + halo, out.data_ptr(), q0, q1, ws.data_ptr(), ws_bytes, stream=st)
