@@ -18,10 +18,13 @@ ncclSend/ncclRecv on the compute stream) and processes shard+halo; torch.distrib
 is only the control plane.  Per-GPU work is fixed: weak scaling.  The same run also reports
 BASELINE configs[4]'s shard size (2^20 samples per GPU per pass).
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`
-(dominant kernel = the fused convert+decimate kernel, timed with HIP events on its
-own stream inside the timed region) and `cpu_baseline` (the reference's own C
-kernels, oracle/_ref, timed on this host's cores; N=1 only).
+The LAST line of stdout (rank 0) is ONE JSON object of < 4 KB: the driver's contract fields plus
+`roofline` (dominant kernel = the fused convert+decimate kernel, timed with HIP events on its
+own stream inside the timed region) and `cpu_baseline` (the reference's own C kernels,
+oracle/_ref, timed on this host's cores; N=1 only) and a few short companions (configs[1]'s
+roofline, stage times, configs[4]'s shard).  Everything else the run measures (ceilings, launch-size
+sweep, host-streamed rates, power) is printed BEFORE it, one object per line prefixed `extras <name> `,
+and written to gpurun_out/bench_extras_<N>gpu.json (contract_line / emit below).
 """
 import argparse
 import json
@@ -102,14 +105,16 @@ def cpu_baseline(seconds_single=6.0, seconds_all=8.0):
         "single_thread_value": round(single["sps_total"] / 1e6, 2),
         "isolated_kernels_Melements_per_s": {k[:-len("_elements_per_s")]: round(v / 1e6, 1) for k, v in stages.items() if k.endswith("_elements_per_s")},
         "harmonic_sum_of_isolated_kernels": round(stages["harmonic_sum_sps"] / 1e6, 2),
-        "sample": (f"oracle/cpu_chain_bench (compiled C caller, no Python in the loop): the FM receiver of examples/fm/fm.hs:34-41 block by "
-                   f"block over 64 x 8192-sample u8 IQ blocks, looped for {seconds_all:.0f} s on {threads} threads (one independent receiver "
-                   f"per hardware thread; {cores} physical cores) and {seconds_single:.0f} s single-thread; kind=reference: convertCAVX / "
-                   "decimateAVXRC / resampleAVXRR / filterAVXSymmetricRR / scaleAVX and the scalar kernels of the seam outputs are the "
-                   "reference's own C (oracle/_ref, -O2 -mavx2 -msse4), fmDemod and the Pipes' block bookkeeping (Haskell in the reference) "
-                   "come from the restatement -- fmDemod's atanf there is the fdlibm f32 MODEL (oracle/sdr_oracle.c: orc_atanf_model, the spec "
-                   "since round 5; == glibc 2.35 atanf on every float), not this host's libm; harmonic_sum_of_isolated_kernels = the five SIMD kernels alone on one cache-resident block "
-                   "(no seam outputs, no re-blocking, no data movement between stages), the ceiling of what the loop can reach"),
+        # `sample` is on the contract line (<= 300 characters there); `sample_detail` goes with the extras
+        "sample": (f"oracle/cpu_chain_bench: the FM receiver of examples/fm/fm.hs:34-41 over 64 x 8192-sample u8 IQ blocks, looped {seconds_all:.0f} s on "
+                   f"{threads} threads ({cores} cores; one receiver per thread) and {seconds_single:.0f} s single-thread; kernels = the reference's own C "
+                   "(oracle/_ref, -O2 -mavx2 -msse4); fmDemod + Pipes bookkeeping from the restatement"),
+        "sample_detail": ("compiled C caller, no Python in the loop; kind=reference: convertCAVX / decimateAVXRC / resampleAVXRR / filterAVXSymmetricRR / "
+                          "scaleAVX and the scalar kernels of the seam outputs are the reference's own C, fmDemod and the Pipes' block bookkeeping "
+                          "(Haskell in the reference) come from the restatement -- fmDemod's atanf there is the fdlibm f32 MODEL (oracle/sdr_oracle.c: "
+                          "orc_atanf_model, the spec since round 5; == glibc 2.35 atanf on every float), not this host's libm; "
+                          "harmonic_sum_of_isolated_kernels = the five SIMD kernels alone on one cache-resident block (no seam outputs, no re-blocking, "
+                          "no data movement between stages), the ceiling of what the loop can reach"),
     }
 
 
@@ -149,21 +154,25 @@ def plumbing_check(args, rank, world):
     plan = sharding.ShardPlan(chain, rank, world, S_len)
     stream = S.iq_u8(world * S_len + plan.halo_cap)                # the same global stream on every rank
     K = max(1, args.passes_per_exchange)
-    # row k: this rank's shard of super-block k (the stream with k added to every byte, so that a halo in the wrong row shows)
-    rows = torch.zeros(K, 2 * plan.n_in, dtype=torch.uint8)
-    for k in range(K):
-        rows[k, :2 * S_len] = torch.from_numpy((stream[2 * plan.s0:2 * plan.s1] + np.uint8(k)).copy())
+    right0 = ((rank + 1) % world) * S_len
     t0 = time.perf_counter()
-    for _ in range(args.warmup + args.steps):
-        if K == 1:
-            sharding.halo_exchange(rows[0], plan, dist)
-        else:
-            sharding.halo_exchange_batch(rows, plan, dist)
+    oks = {}
+    # the run's own K and, as the measured run does for BASELINE configs[4]'s shard, K = 1 and K = 16 (one exchange each is enough here)
+    for kk in sorted({K, 1, 16}):
+        # row k: this rank's shard of super-block k (the stream with k added to every byte, so that a halo in the wrong row shows)
+        rows = torch.zeros(kk, 2 * plan.n_in, dtype=torch.uint8)
+        for k in range(kk):
+            rows[k, :2 * S_len] = torch.from_numpy((stream[2 * plan.s0:2 * plan.s1] + np.uint8(k)).copy())
+        for _ in range((args.warmup + args.steps) if kk == K else 1):
+            if kk == 1:
+                sharding.halo_exchange(rows[0], plan, dist)
+            else:
+                sharding.halo_exchange_batch(rows, plan, dist)
+        oks[kk] = world == 1 or all(np.array_equal(rows[k, 2 * S_len:].numpy(), stream[2 * right0:2 * (right0 + plan.halo_cap)] + np.uint8(k)) for k in range(kk))
     if world > 1:
         dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    right0 = ((rank + 1) % world) * S_len
-    ok = world == 1 or all(np.array_equal(rows[k, 2 * S_len:].numpy(), stream[2 * right0:2 * (right0 + plan.halo_cap)] + np.uint8(k)) for k in range(K))
+    ok = all(oks.values())
     mine = (plan.q0, plan.q1, ok, float(el.item()))
     plans = [mine]
     if world > 1:
@@ -176,6 +185,7 @@ def plumbing_check(args, rank, world):
                           "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks_seen": len(plans),
                           "halo_ok_on_every_rank": all(p[2] for p in plans), "owned_outputs_tile_the_stream": tiles,
                           "halo_transport": "host memory through gloo", "seconds": round(float(el.item()), 4), "passes_per_exchange": K,
+                          "passes_per_exchange_checked": sorted({K, 1, 16}),
                           "samples_per_rank": S_len, "halo_samples": plan.halo_cap,
                           # a shard's first audio output rarely starts a polyphase cycle: the resampler's group (phase) of q0
                           "resampler_group_of_first_output_per_rank": [p[0] % 3 for p in plans],
@@ -197,6 +207,141 @@ def k2_source_sha256():
         text = re.sub(r"//[^\n]*", " ", text)
         h.update(" ".join(text.split()).encode())
     return h.hexdigest()
+
+
+
+# --------------------------------------------------------------------------------------
+# Output: ONE small contract line as the LAST line of stdout; everything else beside it
+# --------------------------------------------------------------------------------------
+CONTRACT_LINE_LIMIT = 4096       # the driver keeps an 8 KB tail of stdout and parses its last line (round 5's 23.5 KB line: parsed = null)
+
+
+def _short(text, limit):
+    text = " ".join(str(text).split())
+    return text if len(text) <= limit else text[:limit - 3] + "..."
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def contract_line(result):
+    """The contract line of a full result: metric / value / config / roofline / cpu_baseline and a handful of short companions,
+    nothing a reader has to scroll for.  The shape follows the reference's own benchmark report -- one short record per
+    benchmark (benchmarks/Benchmarks.hs:79-156) -- not one object holding every experiment of the run.  Returns a dict whose
+    JSON is below CONTRACT_LINE_LIMIT bytes (tests/test_bench_contract.py holds it to that)."""
+    line = _pick(result, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                          "vs_baseline", "dtype", "data", "audio_crc32_per_rank"))
+    cfg = result.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "blocks_per_gpu_per_pass", "samples_per_gpu_per_pass", "passes_per_step", "ms_per_pass",
+                                 "sharding", "ranks_seen_by_rccl", "passes_per_exchange", "exchange_us_per_pass", "devices_visible",
+                                 "ranks_share_devices", "order"))
+    line["config"]["workload"] = _short(cfg.get("workload", ""), 200)
+    if cfg.get("halo_transport"):
+        line["config"]["halo_transport"] = _short(cfg["halo_transport"], 60)
+    if cfg.get("overlap"):
+        line["config"]["overlap"] = _short(cfg["overlap"], 90)
+    rf = result.get("roofline") or {}
+    line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "algorithmic_flops_per_launch",
+                                  "algorithmic_bytes_per_launch"))
+    line["roofline"]["kernel"] = _short(rf.get("kernel", ""), 120)
+    if rf.get("traffic_note"):
+        line["roofline"]["traffic_note"] = _short(rf["traffic_note"], 120)
+    if isinstance(rf.get("hbm"), dict):
+        line["roofline"]["hbm"] = _pick(rf["hbm"], ("achieved", "peak", "unit", "frac"))
+    c1 = result.get("roofline_config1_cfloat_decimate")
+    if isinstance(c1, dict):
+        line["roofline_config1"] = {"kernel": _short(c1.get("kernel", ""), 60), "samples_per_launch": c1.get("samples_per_launch"), "bound": "hbm",
+                                    "ms": c1.get("avg_launch_ms"), "read_only_frac": c1.get("read_only_frac"), "frac": c1.get("frac"),
+                                    "peak": c1.get("peak"), "unit": c1.get("unit")}
+        ce = c1.get("ceilings_same_process")
+        if isinstance(ce, dict):
+            line["roofline_config1"]["over_best_no_arithmetic_stream"] = ce.get("kernel_over_nt_stream")
+    if result.get("stage_ms"):
+        line["stage_ms"] = result["stage_ms"]
+    for key in ("one_pass_at_a_time", "two_passes_in_flight", "fm_carrier_input"):
+        v = result.get(key)
+        if isinstance(v, dict):
+            line[key] = _pick(v, ("value", "ms_per_pass"))
+    s1 = result.get("shard_1M_samples_per_gpu")
+    if isinstance(s1, dict):            # BASELINE configs[4]'s shard, at every passes-per-exchange measured
+        line["shard_1M_samples_per_gpu"] = _pick(s1, ("value", "us_per_pass", "passes_per_exchange", "exchange_us_per_pass", "scaling_efficiency"))
+        for k, v in s1.items():
+            if k.startswith("passes_per_exchange_") and isinstance(v, dict):
+                line["shard_1M_samples_per_gpu"][k] = _pick(v, ("value", "us_per_pass", "exchange_us_per_pass", "scaling_efficiency"))
+    wh = result.get("without_halo_exchange")
+    if isinstance(wh, dict):
+        line["without_halo_exchange"] = {"value": wh.get("value")}
+        if isinstance(wh.get("shard_1M_samples_per_gpu"), dict):
+            line["without_halo_exchange"]["shard_1M_samples_per_gpu"] = _pick(wh["shard_1M_samples_per_gpu"], ("value", "us_per_pass"))
+    for key in ("scaling_efficiency", "per_rank_ms_per_pass"):
+        if key in result:
+            line[key] = result[key]
+    hs = result.get("host_streamed")
+    if isinstance(hs, dict) and isinstance(hs.get("link_roofline"), dict):   # PCIe-inclusive, never `value`: the two ends + configs[3]
+        lr = hs["link_roofline"]
+        line["host_streamed"] = {k: _pick(lr[k], ("Msamples_per_s", "Melements_per_s", "link_GBps", "frac")) for k in
+                                 ("fm_stream_1_block_per_push", "fm_stream_4096_blocks_per_push_memcpy",
+                                  "config3_firResampler_65536_float_blocks_memcpy", "config3_firResampler_65536_float_blocks_zero_copy") if k in lr}
+    sw = result.get("launch_size_sweep")
+    if isinstance(sw, dict):
+        worst = {}
+        for name, rows in sw.items():
+            if isinstance(rows, list):
+                vals = [(r.get("auto_over_best"), r.get("blocks_per_launch")) for r in rows if isinstance(r, dict) and r.get("auto_over_best")]
+                if vals:
+                    w = max(vals)
+                    worst[name] = {"worst_auto_over_best": w[0], "at_blocks": w[1]}
+        if worst:
+            line["launch_size_sweep"] = worst
+    cpu = result.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        line["cpu_baseline"] = _pick(cpu, ("value", "unit", "cores", "kind", "physical_cores", "single_thread_value"))
+        line["cpu_baseline"]["sample"] = _short(cpu.get("sample", ""), 300)
+    else:
+        line["cpu_baseline"] = None
+    if result.get("extras_file"):
+        line["extras_file"] = result["extras_file"]
+    # never over the limit, whatever a later round adds: drop the companions, least important first
+    for key in ("launch_size_sweep", "host_streamed", "fm_carrier_input", "two_passes_in_flight", "one_pass_at_a_time", "per_rank_ms_per_pass",
+                "stage_ms", "roofline_config1"):
+        if len(json.dumps(line)) < CONTRACT_LINE_LIMIT:
+            break
+        line.pop(key, None)
+    return line
+
+
+def emit(result, args, out=None):
+    """Print the run: first the extras (every top-level object of the full result that is not on the contract line), one per
+    stdout line, each prefixed `extras ` so that no line but the last starts with `{`; the full result also goes to
+    gpurun_out/bench_extras_<N>gpu.json (what comes back from a gpurun call; copied to profiles/ by hand).  LAST: the contract line."""
+    out = out or sys.stdout
+    path = None
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, f"bench_extras_{result.get('n_gpus', 1)}gpu.json")
+        with open(path, "w") as f:
+            json.dump(result, f, indent=1)
+        result["extras_file"] = os.path.relpath(path, ROOT)
+    except OSError:
+        path = None
+    line = contract_line(result)
+    # the most-asked-for extras last (the driver keeps a tail): config1 ceilings, sweep, host-streamed
+    order = [k for k in result if k not in ("roofline_config1_cfloat_decimate", "launch_size_sweep", "host_streamed")] + \
+            ["power", "host_streamed", "launch_size_sweep", "roofline_config1_cfloat_decimate"]
+    seen = set()
+    for k in order:
+        if k in seen or k not in result or result[k] is None or k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "extras_file"):
+            seen.add(k)
+            continue
+        seen.add(k)
+        if isinstance(result[k], (dict, list, str)):
+            out.write("extras " + k + " " + json.dumps(result[k]) + "\n")
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+    return line
 
 
 def main():
@@ -758,6 +903,18 @@ def main():
                     "us_per_pass": round(r1["elapsed"] / (r1["passes"] * st1) * 1e6, 2),
                     "passes_per_exchange": r1["ppe"], "exchange_us_per_pass": None if r1["exchange_us"] is None else round(r1["exchange_us"] / r1["ppe"], 2),
                     "note": "BASELINE configs[4] shard size (1M-sample block per GPU per pass): launch/latency-bound"}
+        if world > 1:
+            # configs[4] is quoted on THIS shard: answer it at the K the design recommends (16 super-blocks per exchange) as
+            # well as at K = 1, whatever --passes-per-exchange the run was started with, so one 8-GPU run of the driver's command suffices
+            for kk in (1, 16):
+                if kk == r1["ppe"]:
+                    rk = r1
+                else:
+                    rk = measure(128, st1, 1, 0, 0.05, False, ppe=kk)
+                shard_1m[f"passes_per_exchange_{kk}"] = {
+                    "value": round(world * rk["S_len"] * rk["passes"] * st1 / rk["elapsed"] / 1e6, 1),
+                    "us_per_pass": round(rk["elapsed"] / (rk["passes"] * st1) * 1e6, 2),
+                    "exchange_us_per_pass": None if rk["exchange_us"] is None else round(rk["exchange_us"] / rk["ppe"], 2)}
         try:
             el2, p2, sl2, same2 = measure_in_flight(128, st1, 1, 2)
             shard_1m["two_passes_in_flight"] = {
@@ -788,6 +945,12 @@ def main():
             rs = measure(128, st1, 1, 0, 0.05, False, do_exchange=False)
             replicas["shard_1M_samples_per_gpu"] = {"value": round(world * rs["S_len"] * rs["passes"] * st1 / rs["elapsed"] / 1e6, 1),
                                                     "us_per_pass": round(rs["elapsed"] / (rs["passes"] * st1) * 1e6, 2)}
+            if shard_1m is not None and replicas["shard_1M_samples_per_gpu"]["value"]:
+                rv = replicas["shard_1M_samples_per_gpu"]["value"]
+                shard_1m["scaling_efficiency"] = round(shard_1m["value"] / rv, 4)
+                for kk in (1, 16):
+                    if f"passes_per_exchange_{kk}" in shard_1m:
+                        shard_1m[f"passes_per_exchange_{kk}"]["scaling_efficiency"] = round(shard_1m[f"passes_per_exchange_{kk}"]["value"] / rv, 4)
     dbg("shard_1m done")
     # configs[1] kernel again, right after the sustained chain run (the u8-fused chain is the hotter workload: the clock the
     # chip grants afterwards is lower)
@@ -983,9 +1146,21 @@ def main():
         except Exception as e:                          # noqa: BLE001
             host["push_to_audio_us"] = f"failed: {e!r}"
         try:
+            # BASELINE configs[3]: firResampler 3/10, 191 taps, 65 536-float blocks, streamed (async double-buffered): 4 B up + 1.2 B down per element
             res = L.Resampler(3, 10, S.taps_resamp191(), L.ORDER_AVX)
-            pp = L.Pipe("resampler", res, BLOCK)
-            host["config3_firResampler_pipe_65536_float_blocks_Melements_per_s"] = round(H.pipe_rate(L, pp.h, 65536, 1, BLOCK, 4000, True) / 1e6, 1)
+            for zc in (True, False):
+                pp = L.Pipe("resampler", res, BLOCK)
+                eps = H.pipe_rate(L, pp.h, 65536, 1, BLOCK, 4000, zc)
+                row = {"Melements_per_s": round(eps / 1e6, 1), "us_per_push": round(65536 / eps * 1e6, 2), "link_GBps": round(eps * 5.2 / 1e9, 2)}
+                if isinstance(link, dict) and "pinned_h2d_GBps" in link:
+                    # 65 536 floats = 256 KiB per push (<= pipes.cpp kDirectBytes): the kernels read the pinned staging buffer in place
+                    # over PCIe either way; memcpy = the caller's block is copied into that buffer by the push, zero_copy = the source wrote it there
+                    ceil_ = link["kernel_reads_pinned_host_GBps"]
+                    row["link_ceiling_GBps"] = ceil_
+                    row["frac"] = round(row["link_GBps"] / ceil_, 3) if ceil_ else None
+                host.setdefault("link_roofline", {})["config3_firResampler_65536_float_blocks_" + ("zero_copy" if zc else "memcpy")] = row
+                if zc:
+                    host["config3_firResampler_pipe_65536_float_blocks_Melements_per_s"] = row["Melements_per_s"]
             dec8 = L.Decimator(8, S.taps_decim127(), L.ORDER_AVX, complex_=True)
             pd = L.Pipe("decimator", dec8, BLOCK)
             host["config1_firDecimator_pipe_8192_cfloat_blocks_Melements_per_s"] = round(H.pipe_rate(L, pd.h, BLOCK, 2, BLOCK, 20000, True) / 1e6, 1)
@@ -1106,7 +1281,7 @@ def main():
             "power": power,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(result))
+        emit(result, args)
 
     if comm is not None:
         comm.close()

@@ -19,7 +19,11 @@ LIB = os.path.join(LIBDIR, "libsdr_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+REPO = os.path.dirname(HERE)
+# -ffile-prefix-map: no absolute path of the checkout reaches the objects (__FILE__, debug / assert strings), so that a clean build of
+# the same tree in ANY directory gives the same libsdr_hip.so, byte for byte -- the sha256 build() and smoke() print then says
+# "a build of this tree", not just "the file that was pushed" (README.md "Reproducible build")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", f"-ffile-prefix-map={REPO}=.",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", f"-I{INCLUDE}", f"-I{CSRC}"]
 
 
@@ -62,8 +66,15 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _cuid(src):
+    """hipcc's compilation-unit id (the `__hip_cuid_<id>` symbol) is by default a hash of the ABSOLUTE source path + options; pin it
+    to the file's name so that it does not depend on where the checkout lies"""
+    import hashlib
+    return hashlib.sha1(("sdr_hip:" + os.path.basename(src)).encode()).hexdigest()[:16]
+
+
 def _compile(src, obj, extra):
-    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + extra + ["-x", "hip", "-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + extra + [f"-cuid={_cuid(src)}", "-x", "hip", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
@@ -88,7 +99,8 @@ def build(force=False, save_temps=False, verbose=False):
                 if verbose and warn:
                     sys.stderr.write(warn)
     if jobs or force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        # objects in sorted order (sources() sorts); -pthread: chain.cpp's staging-copy helpers are std::thread
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
