@@ -148,4 +148,18 @@ def cases(p):
     out["resampleRR_legacy_97_100_off33"] = (p.resample_legacy(6000, 97, 100, 33, h1500, x8k), crc(x8k, h1500))
     xc8k = S.cfloat_block(8192, seed=20)
     out["resampleAVXRC_97_100"] = (p.resample("resampleAVXRC", 7000, prep97, 5, xc8k, True)[0], crc(xc8k, h1500))
+    # The reference example's own filters (examples/fm/Coeffs.hs, tests/golden/example_taps.npz) on the three hot kernels, as
+    # examples/fm/fm.hs:30-41 uses them: 51 -> 52 taps duplicated, /8; 3/10 with 31 taps (groups of 11/10/10 -> 16); 32 half-taps
+    he = S.taps_example_rf_decim()
+    hep = np.concatenate([he, np.zeros((-he.size) % 4, np.float32)])
+    out["decimateAVXRC_example_taps"] = (p.decim("decimateAVXRC", (8192 - hep.size) // 8 + 1, 8, duplicate(hep), xu, True), crc(xu, hep))
+    hr = S.taps_example_audio_resampler()
+    prepe = orc.prepare_coeffs(8, 3, 10, hr)
+    xe = S.real_block(8192, seed=21, lo=-3.2, hi=3.2)            # fmDemod's range
+    ne = (8192 * 3 - 3 * prepe["groups"].shape[1]) // 10
+    re_, ge = p.resample("resampleAVXRR", ne, prepe, 0, xe)
+    out["resampleAVXRR_example_taps"] = (re_, crc(xe, hr))
+    out["resampleAVXRR_example_taps_endgroup"] = (np.array([ge], np.float32), crc(xe))
+    ha = S.taps_example_audio_filter_half()
+    out["filterAVXSymmetricRR_example_taps"] = (p.filt("filterAVXSymmetricRR", 8192 - 63, ha, xr), crc(xr, ha))
     return out

@@ -84,3 +84,23 @@ def taps_audio_half32():
     s = np.sin(np.pi * 0.3 * n) / (n * np.pi)
     w = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(64) / 63)
     return (s * w).astype(np.float32)[:32]
+
+
+# The reference FM example's REAL tap tables (examples/fm/Coeffs.hs:11-154; Octave remez designs), as data:
+# tests/golden/example_taps.npz, written by tests/golden/make_example_taps.py in the build container.
+def _example_taps(key):
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example_taps.npz"))
+    return np.ascontiguousarray(d[key], dtype=np.float32)
+
+
+def taps_example_rf_decim():        # 51 taps, fastDecimatorC 8 (fm.hs:30)
+    return _example_taps("rf_decim")
+
+
+def taps_example_audio_resampler():  # 31 taps, fastResamplerR 3 10 (fm.hs:31)
+    return _example_taps("audio_resampler")
+
+
+def taps_example_audio_filter_half():  # 32 = the first half of a 64-tap symmetric filter, fastFilterSymR (fm.hs:32)
+    return _example_taps("audio_filter_half")

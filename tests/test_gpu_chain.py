@@ -174,7 +174,9 @@ def test_fm_stream_long_run_equals_chain(hip, oracle):
     u8 = S.iq_u8(total)
     chain = _chain(hip)
     _, q1, _ = chain.plan(0, total, total)
-    full = _run(hip, chain, to_dev(u8), 0, total, 0, q1)
+    chain.set_small_chain(0)                    # the resident run on the STAGE kernels: 512 blocks are inside the one-kernel chain's
+    full = _run(hip, chain, to_dev(u8), 0, total, 0, q1)   # automatic range since round 5, and the pushes below take it on their own
+    chain.set_small_chain(2)
     st = hip.FmStream(chain, 8 * B, B)
     got = []
     for i in range(0, nblk, 8):
@@ -443,6 +445,31 @@ def test_fused_tail_equals_stage_kernels(hip, oracle, block):
         got = _run(hip, ch, d, 0, total, 0, q1)
         assert exp.size >= B
         assert_bit_equal(got[: exp.size], exp, "fused tail vs restated pipes")
+
+
+@pytest.mark.parametrize("nblk", [300, 600, 900, 1100])
+def test_small_chain_automatic_range_equals_stage_kernels(hip, nblk):
+    """the one-kernel chain's automatic bound moved from ~256 to ~900 source blocks (chain.cpp: small-chain bound) -- every
+    default run in between now takes kernels_small.hip.  The library's own choice (mode 2) against the stage kernels (mode 0), bit for
+    bit, at sizes inside and just past the new range: seamed (8192-sample blocks) and unseamed, from the stream start and as a shard
+    that starts inside the stream (s0 > 0, right halo only, a resampler phase that is not 0)."""
+    total = nblk * B
+    u8 = S.iq_u8(total + 8 * B)
+    for block in (B, 0):
+        ch = _chain(hip, block=block)
+        for s0 in (0, 37 * B + 4096):
+            n_in = total
+            q0, q1, _ = ch.plan(s0, s0 + n_in, s0 + n_in)           # the stream ends where the resident samples end
+            shard = to_dev(u8[2 * 0: 2 * n_in]) if s0 == 0 else to_dev(u8[2 * 4096: 2 * (4096 + n_in)])
+            ch.set_small_chain(0)
+            n0 = hip.lib.sdrhip_debug_small_chain_launches()
+            ref = _run(hip, ch, shard, s0, n_in, q0, q1)
+            assert hip.lib.sdrhip_debug_small_chain_launches() == n0, "mode 0 must never take the one-kernel chain"
+            ch.set_small_chain(2)
+            got = _run(hip, ch, shard, s0, n_in, q0, q1)
+            took = hip.lib.sdrhip_debug_small_chain_launches() - n0
+            assert took == (1 if nblk <= 800 else took), "runs of up to ~900 source blocks are the one-kernel chain's by default"
+            assert_bit_equal(got, ref, f"automatic route vs stage kernels, {nblk} blocks, seam block {block}, s0 {s0} (one-kernel chain launches: {took})")
 
 
 @pytest.mark.parametrize("block", [B, 0, 3 * B, 1000, 200])

@@ -162,6 +162,37 @@ def test_example_shaped_taps_chain(hip, oracle):
     assert_bit_equal(to_host(out)[: exp.size], exp, "example-shaped chain")
 
 
+def test_example_real_taps_chain(hip, oracle):
+    """The reference FM example's OWN filters (examples/fm/Coeffs.hs:11-154 as data: tests/golden/example_taps.npz -- Octave remez
+    designs, 51 / 31 / 32 half-taps) through the whole receiver of examples/fm/fm.hs:34-41, against the restated Pipes, device-resident
+    and block by block through the host-block operator."""
+    from oracle import pipes_model as PM
+    hd, hr, ha = S.taps_example_rf_decim(), S.taps_example_audio_resampler(), S.taps_example_audio_filter_half()
+    nblk = 90
+    u8 = S.iq_u8_fm(nblk * B)
+    blocks = [u8[2 * i * B:2 * (i + 1) * B] for i in range(nblk)]
+    exp = np.concatenate(PM.fm_receiver(oracle, blocks, hd, 8, hr, 3, 10, ha, 0.2, B))
+    chain = hip.FmChain(8, hd, 3, 10, hr, ha, 0.2, B)
+    total = nblk * B
+    q0, q1, _ = chain.plan(0, total, total)
+    ws = torch.empty(chain.workspace_bytes(total), dtype=torch.uint8, device="cuda")
+    out = dev_empty_f32(q1)
+    for mode in (0, 2):                         # stage kernels, then the library's own route
+        chain.set_small_chain(mode)
+        out.zero_()
+        chain.run(ptr(to_dev(u8)), 0, total, ptr(out), 0, q1, ptr(ws), ws.numel())
+        assert exp.size >= 2 * B
+        assert_bit_equal(to_host(out)[: exp.size], exp, f"the example's own taps, device-resident chain (small-chain mode {mode})")
+    st = hip.FmStream(chain, B, B)
+    outs = []
+    for blk in blocks:
+        outs += st.push(blk)
+    outs += st.flush()
+    got = np.concatenate(outs)
+    assert got.size >= exp.size
+    assert_bit_equal(got[: exp.size], exp, "the example's own taps, host-block stream")
+
+
 def test_chain_pipelining_is_invisible(hip):
     """The internal two-stream software pipelining (nsub sub-batches) must not change a bit, and the
     caller's stream must see the finished result without any extra synchronisation."""
