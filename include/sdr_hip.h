@@ -324,13 +324,6 @@ int sdrhip_fm_chain_graph_create(sdrhip_fm_graph **g, sdrhip_fm_chain *c, const 
 int sdrhip_fm_chain_graph_launch(sdrhip_fm_graph *g, void *stream);
 void sdrhip_fm_chain_graph_destroy(sdrhip_fm_graph *g);
 
-/* One run can be software-pipelined over `nsub` sub-batches of the output range (default 1 = off;
- * measured slower than off on MI355X, see chain.cpp):
- * the decimate kernel of sub-batch i+1 runs on the caller's stream while fmDemod / resample /
- * filter of sub-batch i run on an internal second HIP stream; the caller's stream is made to
- * wait for the internal one before the call returns control of the stream.  Results do not
- * depend on nsub (every kernel works in global stream indices). */
-int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain *c, int nsub);
 /* Two runs in flight (round 4; default off).  The receiver's successive batches are independent given their raw input
  * (examples/fm/fm.hs:34-41: no stage carries a RESULT from one batch into the next -- only input samples), so with on = 1
  * consecutive sdrhip_fm_chain_run calls alternate between two internal HIP streams and the two halves of the workspace: the
@@ -351,9 +344,8 @@ int sdrhip_fm_chain_join(sdrhip_fm_chain *c, void *stream);
  * when the chain has the FM receiver's shape (3/10 resampler with 64-float groups, 64 half-tap symmetric filter, AVX
  * order, buffers longer than one tile).  mode 0 = never (the three stage kernels), 1 = always, 2 = auto (default): only
  * for runs of at most 768 audio outputs (pushes of one or two 8192-sample source blocks), where one launch replaces
- * three; longer runs are faster on the stage kernels (every stage is VALU-bound, and a one-tile run is one workgroup);
- * 3 = fmDemod as its own kernel, then resampler + filter fused (measured 0.385 ms against 0.352 for the stage kernels per
- * 2^29-sample pass: not a default).  Same bits. */
+ * three; longer runs are faster on the stage kernels (every stage is VALU-bound, and a one-tile run is one workgroup).
+ * Same bits. */
 int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain *c, int mode);
 /* The WHOLE chain (convert + decimator -> fmDemod -> resampler -> audio filter * gain) as ONE kernel for launch-bound runs
  * -- BASELINE configs[4]'s 2^20-sample shard, a push of a few source blocks -- when the chain has the FM receiver's shape
@@ -372,45 +364,14 @@ long long sdrhip_debug_small_chain_launches(void);
 long long sdrhip_debug_resample_cycle_launches(void);
 /* launches of the real decimator kernel for factors 2 / 4 / 8 / 16 (kernels_decimate_real.hip), process-wide */
 long long sdrhip_debug_decimate_real16_launches(void);
-/* A/B switch (measurements only; results are identical): 0 = the tiled AVX-order decimator runs every tile through its general
- * instantiation, 1 (default) = whole tiles through the specialised one.  SDRHIP_FULL_TILES=0/1 sets the initial value. */
-void sdrhip_debug_set_full_tiles(int on);
-/* A/B switch (measurements only; results are identical): 1 (default) = decimate-by-8, 128-tap, AVX-order launches that are not
- * launch-bound take the register-resident systolic kernel (kernels_systolic.hip, round 4), 0 = the LDS-tiled kernel everywhere.
- * SDRHIP_SYSTOLIC=0/1 sets the initial value.  sdrhip_debug_systolic_launches: launches it has served, process-wide. */
-void sdrhip_debug_set_systolic(int on);
-/* which restatement of fmDemod's arithmetic (Demod.hs:21-46) the stand-alone kernel runs: 0 nested ternaries, 1 selects, 2 the
- * common case with a wave vote and the select form behind it, 3 (default) the same with
- * atanf's argument reduction looked up in an LDS table (what the resampler's fused loader runs), 4 the table form on two samples at a
- * time with packed arithmetic (round 5; measured slower).  Same bits. */
-void sdrhip_debug_set_demod_form(int form);
-int sdrhip_debug_demod_form(void);   /* the form the next stand-alone launch runs (what the setter accepted) */
-/* fmDemod + the 3/10 resampler as a streaming kernel (kernels_resample_stream.hip, round 5): a workgroup walks a run of tiles with the
- * next tile's samples in flight behind the current tile's arithmetic.  0 (default: measured slower, 0.236 against 0.198 ms per 2^26 inputs;
- * SDRHIP_RESAMP_STREAM sets the initial value) = off (the tile kernel with fmDemod in its loader), 1 = runs of at least four tiles per workgroup, 2 = every run it can take, n > 2 = every run, cut for n workgroups (tests);
- * 1000 + m = the same in mode m with the prefetch in LDS (global_load_lds_dwordx4 into per-wave slots) instead of registers.  Same bits.
- * ..._launches: launches it has served; ..._plan: the cut of `ncycles` polyphase cycles over a device of `cus` compute units. */
-void sdrhip_debug_set_resample_demod_stream(int on);
-long long sdrhip_debug_resample_demod_stream_launches(void);
-void sdrhip_debug_resample_demod_stream_plan(int ncycles, int cus, int *ntiles, int *tiles_per_wg, int *grid);
+/* Which kernel serves the decimate-by-8, 128-tap, AVX-order first stage: 0 = the LDS-tiled kernel everywhere, 1 = the
+ * register-resident systolic kernel (kernels_systolic.hip) wherever its shape fits, 2 (default; SDRHIP_SYSTOLIC sets the initial
+ * value) = by launch size and input kind, as measured (tools/route_sweep_fine.py).  Results are identical.
+ * sdrhip_debug_systolic_launches: launches the systolic kernel has served, process-wide; sdrhip_debug_systolic_plan: the strip cut of a
+ * launch of `count` outputs (host arithmetic only): strips [0, nwhole) take the unguarded body. */
+void sdrhip_debug_set_systolic(int mode);
 long long sdrhip_debug_systolic_launches(void);
-/* the strip cut of a systolic launch of `count` outputs (host arithmetic only; demod: the fused decimate + fmDemod form): strips
- * [0, nwhole) take the unguarded body */
-void sdrhip_debug_systolic_plan(int count, int demod, int *nstrips, int *nwhole);
-/* the 3/10 resampler's register-resident systolic kernel (kernels_resample_systolic.hip, round 4): OFF by default -- measured no faster
- * than the LDS-tiled kernel (0.092 against 0.091 ms per 2^26 inputs) -- SDRHIP_RESAMP_SYSTOLIC=1 or the setter switch it on (same bits);
- * launches it has served, and the strip cut of a launch of `ncycles` polyphase cycles whose inputs exist up to avail_total */
-void sdrhip_debug_set_resample_systolic(int on);
-long long sdrhip_debug_resample_systolic_launches(void);
-void sdrhip_debug_resample_systolic_plan(int ncycles, long long avail_total, int *nstrips, int *nwhole);
-/* fmDemod inside the first stage's kernel (round 4; default OFF, SDRHIP_FUSE_K2K3=0/1): when the first stage is the FM receiver's
- * (decimate by 8, 128 taps, AVX order, u8 IQ in) and the run is not launch-bound, the register-resident systolic decimator
- * demodulates its outputs in place and stores the demodulated stream -- the decimated stream (8 B written + 8 B read per decimator
- * output, the largest intermediate of the chain) never reaches HBM.  Same bits; the per-stage timing then books both under
- * `decimate` and reports 0 for `fm_demod`.  Measured slower than the two kernels on MI355X (chain.cpp: 1.095 against 1.052 ms per
- * 2^29-sample pass): fmDemod's arithmetic hides behind its own memory traffic as a kernel of its own and does not inside a
- * kernel bound by instruction issue. */
-int sdrhip_fm_chain_set_decim_demod_fusion(sdrhip_fm_chain *c, int enable);
+void sdrhip_debug_systolic_plan(int count, int *nstrips, int *nwhole);
 /* fmDemod inside the resampler's tile loader for large batches (>= 2^18 resampler outputs per run): the demodulated stream
  * never makes its round trip through HBM (12 B per decimated sample less traffic); the per-stage timing then books the pair
  * under `resample` (and reports 0 for `fm_demod`).  Same bits.  ON by default since round 4 (SDRHIP_FUSE_DEMOD=0 turns it off):
@@ -421,8 +382,7 @@ int sdrhip_fm_chain_set_demod_fusion(sdrhip_fm_chain *c, int enable);
  * launched on; stages {decimate(+seam fix-up), fmDemod, resample, filter(+gain), fused tail (the three in one kernel),
  * whole chain in one kernel (sdrhip_fm_chain_set_small_chain)}.
  * read_timing waits for the recorded runs, returns the SUM of elapsed ms per stage over
- * `*runs` runs and resets the recorder.  With pipelining on, stages of neighbouring sub-batches
- * overlap in time, so the per-stage sums add up to more than the run's wall time. */
+ * `*runs` runs and resets the recorder. */
 int sdrhip_fm_chain_enable_timing(sdrhip_fm_chain *c, int enable);
 int sdrhip_fm_chain_read_timing(sdrhip_fm_chain *c, double ms_sum[6], int *runs);
 

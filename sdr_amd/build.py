@@ -33,20 +33,7 @@ FILE_FLAGS = {"kernels_chain.hip": ["-fno-slp-vectorize"], "kernels_split.hip": 
               "kernels_tail.hip": ["-fno-slp-vectorize"], "kernels_cplx.hip": ["-fno-slp-vectorize"],
               "kernels_resample_cycle.hip": ["-fno-slp-vectorize"], "kernels_decimate_real.hip": ["-fno-slp-vectorize"],
               # packed operations written out as 2-vectors; the vectoriser would undo the DPP-fused additions
-              "kernels_systolic.hip": ["-fno-slp-vectorize"], "kernels_resample_systolic.hip": ["-fno-slp-vectorize"],
-              "kernels_resample_stream.hip": ["-fno-slp-vectorize"]}
-if os.environ.get("SDRHIP_SPLIT_DEFS"):   # tuning experiments, e.g. "-DSPLIT_CB=8 -DSPLIT_U=4"
-    FILE_FLAGS["kernels_split.hip"] = FILE_FLAGS["kernels_split.hip"] + os.environ["SDRHIP_SPLIT_DEFS"].split()
-if os.environ.get("SDRHIP_NO_SLP_FAST"):
-    FILE_FLAGS["kernels_fast.hip"] = ["-fno-slp-vectorize"]
-if os.environ.get("SDRHIP_CHAIN_DEFS"):   # tuning experiments on the tail kernels
-    FILE_FLAGS["kernels_chain.hip"] = FILE_FLAGS["kernels_chain.hip"] + os.environ["SDRHIP_CHAIN_DEFS"].split()
-if os.environ.get("SDRHIP_SYSTOLIC_DEFS"):  # measurements on the systolic decimator, e.g. "-DSDRHIP_SYSTOLIC_ROTCOST=1"
-    FILE_FLAGS["kernels_systolic.hip"] = FILE_FLAGS["kernels_systolic.hip"] + os.environ["SDRHIP_SYSTOLIC_DEFS"].split()
-if os.environ.get("SDRHIP_RSTREAM_DEFS"):  # tuning experiments on the streaming fmDemod + resampler, e.g. "-DSDRHIP_RSTREAM_MINW=5"
-    FILE_FLAGS["kernels_resample_stream.hip"] = FILE_FLAGS["kernels_resample_stream.hip"] + os.environ["SDRHIP_RSTREAM_DEFS"].split()
-if os.environ.get("SDRHIP_FAST_DEFS"):    # tuning experiments on the tiled decimator, e.g. "-DSDRHIP_INL_STEP=8"
-    FILE_FLAGS["kernels_fast.hip"] = FILE_FLAGS.get("kernels_fast.hip", []) + os.environ["SDRHIP_FAST_DEFS"].split()
+              "kernels_systolic.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

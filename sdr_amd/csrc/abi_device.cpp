@@ -378,9 +378,7 @@ int resamp_run_demod(const ResampDesc* r, hipStream_t s, const float* d_iq, bool
     if (d_iq != nullptr) {
         SDRHIP_REQUIRE(!r->cplx && y_count > 0, "resamp_run_demod: fmDemod feeds a real resampler");
         const bool small = g.seamBI > 0 && g.count <= small_generic_r;
-        // (the test modes of the streaming kernel take short runs too: every cut of a run must be reachable at sizes the suite can afford)
-        const int min_fused = resample_demod_stream_mode() % 1000 >= 2 ? 8192 : kFusedDemodMinOutputs;
-        if (!small && r->lanes == 8 && g.count >= min_fused &&
+        if (!small && r->lanes == 8 && g.count >= kFusedDemodMinOutputs &&
             launch_resample_3_10_fast(s, g, t, r->increments.data(), r->d_groups, r->d_plain, d_in, d_out, d_iq, iq_has_prev, y_count)) {
             if (demod_fused) *demod_fused = true;
             SDRHIP_CHECK_HIP(hipGetLastError());

@@ -48,43 +48,23 @@ struct sdrhip_fm_chain {
         return decim.corder == CO_L2 && decim.Lp <= 128;      // the SSE order's fused instantiations (kernels_fast_orders.hip)
     }
 
-    // Optional software pipelining inside one run (sdrhip_fm_chain_set_pipelining): the outputs are cut
-    // into `nsub` sub-batches; the decimate kernel of sub-batch i+1 runs on the caller's stream while
-    // fmDemod / resample / filter of sub-batch i run on `aux`.  OFF by default: an interleaved A/B on
-    // MI355X (tools/pipeline_test.py, 2^29 samples) measured 1.141 ms per run without it against 1.174
-    // (nsub 4) and 1.219 (nsub 8) with it -- every kernel of the chain is VALU-issue-bound, so co-resident
-    // kernels only take issue slots from each other, and the extra launches cost more than they hide.
-    int nsub = 1;
     // fmDemod -> resampler -> audio filter (* gain) as ONE kernel (kernels_tail.hip), y and z never leaving LDS.  Measured on
     // MI355X (2^29 samples per run): 0.43-0.49 ms against 0.38 + 0.02 ms for the three stage kernels and their seam fix-ups --
     // every stage is VALU-bound, fusion saves HBM traffic that was not the limit and pays 7 % recomputed overlap; but a run
     // that fills at most one tile (a push of one to six 8192-sample source blocks) costs ONE launch of a few microseconds
     // instead of eight.  mode 0 = never, 1 = always, 2 = auto (runs of at most one tile): sdrhip_fm_chain_set_fused_tail,
-    // SDRHIP_FUSED_TAIL=0/1/2.
+    // SDRHIP_FUSED_TAIL=0/1/2.  (Rounds 2-4 also measured sub-batch pipelining of one run over two streams and "fmDemod kernel + fused
+    // resampler / filter": both slower, both gone; LABNOTES.)
     int fused_tail = getenv("SDRHIP_FUSED_TAIL") ? atoi(getenv("SDRHIP_FUSED_TAIL")) : 2;
     // fmDemod in the resampler's tile loader: ON by default since round 4 (with the packed-pair resampler the pass gains 1.0 %,
     // 1.005-1.011 against 1.017-1.019 ms, alternating in one process: the pair itself is slower, 0.269 against 0.159 + 0.089 ms, but
     // 0.54 GB less traffic per pass leaves the power-capped decimator 4 % more clock)
     bool fuse_demod = getenv("SDRHIP_FUSE_DEMOD") ? atoi(getenv("SDRHIP_FUSE_DEMOD")) != 0 : true;
-    // fmDemod in the systolic decimator's epilogue (round 4, kernels_systolic.hip): the decimated stream -- the largest intermediate,
-    // 8 B written and 8 B read per decimator output -- never reaches HBM.  OFF by default: measured on MI355X (2^29 samples per pass,
-    // alternating A/B in one process, tools/k2k3_fusion_ab.py) the pair costs 0.908-0.911 ms fused against 0.688-0.691 + 0.159-0.160 ms
-    // as two kernels (whole pass 1.094-1.098 against 1.050-1.055 ms).  The stand-alone fmDemod streams at 5 TB/s with its ~120
-    // instructions per sample hidden behind its own memory traffic; moved into the decimator, the same instructions are added to a
-    // kernel that is bound by instruction issue and power, and the 1.07 GB of traffic saved (0.14 J at 130 pJ/B) buys back less than
-    // that.  Kept as an option (same bits; sdrhip_fm_chain_set_decim_demod_fusion, SDRHIP_FUSE_K2K3=1) and under test.
-    bool fuse_k2k3 = getenv("SDRHIP_FUSE_K2K3") ? atoi(getenv("SDRHIP_FUSE_K2K3")) != 0 : false;
-    bool k2k3_shape_ok() const
-    {
-        return fuse_k2k3 && fused_tail != 3 && fused_first_stage() && decim.corder == CO_L4 && decim.factor == 8 && decim.Lp == 128 &&
-               block >= 0;
-    }
-    bool tail_shape_any() const { return !resamp.cplx && resamp.lanes == 8 && !audio.cplx && audio.sym && audio.lanes == 8 && audio.factor == 1; }
     bool tail_shape_ok(int64_t n_out) const
     {
         // auto: runs of up to two source blocks (measured per push, in place: fused 27.3 / 29.1 / 36.6 us for 1 / 2 / 4 blocks,
         // the stage kernels on their one-launch routes 30.0 / 30.7 / 32.6 -- the single workgroup of a one-tile run is serial)
-        if (fused_tail == 0 || fused_tail == 3 || (fused_tail == 2 && n_out > kFusedTailAutoOutputs)) return false;
+        if (fused_tail == 0 || (fused_tail == 2 && n_out > kFusedTailAutoOutputs)) return false;
         return !resamp.cplx && resamp.lanes == 8 && !audio.cplx && audio.sym && audio.lanes == 8 && audio.factor == 1;
     }
     // The whole chain as one kernel for launch-bound runs (kernels_small.hip): 0 = never, 1 = whenever the configuration is the
@@ -118,10 +98,6 @@ struct sdrhip_fm_chain {
         }
         return SDRHIP_OK;
     }
-    hipStream_t aux = nullptr;
-    std::vector<hipEvent_t> ev_k2;       // per sub-batch: decimator output ready
-    hipEvent_t ev_done = nullptr;        // aux finished this run
-    hipEvent_t ev_free = nullptr;        // caller's stream reached this run (workspace reusable by aux)
 
     // optional per-stage timing with HIP events on the stream each kernel is launched on
     bool timing = false;
@@ -140,17 +116,8 @@ struct sdrhip_fm_chain {
         *ev = ev_pool[ev_used++];
         return SDRHIP_OK;
     }
-    int ensure_streams()
-    {
-        if (aux) return SDRHIP_OK;
-        SDRHIP_CHECK_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-        SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
-        SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&ev_free, hipEventDisableTiming));
-        return SDRHIP_OK;
-    }
     ~sdrhip_fm_chain()
     {
-        if (aux) (void)hipStreamSynchronize(aux);
         for (int j = 0; j < 2; j++) {
             if (lane[j]) (void)hipStreamSynchronize(lane[j]);
             if (ev_in[j]) (void)hipEventDestroy(ev_in[j]);
@@ -158,10 +125,6 @@ struct sdrhip_fm_chain {
             if (lane[j]) (void)hipStreamDestroy(lane[j]);
         }
         for (auto ev : ev_pool) (void)hipEventDestroy(ev);
-        for (auto ev : ev_k2) (void)hipEventDestroy(ev);
-        if (ev_done) (void)hipEventDestroy(ev_done);
-        if (ev_free) (void)hipEventDestroy(ev_free);
-        if (aux) (void)hipStreamDestroy(aux);
     }
 
     // reach of resampler output m in y: the One kernel walks nloop floats, the Cross
@@ -437,17 +400,12 @@ static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
         if (c->timing && c->ev_used > 0) c->ev_used--;      // not this configuration after all: the stage kernels below
     }
 
-    // sub-batches: equal slices of the output range, each with its own back-to-front input ranges
-    int nsub = c->nsub;
-    if (nq < (int64_t)nsub * 65536) nsub = (int)(nq / 65536);   // below ~2^21 input samples a slice is launch-bound
-    if (nsub < 1) nsub = 1;
-    if (nsub > 16) nsub = 16;
-    std::vector<SubRange> sub(nsub);
+    // the stages' ranges, back to front
+    SubRange r;
     size_t off = 0;
-    for (int i = 0; i < nsub; i++) {
-        SubRange& r = sub[i];
-        r.q0 = q0 + nq * i / nsub;
-        r.q1 = q0 + nq * (i + 1) / nsub;
+    {
+        r.q0 = q0;
+        r.q1 = q1;
         r.m0 = r.q0;
         r.m1 = r.q1 + c->audio.Lp - 1;                                                   // resampler outputs z[m0,m1)
         r.ky0 = c->resamp.in_offset(r.m0);
@@ -467,7 +425,7 @@ static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
         r.off_z = r.off_y + align_up((size_t)(r.ky1 - r.ky0) * 4, 256);
         off = r.off_z + align_up((size_t)(r.m1 - r.m0) * 4, 256);
     }
-    const int64_t n_lo = sub.front().kd0 * c->decim.factor, n_hi = (sub.back().kd1 - 1) * c->decim.factor + c->decim.Lp;
+    const int64_t n_lo = r.kd0 * c->decim.factor, n_hi = (r.kd1 - 1) * c->decim.factor + c->decim.Lp;
     if (n_lo < s0 || n_hi > s0 + n_in) {
         set_error("sdrhip_fm_chain_run: outputs [%lld,%lld) need samples [%lld,%lld) but d_in holds [%lld,%lld)",
                   (long long)q0, (long long)q1, (long long)n_lo, (long long)n_hi, (long long)s0, (long long)(s0 + n_in));
@@ -479,20 +437,7 @@ static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
     }
     char* ws = (char*)d_workspace;
     int rc;
-    const bool two_streams = nsub > 1;
-    hipStream_t st = s;   // stream of the tail kernels
-    if (two_streams) {
-        if ((rc = c->ensure_streams()) != SDRHIP_OK) return rc;
-        while ((int)c->ev_k2.size() < nsub) {
-            hipEvent_t e;
-            SDRHIP_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->ev_k2.push_back(e);
-        }
-        st = c->aux;
-        // aux must not touch the workspace / output before everything queued earlier on the caller's stream is done
-        SDRHIP_CHECK_HIP(hipEventRecord(c->ev_free, s));
-        SDRHIP_CHECK_HIP(hipStreamWaitEvent(c->aux, c->ev_free, 0));
-    }
+    hipStream_t st = s;
     auto begin_span = [&](int stage, hipStream_t on, hipEvent_t* b) -> int {
         if (!c->timing) return SDRHIP_OK;
         int r2 = c->new_event(b);
@@ -512,24 +457,14 @@ static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
     };
     if (c->timing) c->runs++;
 
-    for (int i = 0; i < nsub; i++) {
-        const SubRange& r = sub[i];
+    do {
         float* d_d = (float*)(ws + r.off_d);
         float* d_y = (float*)(ws + r.off_y);
         float* d_z = (float*)(ws + r.off_z);
         hipEvent_t b = nullptr;
         // K1+K2 on the caller's stream: u8 -> cfloat -> decimate (convert.c:37-50 fused into decimate.c:105-113)
         if ((rc = begin_span(0, s, &b)) != SDRHIP_OK) return rc;
-        bool k2k3 = false;
-        if (c->k2k3_shape_ok() && !c->tail_shape_ok(r.q1 - r.q0)) {
-            // ... and K3 in the same kernel: y straight from the decimator's registers, d never written (kernels_systolic.hip)
-            if ((rc = c->decim.ensure_device()) != SDRHIP_OK) return rc;
-            const bool last_zero = (int)c->decim.h_plain.size() == c->decim.Lp && c->decim.h_plain[c->decim.Lp - 1] == 0.0f;
-            k2k3 = launch_decimate_demod_systolic(s, d_in_iq, s0, r.kd0, r.kd1, r.ky0, c->decim.d_scaled, c->decim.d_cross, c->decim.Lp, last_zero,
-                                                  c->block, d_y);
-        }
-        if (k2k3) {
-        } else if (c->fused_first_stage()) {
+        if (c->fused_first_stage()) {
             if ((rc = fir_run(&c->decim, s, d_in_iq, true, s0, d_d, r.kd0, r.kd1, c->block)) != SDRHIP_OK) return rc;
         } else {
             float* d_x = (float*)(ws + r.off_x);
@@ -537,10 +472,6 @@ static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
             if ((rc = fir_run(&c->decim, s, d_x, false, r.xa, d_d, r.kd0, r.kd1, c->block)) != SDRHIP_OK) return rc;
         }
         if ((rc = end_span(0, s, b)) != SDRHIP_OK) return rc;
-        if (two_streams) {
-            SDRHIP_CHECK_HIP(hipEventRecord(c->ev_k2[i], s));
-            SDRHIP_CHECK_HIP(hipStreamWaitEvent(st, c->ev_k2[i], 0));
-        }
         if (c->tail_shape_ok(r.q1 - r.q0)) {
             if ((rc = c->resamp.ensure_device()) != SDRHIP_OK || (rc = c->audio.ensure_device()) != SDRHIP_OK) return rc;
             if ((rc = begin_span(4, st, &b)) != SDRHIP_OK) return rc;
@@ -554,32 +485,7 @@ static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
             }
             if (c->timing && c->ev_used > 0) c->ev_used--;      // the span's begin event goes back to the pool
         }
-        if (c->fused_tail == 3 && c->tail_shape_any()) {
-            // K3 as its own kernel, then resampler + filter (* gain) fused: z never reaches HBM, no fix-up launches (mode 3)
-            if ((rc = c->resamp.ensure_device()) != SDRHIP_OK || (rc = c->audio.ensure_device()) != SDRHIP_OK) return rc;
-            if ((rc = begin_span(1, st, &b)) != SDRHIP_OK) return rc;
-            launch_fm_demod_fast(st, d_d + 2 * (r.ky0 - r.kd0), d_y, r.ky1 - r.ky0, r.ky0 > r.kd0, 0.0f, 0.0f);
-            if ((rc = end_span(1, st, b)) != SDRHIP_OK) return rc;
-            if ((rc = begin_span(4, st, &b)) != SDRHIP_OK) return rc;
-            const bool took = launch_fm_tail_fused(st, d_d, r.kd0, r.kd1, r.ky0, r.ky1, d_audio + (r.q0 - q0), r.q0, r.q1, c->resamp.d_groups,
-                                                   c->resamp.row_stride, c->resamp.nloop, c->resamp.increments.data(), c->resamp.num_groups,
-                                                   c->resamp.I, c->resamp.D, c->resamp.Lp, c->resamp.d_plain, c->resamp.ntaps, c->audio.d_taps,
-                                                   c->audio.ntaps_kernel, c->audio.d_cross, c->gain, c->block, d_y);
-            if (took) {
-                if ((rc = end_span(4, st, b)) != SDRHIP_OK) return rc;
-                continue;
-            }
-            if (c->timing && c->ev_used > 0) c->ev_used--;
-            // not the FM receiver's shape: y is in place, the stage kernels finish the run
-            if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;
-            if ((rc = resamp_run(&c->resamp, st, d_y, r.ky0, d_z, r.m0, r.m1, c->block, c->block)) != SDRHIP_OK) return rc;
-            if ((rc = end_span(2, st, b)) != SDRHIP_OK) return rc;
-            if ((rc = begin_span(3, st, &b)) != SDRHIP_OK) return rc;
-            if ((rc = fir_run(&c->audio, st, d_z, false, r.m0, d_audio + (r.q0 - q0), r.q0, r.q1, c->block, c->gain)) != SDRHIP_OK) return rc;
-            if ((rc = end_span(3, st, b)) != SDRHIP_OK) return rc;
-            continue;
-        }
-        if (c->fuse_demod && !k2k3) {
+        if (c->fuse_demod) {
             // K3+K4: fmDemod inside the resampler's tile loader on large batches (y never reaches HBM), a stand-alone fmDemod
             // launch first otherwise; timed as the resample stage
             if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;
@@ -588,11 +494,9 @@ static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
             if ((rc = end_span(2, st, b)) != SDRHIP_OK) return rc;
         } else {
             // K3: fmDemod; at stream start the carried sample is 0 (Demod.hs:41)
-            if (!k2k3) {
-                if ((rc = begin_span(1, st, &b)) != SDRHIP_OK) return rc;
-                launch_fm_demod_fast(st, d_d + 2 * (r.ky0 - r.kd0), d_y, r.ky1 - r.ky0, r.ky0 > r.kd0, 0.0f, 0.0f);
-                if ((rc = end_span(1, st, b)) != SDRHIP_OK) return rc;
-            }
+            if ((rc = begin_span(1, st, &b)) != SDRHIP_OK) return rc;
+            launch_fm_demod_fast(st, d_d + 2 * (r.ky0 - r.kd0), d_y, r.ky1 - r.ky0, r.ky0 > r.kd0, 0.0f, 0.0f);
+            if ((rc = end_span(1, st, b)) != SDRHIP_OK) return rc;
             // K4: polyphase resample
             if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;
             if ((rc = resamp_run(&c->resamp, st, d_y, r.ky0, d_z, r.m0, r.m1, c->block, c->block)) != SDRHIP_OK) return rc;
@@ -603,12 +507,7 @@ static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
         if ((rc = begin_span(3, st, &b)) != SDRHIP_OK) return rc;
         if ((rc = fir_run(&c->audio, st, d_z, false, r.m0, d_audio + (r.q0 - q0), r.q0, r.q1, c->block, c->gain)) != SDRHIP_OK) return rc;
         if ((rc = end_span(3, st, b)) != SDRHIP_OK) return rc;
-    }
-    if (two_streams) {
-        // the caller's stream continues only after the tail of the last sub-batch
-        SDRHIP_CHECK_HIP(hipEventRecord(c->ev_done, c->aux));
-        SDRHIP_CHECK_HIP(hipStreamWaitEvent(s, c->ev_done, 0));
-    }
+    } while (false);
     SDRHIP_CHECK_HIP(hipGetLastError());
     return SDRHIP_OK;
 }
@@ -632,7 +531,7 @@ int sdrhip_fm_chain_graph_create(sdrhip_fm_graph** out, sdrhip_fm_chain* c, cons
 {
     SDRHIP_REQUIRE(out != nullptr && c != nullptr, "sdrhip_fm_chain_graph_create");
     *out = nullptr;
-    SDRHIP_REQUIRE(!c->timing && c->nsub == 1 && !c->overlap, "sdrhip_fm_chain_graph_create: per-stage timing, sub-batch pipelining and two runs "
+    SDRHIP_REQUIRE(!c->timing && !c->overlap, "sdrhip_fm_chain_graph_create: per-stage timing and two runs "
                                                "in flight record events on the chain's own streams: switch them off for a captured run");
     sdrhip_fm_graph* g = new sdrhip_fm_graph();
     hipError_t e = hipStreamCreateWithFlags(&g->cap, hipStreamNonBlocking);
@@ -662,16 +561,9 @@ int sdrhip_fm_chain_graph_launch(sdrhip_fm_graph* g, void* stream)
 
 void sdrhip_fm_chain_graph_destroy(sdrhip_fm_graph* g) { delete g; }
 
-int sdrhip_fm_chain_set_pipelining(sdrhip_fm_chain* c, int nsub)
-{
-    SDRHIP_REQUIRE(c != nullptr && nsub >= 1 && nsub <= 16, "sdrhip_fm_chain_set_pipelining");
-    c->nsub = nsub;
-    return SDRHIP_OK;
-}
-
 int sdrhip_fm_chain_set_fused_tail(sdrhip_fm_chain* c, int enable)
 {
-    SDRHIP_REQUIRE(c != nullptr && enable >= 0 && enable <= 3, "sdrhip_fm_chain_set_fused_tail");
+    SDRHIP_REQUIRE(c != nullptr && enable >= 0 && enable <= 2, "sdrhip_fm_chain_set_fused_tail");
     c->fused_tail = enable;
     return SDRHIP_OK;
 }
@@ -688,25 +580,9 @@ int sdrhip_fm_chain_set_small_chain(sdrhip_fm_chain* c, int mode, int64_t max_ou
 long long sdrhip_debug_small_chain_launches(void) { return fm_chain_small_launch_count(); }
 long long sdrhip_debug_resample_cycle_launches(void) { return resample_cycle_launch_count(); }
 long long sdrhip_debug_decimate_real16_launches(void) { return decimate_real16_launch_count(); }
-void sdrhip_debug_set_full_tiles(int on) { set_full_tiles(on); }
 void sdrhip_debug_set_systolic(int on) { set_systolic(on); }
-void sdrhip_debug_set_demod_form(int form) { set_demod_form(form); }
-int sdrhip_debug_demod_form(void) { return demod_form(); }
-void sdrhip_debug_set_resample_demod_stream(int on) { set_resample_demod_stream(on); }
-long long sdrhip_debug_resample_demod_stream_launches(void) { return resample_demod_stream_launch_count(); }
-void sdrhip_debug_resample_demod_stream_plan(int ncycles, int cus, int* ntiles, int* tiles_per_wg, int* grid) { resample_demod_stream_plan(ncycles, cus, ntiles, tiles_per_wg, grid); }
 long long sdrhip_debug_systolic_launches(void) { return systolic_launch_count(); }
-void sdrhip_debug_systolic_plan(int count, int demod, int* nstrips, int* nwhole) { systolic_plan(count, demod != 0, nstrips, nwhole); }
-long long sdrhip_debug_resample_systolic_launches(void) { return resample_systolic_launch_count(); }
-void sdrhip_debug_set_resample_systolic(int on) { set_resample_systolic(on); }
-void sdrhip_debug_resample_systolic_plan(int ncycles, long long avail_total, int* nstrips, int* nwhole) { resample_systolic_plan(ncycles, avail_total, nstrips, nwhole); }
-
-int sdrhip_fm_chain_set_decim_demod_fusion(sdrhip_fm_chain* c, int enable)
-{
-    SDRHIP_REQUIRE(c != nullptr && (enable == 0 || enable == 1), "sdrhip_fm_chain_set_decim_demod_fusion");
-    c->fuse_k2k3 = enable != 0;
-    return SDRHIP_OK;
-}
+void sdrhip_debug_systolic_plan(int count, int* nstrips, int* nwhole) { systolic_plan(count, nstrips, nwhole); }
 
 int sdrhip_fm_chain_set_demod_fusion(sdrhip_fm_chain* c, int enable)
 {

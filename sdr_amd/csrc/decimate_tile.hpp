@@ -228,9 +228,6 @@ struct Stage {
 // by 1/128 like the samples in LDS are un-scaled: the products are the reference's, see Stage::store); the window of
 // output r starts r*D samples into the thread's.  All R chains advance together (a thread's outputs usually straddle
 // together), IS taps per step so that the LDS reads and the tap load of a step are in flight at once.
-#ifndef SDRHIP_INL_STEP
-#define SDRHIP_INL_STEP 4
-#endif
 template <int D, int R, class T, int TC, bool GUARD>
 __device__ __forceinline__ void inline_cross_outputs(const float2* __restrict__ win, const float* __restrict__ taps, int plen,
                                                      const bool (&cross)[R], float2 (&res)[R])
@@ -238,7 +235,7 @@ __device__ __forceinline__ void inline_cross_outputs(const float2* __restrict__ 
     float re[R], im[R];
 #pragma unroll
     for (int r = 0; r < R; r++) re[r] = im[r] = 0.0f;
-    constexpr int IS = (TC % SDRHIP_INL_STEP == 0 || SDRHIP_INL_STEP % TC == 0) && (!GUARD || SDRHIP_INL_STEP <= TC) ? SDRHIP_INL_STEP : 4;
+    constexpr int IS = 4;
 #pragma unroll 1
     for (int j0 = 0; j0 < plen; j0 += IS) {           // plen is a multiple of TC (4 or 8)
         float2 x[R][IS];
@@ -555,14 +552,6 @@ __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const
     *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
 }
 
-// SDRHIP_FULL_TILES=0 / sdrhip_debug_set_full_tiles(0): every tile through the general instantiation (A/B measurements)
-inline std::atomic<int>& full_tiles_flag()
-{
-    static std::atomic<int> f{getenv("SDRHIP_FULL_TILES") ? atoi(getenv("SDRHIP_FULL_TILES")) : 1};
-    return f;
-}
-inline bool full_tiles_enabled() { return full_tiles_flag().load(std::memory_order_relaxed) != 0; }
-
 // inline_cross: the kernel computes the Cross outputs itself (no fix-up launch); *inlined tells whether the geometry allowed
 // it (a tile must span less than one buffer)
 template <int D, int P, int R, int NT, bool U8, int TC = ((P % 8 == 0) ? 8 : 4), bool GUARD = false, int NP = 4, int ORD = 0, int PSKIP = 0>
@@ -592,7 +581,7 @@ void launch_c4(hipStream_t s, const Geom& g, const float* taps, const void* in, 
     // Large launches without in-kernel seams: whole tiles take the FULL body inside the same launch (MIXED kernel).  A tile is
     // whole when its OUTS outputs are wanted and its SPAN samples exist: the launch's samples end at (count - 1) * D + Lp, and
     // SPAN = (OUTS - 1) * D + P reaches past that of a shorter (guarded) filter's own length, hence one tile less there.
-    if (inl_seam == 0 && g.count >= 128 * T::OUTS && full_tiles_enabled()) {
+    if (inl_seam == 0 && g.count >= 128 * T::OUTS) {
         const int nfull = g.count / T::OUTS - ((GUARD && g.Lp < P) ? 1 : 0);
         static std::atomic<bool> attr_full[64];
         auto kmixed = k_decimate_c4<D, P, R, NT, U8, TC, GUARD, NP, ORD, PSKIP, true>;

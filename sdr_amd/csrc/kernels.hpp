@@ -144,8 +144,6 @@ long long resample_cycle_launch_count();
 // kernels_chain.hip: fast paths of the low-rate stages
 void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int64_t count, bool has_prev,
                           float last_re, float last_im);
-int demod_form();                // the form the stand-alone kernel launches next
-void set_demod_form(int form);   // 0 ternaries, 1 selects, 2 common case + wave vote, 3 (default) the same with the LDS table: same bits, for tests and A/B
 // real filters (D == 1), AVX order, nk taps walked (half-taps when sym), nk % 8 == 0
 // lanes: 8 = AVX order, 4 = SSE order (the same kernel with four lane partials per output)
 bool launch_fir_real8_fast(hipStream_t s, const Geom& g, bool sym, const float* d_taps, int nk, const float* d_cross_taps,
@@ -156,25 +154,6 @@ bool launch_filter_cplx4_fast(hipStream_t s, const Geom& g, const float* d_dup_t
 // kernels_fast_filter.hip: complex filters of exactly 128 / 64 taps (AVX "RC" order, plain taps) on the tiled decimator with D = 1
 bool launch_filter_c4_tile(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps, const float* d_in,
                            float* d_out);
-// kernels_resample_systolic.hip (round 4): the whole cycles of a 3/10 launch (three 64-float groups, increments {4,3,3}, AVX order) by a
-// register-resident systolic walk; cycle c starts at d_in[pos + 10c] and yields d_out[3c .. 3c + 2].  false = not taken.
-bool launch_resample3_systolic(hipStream_t s, const float* d_in, int64_t pos, int ncycles, int64_t avail_total, const float* d_groups,
-                               int row_stride, float* d_out);
-void resample_systolic_plan(int ncycles, int64_t avail_total, int* nstrips, int* nwhole);
-long long resample_systolic_launch_count();
-void set_resample_systolic(int on);     // default 0: measured no faster than the tile kernel
-// kernels_resample_stream.hip (round 5): fmDemod + the whole cycles of a 3/10 launch as a streaming kernel (a workgroup walks a run of
-// tiles, the next tile's complex samples in flight behind the current tile's arithmetic).  d_iq: decimator output, sample 0 = input 0 of
-// the launch (y_count of them; d_iq[-2..-1] exists when iq_has_prev); cycle c starts at input pos + 10 c; d_y receives the phases
-// other kernels still read (within ykeep of a multiple of yseam in absolute position y_abs0 + n, and the first / last nedge).
-// false = switched off or too short a run, nothing launched.
-bool launch_resample3_demod_stream(hipStream_t s, const float* d_iq, int64_t pos, int ncycles, bool iq_has_prev, int64_t y_count,
-                                   const float* d_groups, int row_stride, float* d_out, float* d_y, int64_t y_abs0, int yseam, int ykeep,
-                                   int nedge);
-void set_resample_demod_stream(int on);   // 0 (default) off, 1 runs long enough to stream, 2 every run it can take, n > 2 every run cut for n workgroups
-int resample_demod_stream_mode();
-long long resample_demod_stream_launch_count();
-void resample_demod_stream_plan(int ncycles, int cus, int* ntiles, int* tiles_per_wg, int* grid);
 // kernels_cplx.hip: the same shape on complex data ("RC2" orders of resampleAVXRC / resampleSSERC)
 bool launch_resample3c_fast(hipStream_t s, const Geom& g, ComplexOrder order, const ResampTable& t, const int* increments, const float* d_groups,
                             const float* d_plain_taps, const float* d_in, float* d_out);
@@ -190,7 +169,7 @@ constexpr int kTailTileOutputs = 2046;   // audio outputs one workgroup of the f
 bool launch_fm_tail_fused(hipStream_t s, const float* d_d, int64_t kd0, int64_t kd1, int64_t ky0, int64_t ky1, float* d_audio,
                           int64_t q0, int64_t q1, const float* d_groups, int row_stride, int nloop, const int* increments,
                           int ngroups, int I, int D, int rLp, const float* d_rplain, int ntaps, const float* d_fhalf, int nhalf,
-                          const float* d_fplain, float gain, int64_t seam, const float* d_y = nullptr);
+                          const float* d_fplain, float gain, int64_t seam);
 // kernels_small.hip: the WHOLE chain (u8 IQ -> /8 decimator -> fmDemod -> 3/10 resampler -> symmetric filter * gain) as one
 // kernel for launch-bound runs; d_in holds samples [s0, s0 + n_in).  tile_outputs: audio outputs per workgroup (0 = chosen
 // from the size of the run).  false = the configuration is not the FM chain's, nothing launched
@@ -209,14 +188,9 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
 // walk (d_taps: plain taps, pre-scaled by 1/128 for u8 input).  false = not this shape / too small, nothing launched.
 bool launch_decimate_c4_systolic(hipStream_t s, const Geom& g, const float* d_taps, int P, const void* d_in, bool in_is_u8, float* d_out,
                                  bool last_tap_zero);
-// the FM chain's K2 + K3 in one launch: decimator outputs [kd0, kd1) demodulated in place, y[k] for k in [ky0, kd1) stored at d_y[k - ky0]
-bool launch_decimate_demod_systolic(hipStream_t s, const uint8_t* d_in, int64_t in_base, int64_t kd0, int64_t kd1, int64_t ky0,
-                                    const float* d_scaled_taps, const float* d_plain_taps, int P, bool last_tap_zero, int64_t seam_block,
-                                    float* d_y);
-void systolic_plan(int count, bool demod, int* nstrips, int* nwhole);   // host arithmetic of the strip cut (CPU-testable)
-void set_systolic(int on);          // A/B switch (SDRHIP_SYSTOLIC=0: the tile kernel everywhere)
+void systolic_plan(int count, int* nstrips, int* nwhole);   // host arithmetic of the strip cut (CPU-testable)
+void set_systolic(int mode);        // 0 = the tile kernel everywhere, 1 = the systolic kernel wherever its shape fits, 2 (default) = by launch size
 long long systolic_launch_count();  // diagnostics
-void set_full_tiles(int on);   // A/B switch of the FULL-tile instantiations of the AVX-order tiled decimator (decimate_tile.hpp)
 // kernels_fast_orders.hip: the same tiled decimator for the SSE "RC" and the "RC2" summation orders (CO_L2, CO_X4, CO_X2)
 bool launch_decimate_c_orders_fast(hipStream_t s, const Geom& g, ComplexOrder order, const float* d_plain_taps, int P,
                                    const float* d_cross_taps, const void* d_in, bool in_is_u8, float* d_out);

@@ -326,16 +326,14 @@ bool launch_decimate_real16_fast(hipStream_t s, const Geom& g, int lanes, const 
                                  float* d_out, float gain, bool apply_gain, int ncross, bool sym)
 {
     if (ncross <= 0) ncross = g.Lp;              // taps the sequential (Cross) outputs walk: a resampler's are the unpadded ones
-    static const bool off = getenv("SDRHIP_DECIM_REAL16") != nullptr && atoi(getenv("SDRHIP_DECIM_REAL16")) == 0;     // A/B: the split kernel
-    if (off || g.I != 1 || g.seamBI < 0 || g.count < 4096) return false;
+    if (g.I != 1 || g.seamBI < 0 || g.count < 4096) return false;
     if (!(lanes == 8 || lanes == 4) || nk < 8 || nk > 2048) return false;
     if (sym ? (nk % 8 != 0 || 2 * nk != g.Lp) : (nk % lanes != 0 || nk != g.Lp)) return false;     // sym: nk = half-taps
     if (g.seamBI != 0 && d_cross_taps == nullptr) return false;
     bool took = false;
-    static const int ring_env = getenv("SDRHIP_DR_RING") ? atoi(getenv("SDRHIP_DR_RING")) : -1;                     // A/B: -1 = the default per shape
 #define DR(DV, RDEF)                                                                                               \
     if (g.D == DV) {                                                                                               \
-        const bool ring = ring_env < 0 ? RDEF : ring_env != 0;                                                     \
+        const bool ring = RDEF;                                                                                     \
         if (lanes == 8) took = ring ? launch_dr<DV, 8, true>(s, g, d_taps, nk, d_in, d_out, gain, apply_gain)       \
                                     : launch_dr<DV, 8, false>(s, g, d_taps, nk, d_in, d_out, gain, apply_gain);     \
         else took = ring ? launch_dr<DV, 4, true>(s, g, d_taps, nk, d_in, d_out, gain, apply_gain)                  \

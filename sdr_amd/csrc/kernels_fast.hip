@@ -26,8 +26,6 @@
 
 namespace sdrhip {
 
-void set_full_tiles(int on) { full_tiles_flag().store(on); }
-
 bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_taps, int P, const float* d_cross_taps,
                              const void* d_in, bool in_is_u8, float* d_out, bool last_tap_zero)
 {
@@ -52,9 +50,7 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
     // Launch-bound sizes (a host block per push .. a 2^20-sample shard) compute their Cross outputs inside the tile kernel:
     // one launch instead of two (abi_device.cpp: the 5v row).  At full size that loses to the fix-up launch (0.87-1.0 ms
     // against 0.71 per 2^29 samples: the straddlers' sequential loops hold whole workgroups' resources).
-    // SDRHIP_INLINE_CROSS_MAX overrides the bound for experiments.
-    static const int64_t inl_env = getenv("SDRHIP_INLINE_CROSS_MAX") ? atoll(getenv("SDRHIP_INLINE_CROSS_MAX")) : -1;
-    const int64_t inl_max = inl_env >= 0 ? inl_env : 5 * (int64_t)small_launch_outputs();
+    const int64_t inl_max = 5 * (int64_t)small_launch_outputs();
     const bool inl = g.seamBI > 0 && g.count <= inl_max;
     bool inlined = false;
     // R = 2 outputs per thread, 256 threads, 4 workgroups per CU.  Alternatives measured on MI355X and dropped:

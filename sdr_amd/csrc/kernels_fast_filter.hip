@@ -67,8 +67,6 @@ bool launch_filter_c4_tile(hipStream_t s, const Geom& g, const float* d_plain_ta
     const int64_t x0 = g.k_begin - g.in_base;
     if (((reinterpret_cast<uintptr_t>(d_in) + 8 * (uintptr_t)x0) & 15) != 0) return false;      // 16-byte aligned tile starts
     if ((reinterpret_cast<uintptr_t>(d_out) & 15) != 0) return false;
-    static const bool off = getenv("SDRHIP_FILTER_TILE") != nullptr && atoi(getenv("SDRHIP_FILTER_TILE")) == 0;     // A/B: the rolled kernel
-    if (off) return false;
     if (P == 128) launch_c4<1, 128, 4, 256, false>(s, g, d_plain_taps, d_in, d_out);
     else launch_c4<1, 64, 4, 256, false>(s, g, d_plain_taps, d_in, d_out);
     if (g.seamBI != 0) {

@@ -199,19 +199,11 @@ constexpr int DC_RUN_IN = 12288;   // samples of run-in: 0.997^12288 ~ 1e-16 of 
 constexpr int DC_REPAIR_ROUNDS = 3;
 // Every lane walks run-in + chunk samples at the latency of the dependent f64 chain, so the time is ~(C + W) steps whatever
 // the lane count; more lanes than this only add redundant run-in traffic (measured: 2^18 lanes thrash the L2 at n = 2^26).
-int64_t dc_max_lanes()
-{
-    static const int64_t v = [] {
-        const char* e = getenv("SDRHIP_DC_MAX_LANES");
-        const long x = e ? atol(e) : 0;
-        return (int64_t)(x >= 64 ? x : 32768);
-    }();
-    return v;
-}
+constexpr int64_t kDcMaxLanes = 32768;
 struct DcPlan { int C; int nchunks; };
 DcPlan dc_plan(int64_t num)
 {
-    const int64_t lanes = dc_max_lanes();
+    const int64_t lanes = kDcMaxLanes;
     int64_t C = (num + lanes - 1) / lanes;
     if (C < 256) C = 256;
     C = (C + 3) & ~(int64_t)3;

@@ -239,8 +239,7 @@ bool launch_resample_cycle_fast(hipStream_t s, const Geom& g, int lanes, const R
         lanes = corder == CO_X4 ? 8 : 4;
     }
     const int es = cplx ? 2 : 1;
-    static const bool off = getenv("SDRHIP_RESAMP_CYCLE") != nullptr && atoi(getenv("SDRHIP_RESAMP_CYCLE")) == 0;     // A/B: the split kernel
-    if (off || t.force_seq || t.ext != nullptr || g.seamBI < 0 || g.count < 4096) return false;
+    if (t.force_seq || t.ext != nullptr || g.seamBI < 0 || g.count < 4096) return false;
     if (!(lanes == 8 || lanes == 4) || t.ngroups != g.I || t.nloop < 8 || t.nloop % lanes != 0 || t.nloop > 1024) return false;
     if (g.seamBI != 0 && d_plain_taps == nullptr) return false;
     const int I = g.I, D = g.D;

@@ -55,13 +55,6 @@ struct SmallParams {
     int64_t seam;            // block size B of every Pipe (0 = contiguous stream)
 };
 
-#ifdef SDRHIP_SMALL_PROBE
-// development probe (tools/k2lab/small_lab.hip): shader-clock cycles each phase takes, summed over the probed workgroups
-struct SmallProbe { unsigned long long cyc[6], rt, n; };
-#define SM_PROBE_MARK(i) do { if (pr != nullptr && threadIdx.x == 0 && (blockIdx.x & 7) == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); if (i > 0) atomicAdd(&pr->cyc[i - 1], t_ - tprev_); tprev_ = t_; } } while (0)
-#else
-#define SM_PROBE_MARK(i) do { } while (0)
-#endif
 
 // The reference's horizontal add of 8 lane partials, ((a0+a1)+(a2+a3))+((a4+a5)+(a6+a7)) (common.h:18-29), over the 8 lanes
 // of a group as DPP operands of three adds: xor-1, xor-2 partners (quad_perm), then lane l + 4 (row_shl:4).  IEEE addition
@@ -192,16 +185,8 @@ __global__ void __launch_bounds__(SM_NT, 2) k_fm_chain_small(const uint8_t* __re
                                                              const float* __restrict__ dtaps, const float* __restrict__ groups,
                                                              const float* __restrict__ rplain, const float* __restrict__ fplain,
                                                              SmallParams p
-#ifdef SDRHIP_SMALL_PROBE
-                                                             , SmallProbe* pr
-#endif
 )
 {
-#ifdef SDRHIP_SMALL_PROBE
-    unsigned long long tprev_ = 0;
-    const unsigned long long rt0_ = wall_clock64();
-#endif
-    SM_PROBE_MARK(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
     __shared__ __attribute__((aligned(16))) float gtab[3 * SM_NL];   // the three polyphase groups
@@ -270,7 +255,6 @@ __global__ void __launch_bounds__(SM_NT, 2) k_fm_chain_small(const uint8_t* __re
         else if (tid < SM_LF + 128) dtl[tid - SM_LF] = t_f;
     }
     __syncthreads();
-    SM_PROBE_MARK(1);
 
     // ---- phase 1: decimator outputs k = kb + 2 tid + {0, 1}.  Waves whose outputs no y of the tile reads skip the MACs.
     float2 res[2] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
@@ -327,7 +311,6 @@ __global__ void __launch_bounds__(SM_NT, 2) k_fm_chain_small(const uint8_t* __re
         }
     }
     __syncthreads();                                                  // every read of the input tile is done: reuse its space
-    SM_PROBE_MARK(2);
     float2* dl = lds;                                                 // d of the tile, SM_KD float2
     float* ys = reinterpret_cast<float*>(dl + SM_KD);                 // y[j] <-> k = y0 + j, SM_KD floats
     float* zs = ys + SM_KD + 16;                                      // z[i] <-> m = 3 c0 + i, 3 NC floats
@@ -354,7 +337,6 @@ __global__ void __launch_bounds__(SM_NT, 2) k_fm_chain_small(const uint8_t* __re
         }
     }
     __syncthreads();
-    SM_PROBE_MARK(3);
 
     // ---- phase 3: polyphase resampler.  z[3 cl + g] = sum_j groups[g][j] * y[10 cl + pre[g] + j] with lane partial j & 7
     // accumulated from +0 in increasing j and the tree ((a0+a1)+(a2+a3))+((a4+a5)+(a6+a7)) (resample.c:70-87, common.h:18-29).
@@ -424,7 +406,6 @@ __global__ void __launch_bounds__(SM_NT, 2) k_fm_chain_small(const uint8_t* __re
         }
     }
     __syncthreads();
-    SM_PROBE_MARK(4);
 
     // ---- phase 4: symmetric audio filter + gain: pair-add first, lane partial k & 7 from +0 in increasing k, tree
     // (filter.c:60-68, common.h:181-201); fm.hs:40's `* gain` as a separate multiply of the rounded output.  8 lanes per
@@ -474,15 +455,8 @@ __global__ void __launch_bounds__(SM_NT, 2) k_fm_chain_small(const uint8_t* __re
         }
         if (is_cross) audio[qa + o_lo + tid - p.q0] = seq_c * p.gain;
     }
-    SM_PROBE_MARK(5);
-#ifdef SDRHIP_SMALL_PROBE
-    if (pr != nullptr && threadIdx.x == 0 && (blockIdx.x & 7) == 0) { atomicAdd(&pr->rt, wall_clock64() - rt0_); atomicAdd(&pr->n, 1ull); }
-#endif
 }
 
-#ifdef SDRHIP_SMALL_PROBE
-SmallProbe* g_small_probe = nullptr;
-#endif
 
 std::atomic<long long> g_small_launches{0};
 
@@ -531,12 +505,7 @@ bool launch_fm_chain_small(hipStream_t s, const uint8_t* d_in, int64_t s0, int64
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SmT::LDS_BYTES);
             if (dev >= 0 && dev < 64) attr_set[which][dev] = true;
         }
-#ifdef SDRHIP_SMALL_PROBE
-        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(SM_NT), SmT::LDS_BYTES, s, d_in, d_audio, d_dscaled, d_groups, d_rplain, d_fplain, p,
-                           g_small_probe);
-#else
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(SM_NT), SmT::LDS_BYTES, s, d_in, d_audio, d_dscaled, d_groups, d_rplain, d_fplain, p);
-#endif
     };
     if (last_tap_zero) launch(k_fm_chain_small<1>, 1);
     else launch(k_fm_chain_small<0>, 0);

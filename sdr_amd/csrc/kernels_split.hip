@@ -24,17 +24,10 @@
 #include "crossfix.hpp"
 #include "kernels.hpp"
 
-// Tuning knobs (build with SDRHIP_SPLIT_DEFS="-DSPLIT_CB=2 ..." to experiment; DESIGN.md lists what was measured):
-// chunks per guarded block, input-span bytes per tile, outputs per lane.
-#ifndef SPLIT_CB
-#define SPLIT_CB 4
-#endif
-#ifndef SPLIT_SPAN_BYTES
-#define SPLIT_SPAN_BYTES 32768
-#endif
-#ifndef SPLIT_U
-#define SPLIT_U 2
-#endif
+// Tile shape (measured alternatives: LABNOTES): chunks per guarded block, input-span bytes per tile, outputs per lane.
+constexpr int SPLIT_CB = 4;
+constexpr int SPLIT_SPAN_BYTES = 32768;
+constexpr int SPLIT_U = 2;
 
 namespace sdrhip {
 
@@ -244,15 +237,6 @@ __global__ void __launch_bounds__(256) k_split(SplitArgs a)
     }
 }
 
-bool split_enabled()
-{
-    static const bool on = [] {
-        const char* e = getenv("SDRHIP_NO_SPLIT");
-        return !(e && e[0] == '1');
-    }();
-    return on;
-}
-
 // Tile geometry: as many cycles as fit a 32 KiB input span (64 KiB when a large decimation factor needs it) and 1024
 // outputs, in whole runs of U groups of G = 64/M outputs (U = 2 independent accumulator chains per lane -- 4 and 8 measured no better -- when the tile is
 // big enough, else 1).
@@ -370,7 +354,7 @@ long long split_launch_count() { return g_split_launches.load(); }
 bool launch_fir_split(hipStream_t s, const Geom& g, bool cplx, int lanes, ComplexOrder corder, bool sym, const float* d_taps,
                       int ntaps, const float* d_cross_taps, const float* d_in, float* d_out, float gain, bool apply_gain)
 {
-    if (!split_enabled() || g.I != 1 || g.count < SPLIT_MIN_OUTPUTS || g.seamBI < 0) return false;
+    if (g.I != 1 || g.count < SPLIT_MIN_OUTPUTS || g.seamBI < 0) return false;
     if (g.seamBI != 0 && d_cross_taps == nullptr) return false;
     OrderInfo o;
     if (!(cplx ? cplx_order(corder, o) : real_order(lanes, o))) return false;
@@ -418,7 +402,7 @@ bool launch_fir_split(hipStream_t s, const Geom& g, bool cplx, int lanes, Comple
 bool launch_resample_split(hipStream_t s, const Geom& g, bool cplx, int lanes, ComplexOrder corder, const ResampTable& t,
                            const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out)
 {
-    if (!split_enabled() || g.count < SPLIT_MIN_OUTPUTS || g.seamBI < 0 || t.force_seq || t.ext != nullptr) return false;
+    if (g.count < SPLIT_MIN_OUTPUTS || g.seamBI < 0 || t.force_seq || t.ext != nullptr) return false;
     if (g.seamBI != 0 && d_plain_taps == nullptr) return false;
     OrderInfo o;
     if (!(cplx ? cplx_order(corder, o) : real_order(lanes, o))) return false;

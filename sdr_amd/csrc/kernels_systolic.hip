@@ -34,12 +34,7 @@
 #include <type_traits>
 #include <utility>
 
-#include "demod.hpp"
 #include "kernels.hpp"
-
-#ifndef SDRHIP_SYSTOLIC_ROTCOST
-#define SDRHIP_SYSTOLIC_ROTCOST 0
-#endif
 
 namespace sdrhip {
 namespace {
@@ -90,7 +85,7 @@ constexpr int kCfRow = 36;
 constexpr int kCfWaveDw = 64 * kCfRow;
 
 // `avail`: samples that exist from the strip's first one on (>= kStripSpan for a whole strip); beyond them zeros (u8: 128)
-template <bool U8, bool WHOLE>
+template <bool U8, bool WHOLE, bool NTL>
 __device__ __forceinline__ void load_strip(const void* __restrict__ in, int64_t strip_s0, int64_t avail, float* __restrict__ wbuf, int lane, f2 (&S)[32])
 {
     if constexpr (U8) {
@@ -129,8 +124,12 @@ __device__ __forceinline__ void load_strip(const void* __restrict__ in, int64_t 
                     // non-temporal: every byte is read once (bar the 6 % strip overlap): 226 -> 221 us per 2^27 samples, and the
                     // copy-only stream of this shape gains 15 % from the same hint
                     typedef float f4v __attribute__((ext_vector_type(4)));
-                    const f4v t4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
-                    v[j] = make_float4(t4.x, t4.y, t4.z, t4.w);
+                    if constexpr (NTL) {
+                        const f4v t4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+                        v[j] = make_float4(t4.x, t4.y, t4.z, t4.w);
+                    } else {
+                        v[j] = *reinterpret_cast<const float4*>(p);
+                    }
                 } else {
                     v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (s < avail) { v[j].x = p[0]; v[j].y = p[1]; }
@@ -150,23 +149,17 @@ __device__ __forceinline__ void load_strip(const void* __restrict__ in, int64_t 
 
 // PSKIP: the last PSKIP taps are the zero padding (Filter.hs:146-148) and every sample is finite (u8 input): their MACs are
 // skipped -- exact, see decimate_tile.hpp:mac_window.
-// DEMOD (round 4, K2 + K3 in one kernel): the decimator's outputs never reach HBM -- the lane that holds outputs o .. o+3 demodulates
-// them in place (fmDemod, Demod.hs:21-46: y[k] = phase(d[k] * conj(d[k-1])); output o's predecessor comes from the lane below by one
-// more DPP) and stores y.  Strips then advance by 239 outputs: the first output of a strip is only the predecessor of the
-// second (the previous strip stores its y), exactly the role decimator output kd0 = ky0 - 1 plays for a whole launch.
-// `count` = decimator outputs of the launch, `yshift` = 1 when output 0 is such a predecessor (else y[0] = phase(d[0] * conj(0)),
-// the stream's very first sample, Demod.hs:41).
-template <bool U8, int PSKIP, bool WHOLE, bool DEMOD>
+// (Round 4 also built fmDemod into this kernel's epilogue -- K2 + K3 in one launch, the decimated stream never written -- bit-equal and
+// slower: the pair 0.91 ms against 0.69 + 0.16.  tools/lab_variants/decimate_demod_systolic.hip, LABNOTES.)
+template <bool U8, int PSKIP, bool WHOLE, bool NTL>
 __device__ __forceinline__ void systolic_strip(const void* __restrict__ in, int64_t x0, int strip, int count, const float* __restrict__ taps,
-                                               float* __restrict__ out, float* __restrict__ wbuf, int lane, int yshift)
+                                               float* __restrict__ out, float* __restrict__ wbuf, int lane)
 {
-    constexpr int kOuts = DEMOD ? kStripOuts - 1 : kStripOuts;      // outputs a strip advances by
-    constexpr int kStep = 8 * kOuts;
     f2 S[32];
-    const int64_t strip_s0 = x0 + (int64_t)kStep * strip;
+    const int64_t strip_s0 = x0 + (int64_t)kStripStep * strip;
     // samples of the launch: (count - 1) * 8 + 128 from x0 on
-    const int64_t avail = WHOLE ? kStripSpan : ((int64_t)(count - 1) * 8 + 128) - (int64_t)kStep * strip;
-    load_strip<U8, WHOLE>(in, strip_s0, avail, wbuf, lane, S);
+    const int64_t avail = WHOLE ? kStripSpan : ((int64_t)(count - 1) * 8 + 128) - (int64_t)kStripStep * strip;
+    load_strip<U8, WHOLE, NTL>(in, strip_s0, avail, wbuf, lane, S);
 
     f2 acc[4][4];
     f8 tc[16];
@@ -187,17 +180,6 @@ __device__ __forceinline__ void systolic_strip(const void* __restrict__ in, int6
                 if (b == 0 && r < 4) {
                     acc[i][k] = f2{0.f, 0.f} + p;                  // the first addition of the partial: +0 + product
                 } else if (t > 0 && c == 0 && r < 4) {
-#if SDRHIP_SYSTOLIC_ROTCOST
-                    // MEASUREMENT ONLY (LABNOTES round 5, VERDICT r04 "next" 4): what a rotating walk would have to add -- the partial sums
-                    // that leave lane 63 entering lane 0 of the next strip -- costs at least one lane-0 patch per value and stage boundary:
-                    // a v_mov_b32_dpp wave_ror:1 of the value (here of the accumulator itself; the result is thrown away, the
-                    // instruction is not)
-                    {
-                        float rx, ry;
-                        asm volatile("v_mov_b32_dpp %0, %2 wave_ror:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %3 wave_ror:1 row_mask:0xf bank_mask:0xf"
-                                     : "=&v"(rx), "=&v"(ry) : "v"(acc[i][k].x), "v"(acc[i][k].y));
-                    }
-#endif
                     acc[i][k] = f2{dpp_shr1(acc[i][k].x) + p.x, dpp_shr1(acc[i][k].y) + p.y};   // the group enters the stage one lane up
                 } else {
                     acc[i][k] = acc[i][k] + p;
@@ -218,50 +200,24 @@ __device__ __forceinline__ void systolic_strip(const void* __restrict__ in, int6
 #pragma unroll
     for (int i = 0; i < 4; i++) res[i] = (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
     res[0] = f2{dpp_shr1(res[0].x), dpp_shr1(res[0].y)};           // output 0 of the group sat one lane below
-    if constexpr (!DEMOD) {
-        if (lane >= 4) {
-            const int o = kStripOuts * strip + 4 * (lane - 4);
-            if (WHOLE || o + 4 <= count) {
-                float4* dst = reinterpret_cast<float4*>(out + 2 * (int64_t)o);
-                dst[0] = make_float4(res[0].x, res[0].y, res[1].x, res[1].y);
-                dst[1] = make_float4(res[2].x, res[2].y, res[3].x, res[3].y);
-            } else {
+    if (lane >= 4) {
+        const int o = kStripOuts * strip + 4 * (lane - 4);
+        if (WHOLE || o + 4 <= count) {
+            float4* dst = reinterpret_cast<float4*>(out + 2 * (int64_t)o);
+            dst[0] = make_float4(res[0].x, res[0].y, res[1].x, res[1].y);
+            dst[1] = make_float4(res[2].x, res[2].y, res[3].x, res[3].y);
+        } else {
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (o + i < count) *reinterpret_cast<float2*>(out + 2 * (int64_t)(o + i)) = make_float2(res[i].x, res[i].y);
-            }
-        }
-    } else {
-        // the predecessor of the lane's first output: the last output of the lane below (lane 4: of the previous strip -- not here)
-        const f2 below = f2{dpp_shr1(res[3].x), dpp_shr1(res[3].y)};
-        if (lane >= 4) {
-            const int o = 4 * (lane - 4);                          // strip-local output of res[0]
-            const int j = kOuts * strip + o;                       // launch-local decimator output
-            const bool first_of_stream = strip == 0 && o == 0 && yshift == 0;
-            const f2 p0 = first_of_stream ? f2{0.f, 0.f} : below;
-            float y[4];
-            y[0] = fm_phase_sel(make_float2(res[0].x, res[0].y), make_float2(p0.x, p0.y));
-#pragma unroll
-            for (int i = 1; i < 4; i++) y[i] = fm_phase_sel(make_float2(res[i].x, res[i].y), make_float2(res[i - 1].x, res[i - 1].y));
-            float* dst = out + ((int64_t)j - yshift);              // y of output j
-            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-            if (o > 0 && (WHOLE || j + 4 <= count)) {
-                *reinterpret_cast<f4u*>(dst) = f4u{y[0], y[1], y[2], y[3]};      // 4-byte aligned 16-byte store
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const bool mine = (o + i > 0) || first_of_stream;           // a strip's output 0 belongs to the previous strip
-                    if (mine && j + i < count) dst[i] = y[i];
-                }
-            }
+            for (int i = 0; i < 4; i++)
+                if (o + i < count) *reinterpret_cast<float2*>(out + 2 * (int64_t)(o + i)) = make_float2(res[i].x, res[i].y);
         }
     }
 }
 
-template <bool U8, int PSKIP, bool DEMOD = false>
+template <bool U8, int PSKIP, bool NTL = true>
 __global__ void __launch_bounds__(64 * kWavesPerWg, 4) k_decimate_systolic(const void* __restrict__ in, int64_t x0 /* sample of output 0's window in `in` */,
                                                                           int count, const float* __restrict__ taps, float* __restrict__ out,
-                                                                          int nwhole /* strips [0, nwhole) are whole */, int nstrips, int yshift)
+                                                                          int nwhole /* strips [0, nwhole) are whole */, int nstrips)
 {
     __shared__ __attribute__((aligned(16))) float tbuf[U8 ? 4 : kWavesPerWg * kCfWaveDw];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -272,95 +228,13 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, 4) k_decimate_systolic(const
     const int strip = wg * kWavesPerWg + wave;
     if (strip >= nstrips) return;
     float* wbuf = tbuf + (U8 ? 0 : kCfWaveDw * wave);
-    if (strip < nwhole) systolic_strip<U8, PSKIP, true, DEMOD>(in, x0, strip, count, taps, out, wbuf, lane, yshift);
-    else systolic_strip<U8, PSKIP, false, DEMOD>(in, x0, strip, count, taps, out, wbuf, lane, yshift);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Seams of the fused decimate + fmDemod launch.  At a buffer boundary E (a multiple of the reference's block) the 15 decimator outputs
-// whose windows straddle E are computed by the reference in sequential order (decimateCrossHighLevel, FilterInternal.hs:397-402); they
-// change 16 demodulated outputs, y[E/8 - 15 .. E/8].  One group of 32 threads per seam: the 256 samples around E are staged once (one
-// 16-byte load per thread), threads 0..16 compute d[E/8 - 16 .. E/8] -- the two ends in the SIMD order (they are ordinary One outputs,
-// needed as neighbours), the 15 in between sequentially -- and threads 0..15 demodulate and overwrite the 16 y.
-constexpr int kFixSeamsPerWg = 8;
-constexpr int kFixRow = 256 + 256 / 8;      // one float2 of padding after every 8 samples
-__global__ void __launch_bounds__(32 * kFixSeamsPerWg) k_decimate_demod_crossfix(const uint8_t* __restrict__ in, int64_t in_base, int64_t kd0, int count,
-                                                                                int yshift, const float* __restrict__ xtaps, float* __restrict__ y,
-                                                                                int64_t first_seam, int nseams, int64_t seam)
-{
-    __shared__ float2 rows[kFixSeamsPerWg][kFixRow];
-    __shared__ float2 dd[kFixSeamsPerWg][17];
-    const int g = threadIdx.x >> 5, t = threadIdx.x & 31;
-    const int si = blockIdx.x * kFixSeamsPerWg + g;
-    const bool live = si < nseams;
-    const int64_t E = (first_seam + si) * seam;                                 // global sample index of the boundary
-    const int64_t lo = kd0 * 8, hi = (kd0 + count - 1) * 8 + 128;               // samples the launch may read
-    if (live) {
-        const int64_t s_first = E - 128 + 8 * t;                                // this thread's 8 samples
-        float2 smp[8];
-        if (s_first >= lo && s_first + 8 <= hi) {
-            const uint4 q = *reinterpret_cast<const uint4*>(in + 2 * (s_first - in_base));
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                smp[2 * k] = make_float2(((float)(w[k] & 0xff) - 128.0f) * (1.0f / 128.0f), ((float)((w[k] >> 8) & 0xff) - 128.0f) * (1.0f / 128.0f));
-                smp[2 * k + 1] = make_float2(((float)((w[k] >> 16) & 0xff) - 128.0f) * (1.0f / 128.0f), ((float)(w[k] >> 24) - 128.0f) * (1.0f / 128.0f));
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int64_t sk = s_first + k;
-                smp[k] = make_float2(0.f, 0.f);
-                if (sk >= lo && sk < hi) {
-                    const uchar2 u = *reinterpret_cast<const uchar2*>(in + 2 * (sk - in_base));
-                    smp[k] = make_float2(((float)u.x - 128.0f) * (1.0f / 128.0f), ((float)u.y - 128.0f) * (1.0f / 128.0f));
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) rows[g][9 * t + k] = smp[k];                 // sample 8t + k sits at 8t + k + t
-    }
-    __syncthreads();
-    if (live && t < 17) {
-        const float2* w = &rows[g][9 * t];                                      // window of candidate m = E/8 - 16 + t starts at sample 8t
-        float2 r;
-        if (t == 0 || t == 16) {
-            float2 L[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
-#pragma unroll 4
-            for (int j = 0; j < 128; j++) {
-                const float2 x = w[j + j / 8];
-                const float h = xtaps[j];
-                L[j & 3].x = L[j & 3].x + x.x * h;
-                L[j & 3].y = L[j & 3].y + x.y * h;
-            }
-            r = make_float2((L[0].x + L[1].x) + (L[2].x + L[3].x), (L[0].y + L[1].y) + (L[2].y + L[3].y));
-        } else {
-            float re = 0.0f, im = 0.0f;
-#pragma unroll 4
-            for (int j = 0; j < 128; j++) {
-                const float2 x = w[j + j / 8];
-                const float h = xtaps[j];
-                re = re + x.x * h;
-                im = im + x.y * h;
-            }
-            r = make_float2(re, im);
-        }
-        dd[g][t] = r;
-    }
-    __syncthreads();
-    if (live && t < 16) {
-        const int64_t k = E / 8 - 15 + t;                                       // y[k] = phase(d[k] conj d[k-1])
-        const int64_t j = k - kd0;
-        if (j >= 0 && j < count && (j > 0 || yshift == 0)) {
-            const float2 prev = j > 0 ? dd[g][t] : make_float2(0.f, 0.f);
-            y[j - yshift] = fm_phase_sel(dd[g][t + 1], prev);
-        }
-    }
+    if (strip < nwhole) systolic_strip<U8, PSKIP, true, NTL>(in, x0, strip, count, taps, out, wbuf, lane);
+    else systolic_strip<U8, PSKIP, false, NTL>(in, x0, strip, count, taps, out, wbuf, lane);
 }
 
 std::atomic<int>& systolic_flag()
 {
-    static std::atomic<int> f{getenv("SDRHIP_SYSTOLIC") ? atoi(getenv("SDRHIP_SYSTOLIC")) : 1};
+    static std::atomic<int> f{getenv("SDRHIP_SYSTOLIC") ? atoi(getenv("SDRHIP_SYSTOLIC")) : 2};
     return f;
 }
 std::atomic<long long> g_systolic_launches{0};
@@ -368,84 +242,54 @@ std::atomic<long long> g_systolic_launches{0};
 }  // namespace
 
 // How a launch of `count` outputs is cut into wave-strips (host arithmetic, testable without a GPU: sdrhip_debug_systolic_plan).
-// plain: strip t covers outputs 240 t .. 240 t + 239 and reads samples 1920 t .. 1920 t + 2047; demod: strips advance by 239
-// outputs (strip t covers 239 t .. 239 t + 239, its first output being only a predecessor).  Strips [0, nwhole) have all their
+// Strip t covers outputs 240 t .. 240 t + 239 and reads samples 1920 t .. 1920 t + 2047.  Strips [0, nwhole) have all their
 // outputs wanted and all their samples inside the launch's (count - 1) * 8 + 128.
-void systolic_plan(int count, bool demod, int* nstrips, int* nwhole)
+void systolic_plan(int count, int* nstrips, int* nwhole)
 {
-    if (demod) {
-        constexpr int kOuts = kStripOuts - 1;
-        *nstrips = count > 1 ? (count - 1 + kOuts - 1) / kOuts : 1;
-        *nwhole = count >= kStripOuts + 1 ? (count - 1 - kStripOuts) / kOuts + 1 : 0;
-    } else {
-        *nstrips = (count + kStripOuts - 1) / kStripOuts;
-        int w = count / kStripOuts;
-        while (w > 0 && (int64_t)kStripStep * (w - 1) + kStripSpan > (int64_t)(count - 1) * 8 + 128) w--;
-        *nwhole = w;
-    }
+    *nstrips = (count + kStripOuts - 1) / kStripOuts;
+    int w = count / kStripOuts;
+    while (w > 0 && (int64_t)kStripStep * (w - 1) + kStripSpan > (int64_t)(count - 1) * 8 + 128) w--;
+    *nwhole = w;
 }
 
-void set_systolic(int on) { systolic_flag().store(on); }
+void set_systolic(int mode) { systolic_flag().store(mode); }
 long long systolic_launch_count() { return g_systolic_launches.load(); }
 
 // The SIMD ("One") outputs of a decimate-by-8, 128-tap, AVX-order launch.  False = not this kernel's shape or too small to be
 // worth it (the tile kernel computes its Cross outputs in place for launch-bound sizes); the caller then takes the tile kernel.
+//
+// cfloat input, plain or non-temporal loads (round 6, tools/route_sweep_fine.py; profiles/r06/route_sweep_fine*.txt): the launch reads
+// 64 B per output.  Between ~64 MB and ~285 MB the input of a back-to-back caller -- or of a pipeline whose producer has just written
+// it -- sits in the 256 MB Infinity Cache: plain loads are served from there (B = 2048 blocks: 33.8 us against 41.2 with
+// non-temporal loads and 39.0 for the tile kernel), a non-temporal load of a cached line is the slow case.  Past that size the
+// stream comes from HBM whatever the hint says and the non-temporal form wins by 2-4 % (it does not evict the taps and the outputs'
+// lines); below it both forms are within noise of each other and of launch latency.
+constexpr int64_t kPlainLoadMinOutputs = (int64_t)1000 * 1024;      // ~64 MB of cfloat input
+constexpr int64_t kPlainLoadMaxOutputs = (int64_t)4400 * 1024;      // ~285 MB
+
 bool launch_decimate_c4_systolic(hipStream_t s, const Geom& g, const float* d_taps, int P, const void* d_in, bool in_is_u8, float* d_out,
                                  bool last_tap_zero)
 {
-    if (!systolic_flag().load(std::memory_order_relaxed)) return false;
+    const int mode = systolic_flag().load(std::memory_order_relaxed);
+    if (mode == 0) return false;
     if (g.I != 1 || g.D != 8 || P != 128 || g.Lp != 128 || g.count < 64 * kStripOuts * kWavesPerWg) return false;
     const int64_t x0 = g.k_begin * g.D - g.in_base;
     const uintptr_t base = reinterpret_cast<uintptr_t>(d_in);
     if (((base + (in_is_u8 ? 2 : 8) * (uintptr_t)x0) & 15) != 0 || (reinterpret_cast<uintptr_t>(d_out) & 15) != 0) return false;
     // strip n is whole when its 240 outputs are wanted and its 2048 samples exist: 1920 n + 2048 <= (count - 1) * 8 + 128
     int nstrips, nwhole;
-    systolic_plan(g.count, false, &nstrips, &nwhole);
+    systolic_plan(g.count, &nstrips, &nwhole);
     const int nwg = (nstrips + kWavesPerWg - 1) / kWavesPerWg;
     const dim3 grid(((nwg + 63) / 64) * 64), block(64 * kWavesPerWg);
     if (in_is_u8) {
-        if (last_tap_zero) hipLaunchKernelGGL((k_decimate_systolic<true, 1>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips, 0);
-        else hipLaunchKernelGGL((k_decimate_systolic<true, 0>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips, 0);
+        if (last_tap_zero) hipLaunchKernelGGL((k_decimate_systolic<true, 1>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips);
+        else hipLaunchKernelGGL((k_decimate_systolic<true, 0>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips);
+    } else if (mode == 2 && g.count >= kPlainLoadMinOutputs && g.count <= kPlainLoadMaxOutputs) {
+        hipLaunchKernelGGL((k_decimate_systolic<false, 0, false>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips);
     } else {
-        hipLaunchKernelGGL((k_decimate_systolic<false, 0>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips, 0);
+        hipLaunchKernelGGL((k_decimate_systolic<false, 0, true>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips);
     }
     g_systolic_launches.fetch_add(1, std::memory_order_relaxed);
-    return true;
-}
-
-// K2 + K3 of the FM chain in one launch (+ the seam launch): u8 IQ -> decimate by 8 (128 taps, AVX order) -> fmDemod, the decimated
-// stream never written.  Decimator outputs [kd0, kd1) are computed, demodulated outputs [ky0, kd1) stored at d_y[k - ky0], where
-// ky0 = kd0 + 1 (output kd0 is only y[ky0]'s predecessor) or ky0 = kd0 = 0 (the stream's first sample, predecessor 0).
-// false = not this shape / too small: the caller runs the two stages on their own.
-bool launch_decimate_demod_systolic(hipStream_t s, const uint8_t* d_in, int64_t in_base, int64_t kd0, int64_t kd1, int64_t ky0,
-                                    const float* d_scaled_taps, const float* d_plain_taps, int P, bool last_tap_zero, int64_t seam_block,
-                                    float* d_y)
-{
-    if (!systolic_flag().load(std::memory_order_relaxed)) return false;
-    const int64_t n = kd1 - kd0;
-    if (P != 128 || n < 64 * kStripOuts * kWavesPerWg || n >= (int64_t)0x7fffffff || seam_block < 0) return false;
-    if (!(ky0 == kd0 + 1 || (ky0 == kd0 && kd0 == 0))) return false;
-    if (seam_block != 0 && (seam_block % 8 != 0 || seam_block < 256)) return false;
-    const int64_t x0 = kd0 * 8 - in_base;
-    if (x0 < 0 || ((reinterpret_cast<uintptr_t>(d_in) + 2 * (uintptr_t)x0) & 15) != 0 || (reinterpret_cast<uintptr_t>(d_y) & 3) != 0) return false;
-    const int count = (int)n, yshift = (int)(ky0 - kd0);
-    // strip t is whole when all of its outputs 239 t .. 239 t + 239 exist (then so do its 2048 samples)
-    int nstrips, nwhole;
-    systolic_plan(count, true, &nstrips, &nwhole);
-    const int nwg = (nstrips + kWavesPerWg - 1) / kWavesPerWg;
-    const dim3 grid(((nwg + 63) / 64) * 64), block(64 * kWavesPerWg);
-    if (last_tap_zero) hipLaunchKernelGGL((k_decimate_systolic<true, 1, true>), grid, block, 0, s, (const void*)d_in, x0, count, d_scaled_taps, d_y, nwhole, nstrips, yshift);
-    else hipLaunchKernelGGL((k_decimate_systolic<true, 0, true>), grid, block, 0, s, (const void*)d_in, x0, count, d_scaled_taps, d_y, nwhole, nstrips, yshift);
-    g_systolic_launches.fetch_add(1, std::memory_order_relaxed);
-    if (seam_block != 0) {
-        const int64_t v_lo = kd0 * 8, v_hi = (kd1 - 1) * 8 + 128;
-        const int64_t first = v_lo / seam_block + 1, last = (v_hi - 1) / seam_block;     // boundaries strictly inside the launch's samples
-        if (last >= first) {
-            const int nseams = (int)(last - first + 1);
-            hipLaunchKernelGGL(k_decimate_demod_crossfix, dim3((nseams + kFixSeamsPerWg - 1) / kFixSeamsPerWg), dim3(32 * kFixSeamsPerWg), 0, s, d_in, in_base,
-                               kd0, count, yshift, d_plain_taps, d_y, first, nseams, seam_block);
-        }
-    }
     return true;
 }
 

@@ -32,13 +32,6 @@ constexpr int TAIL_NL = 64;                               // resampler group len
 constexpr int TAIL_NY = 10 * (TAIL_NC - 1) + 7 + TAIL_NL; // y values per tile: 7311
 constexpr int TAIL_NY_PAD = (TAIL_NY + 3 + 8) & ~3;
 
-#ifdef SDRHIP_TAIL_PROBE
-// development probe (tools/k2lab/tail_lab.hip): shader-clock cycles each phase takes, summed over the probed workgroups
-struct TailProbe { unsigned long long cyc[4], rt, n; };
-#define TAIL_PROBE_MARK(i) do { if (pr != nullptr && threadIdx.x == 0 && (blockIdx.x & 15) == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); if (i > 0) atomicAdd(&pr->cyc[i - 1], t_ - tprev_); tprev_ = t_; } } while (0)
-#else
-#define TAIL_PROBE_MARK(i) do { } while (0)
-#endif
 
 struct TailParams {
     int64_t kd0, kd1;        // d holds [kd0, kd1)
@@ -64,22 +57,11 @@ __device__ __forceinline__ tail_f8 tail_taps8(const float* base, int chunk)
 
 // d: decimator output (d[0] = global index kd0); audio[0] = output q0; groups: 3 rows of row_stride floats (group g =
 // outputs m = 3c + g); rplain: the resampler's plain taps; fhalf / fplain: the audio filter's 64 half-taps / 128 plain taps
-// YIN: d_in is the DEMODULATED stream y (y[0] = global index ky0), produced by the stand-alone fmDemod kernel: phase 1 only
-// stages it (resampler + filter fused, z never reaches HBM, no recomputed fmDemod overlap).
-template <bool YIN>
 __global__ void __launch_bounds__(TAIL_NT, 4) k_fm_tail(const float* __restrict__ d_in, float* __restrict__ audio,
                                                         const float* __restrict__ groups, const float* __restrict__ rplain,
                                                         const float* __restrict__ fhalf, const float* __restrict__ fplain, TailParams p
-#ifdef SDRHIP_TAIL_PROBE
-                                                        , TailProbe* pr
-#endif
 )
 {
-#ifdef SDRHIP_TAIL_PROBE
-    unsigned long long tprev_ = 0;
-    const unsigned long long rt0_ = wall_clock64();
-#endif
-    TAIL_PROBE_MARK(0);
     __shared__ __attribute__((aligned(16))) float ys[TAIL_NY_PAD];
     __shared__ __attribute__((aligned(16))) float zs[TAIL_NZ + 16];
     // the un-grouped taps of the two sequential (Cross) kernels: read per lane at data-dependent offsets, and a dependent
@@ -100,34 +82,6 @@ __global__ void __launch_bounds__(TAIL_NT, 4) k_fm_tail(const float* __restrict_
     constexpr int NQ = (TAIL_NY + 3) / 4;                      // quads of y per tile
     constexpr int ROUNDS = (NQ + TAIL_NT - 1) / TAIL_NT;
     const int64_t klo = p.ky0 > y0 ? p.ky0 : y0;               // first y this tile has to produce
-    if constexpr (YIN) {
-        // all of the tile's loads in flight, then the LDS stores (y0 = 10 c0 is even, ky0 arbitrary: 4-byte loads at the
-        // ragged ends, 16-byte ones where the quad lies inside [ky0, ky1) and the address allows)
-        float4 q[ROUNDS];
-        const bool al = ((reinterpret_cast<uintptr_t>(d_in) + 4 * (uint64_t)(y0 - p.ky0)) & 15) == 0;
-#pragma unroll
-        for (int rd = 0; rd < ROUNDS; rd++) {
-            const int qd = tid + rd * TAIL_NT;
-            const int64_t k = y0 + 4 * (int64_t)qd;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (qd < NQ) {
-                if (al && k >= p.ky0 && k + 4 <= p.ky1) {
-                    v = *reinterpret_cast<const float4*>(d_in + (k - p.ky0));
-                } else {
-                    if (k + 0 >= p.ky0 && k + 0 < p.ky1) v.x = d_in[k + 0 - p.ky0];
-                    if (k + 1 >= p.ky0 && k + 1 < p.ky1) v.y = d_in[k + 1 - p.ky0];
-                    if (k + 2 >= p.ky0 && k + 2 < p.ky1) v.z = d_in[k + 2 - p.ky0];
-                    if (k + 3 >= p.ky0 && k + 3 < p.ky1) v.w = d_in[k + 3 - p.ky0];
-                }
-            }
-            q[rd] = v;
-        }
-#pragma unroll
-        for (int rd = 0; rd < ROUNDS; rd++) {
-            const int qd = tid + rd * TAIL_NT;
-            if (qd < NQ) *reinterpret_cast<float4*>(&ys[4 * qd]) = q[rd];
-        }
-    } else {
     auto load5 = [&](int qd, float2 (&v)[5]) {
         const int64_t k = y0 + 4 * (int64_t)qd;                // v[e] = d[k - 1 + e]
 #pragma unroll
@@ -160,9 +114,7 @@ __global__ void __launch_bounds__(TAIL_NT, 4) k_fm_tail(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 5; e++) cur[e] = nxt[e];
     }
-    }
     __syncthreads();
-    TAIL_PROBE_MARK(1);
 
     // ---- phase 2: polyphase resampler, one cycle (3 outputs) per thread and round.
     // Seam classification in 32-bit arithmetic relative to the tile (the launcher guarantees a tile spans less than one
@@ -233,7 +185,6 @@ __global__ void __launch_bounds__(TAIL_NT, 4) k_fm_tail(const float* __restrict_
         zs[3 * cl + 2] = res[2];
     }
     __syncthreads();
-    TAIL_PROBE_MARK(2);
 
     // ---- phase 3: symmetric audio filter (pair-add first, 8 lanes, tree) + gain; 4 consecutive outputs per thread.
     constexpr int NK = TAIL_LF / 2;
@@ -285,22 +236,15 @@ __global__ void __launch_bounds__(TAIL_NT, 4) k_fm_tail(const float* __restrict_
             if (o < TAIL_A && q >= p.q0 && q < p.q1) audio[q - p.q0] = res;
         }
     }
-    TAIL_PROBE_MARK(3);
-#ifdef SDRHIP_TAIL_PROBE
-    if (pr != nullptr && threadIdx.x == 0 && (blockIdx.x & 15) == 0) { atomicAdd(&pr->rt, wall_clock64() - rt0_); atomicAdd(&pr->n, 1ull); }
-#endif
 }
 
-#ifdef SDRHIP_TAIL_PROBE
-TailProbe* g_tail_probe = nullptr;
-#endif
 
 }  // namespace
 
 bool launch_fm_tail_fused(hipStream_t s, const float* d_d, int64_t kd0, int64_t kd1, int64_t ky0, int64_t ky1, float* d_audio,
                           int64_t q0, int64_t q1, const float* d_groups, int row_stride, int nloop, const int* increments,
                           int ngroups, int I, int D, int rLp, const float* d_rplain, int ntaps, const float* d_fhalf, int nhalf,
-                          const float* d_fplain, float gain, int64_t seam, const float* d_y)
+                          const float* d_fplain, float gain, int64_t seam)
 {
     // specialised for the FM chain's tail: 3/10 resampler with 64-float groups, 64 half-tap symmetric filter, AVX orders
     if (!(ngroups == 3 && nloop == TAIL_NL && I == 3 && D == 10 && increments[0] == 4 && increments[1] == 3 && increments[2] == 3)) return false;
@@ -313,14 +257,7 @@ bool launch_fm_tail_fused(hipStream_t s, const float* d_d, int64_t kd0, int64_t 
     p.row_stride = row_stride; p.ntaps = ntaps; p.rLp = rLp; p.gain = gain; p.seam = seam;
     const int64_t qa0 = (q0 / 3) * 3;
     const int64_t tiles = (q1 - qa0 + TAIL_A - 1) / TAIL_A;
-    #ifdef SDRHIP_TAIL_PROBE
-    hipLaunchKernelGGL(k_fm_tail<false>, dim3((unsigned)tiles), dim3(TAIL_NT), 0, s, d_d, d_audio, d_groups, d_rplain, d_fhalf, d_fplain, p, g_tail_probe);
-#else
-    if (d_y != nullptr)        // y[ky0, ky1) already demodulated by the stage kernel: resampler + filter only
-        hipLaunchKernelGGL(k_fm_tail<true>, dim3((unsigned)tiles), dim3(TAIL_NT), 0, s, d_y, d_audio, d_groups, d_rplain, d_fhalf, d_fplain, p);
-    else
-        hipLaunchKernelGGL(k_fm_tail<false>, dim3((unsigned)tiles), dim3(TAIL_NT), 0, s, d_d, d_audio, d_groups, d_rplain, d_fhalf, d_fplain, p);
-#endif
+    hipLaunchKernelGGL(k_fm_tail, dim3((unsigned)tiles), dim3(TAIL_NT), 0, s, d_d, d_audio, d_groups, d_rplain, d_fhalf, d_fplain, p);
     return true;
 }
 

@@ -125,9 +125,7 @@ lib.sdrhip_fm_chain_graph_create.argtypes = [C.POINTER(_vp), _vp, _vp, _i64, _i6
 lib.sdrhip_fm_chain_graph_launch.argtypes = [_vp, _vp]
 lib.sdrhip_fm_chain_graph_destroy.argtypes = [_vp]
 lib.sdrhip_fm_chain_graph_destroy.restype = None
-lib.sdrhip_fm_chain_set_pipelining.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_set_overlap.argtypes = [_vp, C.c_int]
-lib.sdrhip_fm_chain_set_decim_demod_fusion.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_join.argtypes = [_vp, _vp]
 lib.sdrhip_fm_chain_set_fused_tail.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_set_small_chain.argtypes = [_vp, C.c_int, _i64, C.c_int]
@@ -135,19 +133,10 @@ lib.sdrhip_debug_small_chain_launches.restype = C.c_longlong
 lib.sdrhip_debug_resample_cycle_launches.restype = C.c_longlong
 lib.sdrhip_debug_decimate_real16_launches.restype = C.c_longlong
 lib.sdrhip_debug_systolic_launches.restype = C.c_longlong
-lib.sdrhip_debug_resample_systolic_launches.restype = C.c_longlong
-lib.sdrhip_debug_set_resample_systolic.argtypes = [C.c_int]
 lib.sdrhip_debug_set_systolic.argtypes = [C.c_int]
-lib.sdrhip_debug_set_demod_form.argtypes = [C.c_int]
-lib.sdrhip_debug_set_demod_form.restype = None
-lib.sdrhip_debug_demod_form.argtypes = []
-lib.sdrhip_debug_demod_form.restype = C.c_int
-lib.sdrhip_debug_set_resample_demod_stream.argtypes = [C.c_int]
-lib.sdrhip_debug_set_resample_demod_stream.restype = None
-lib.sdrhip_debug_resample_demod_stream_launches.argtypes = []
-lib.sdrhip_debug_resample_demod_stream_launches.restype = C.c_longlong
-lib.sdrhip_debug_resample_demod_stream_plan.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
-lib.sdrhip_debug_resample_demod_stream_plan.restype = None
+lib.sdrhip_debug_set_systolic.restype = None
+lib.sdrhip_debug_systolic_plan.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+lib.sdrhip_debug_systolic_plan.restype = None
 lib.sdrhip_fm_chain_enable_timing.argtypes = [_vp, C.c_int]
 lib.sdrhip_fm_chain_read_timing.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]
 
@@ -469,14 +458,6 @@ class FmChain(_Handle):
         return lib.sdrhip_fm_chain_workspace_bytes(self.h, n_in)
 
     STAGES = ("decimate", "fm_demod", "resample", "filter", "fused_tail", "fused_chain")
-
-    def set_pipelining(self, nsub):
-        check(lib.sdrhip_fm_chain_set_pipelining(self.h, nsub), "sdrhip_fm_chain_set_pipelining")
-
-    def set_decim_demod_fusion(self, on):
-        """fmDemod in the systolic decimator's epilogue (default OFF: measured slower than the two kernels, chain.cpp): the
-        decimated stream then never reaches HBM."""
-        check(lib.sdrhip_fm_chain_set_decim_demod_fusion(self.h, 1 if on else 0), "sdrhip_fm_chain_set_decim_demod_fusion")
 
     def set_overlap(self, on):
         """Two runs in flight: consecutive runs alternate between two internal streams and workspace halves (sdr_hip.h)."""

@@ -195,68 +195,34 @@ def test_drop_in_failures_reach_the_error_handler_instead_of_abort(L):
 
 
 def test_systolic_strip_plan_covers_every_launch_exactly(L):
-    """kernels_systolic.hip cuts a launch into wave-strips on the host: whole strips (unguarded loads and stores) must lie entirely
-    inside the launch's outputs AND samples, the strips together must cover every output, and the first strip that is not whole must
-    really be ragged -- for the plain decimator (240 outputs per strip) and the fused decimate + fmDemod form (239)."""
+    """kernels_systolic.hip cuts a launch into wave-strips on the host (240 outputs per strip): whole strips (unguarded loads and
+    stores) must lie entirely inside the launch's outputs AND samples, the strips together must cover every output, and the first
+    strip that is not whole must really be ragged."""
     import random
     lib = L.lib
-    lib.sdrhip_debug_systolic_plan.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    lib.sdrhip_debug_systolic_plan.restype = None
     rng = random.Random(4)
     counts = list(range(1, 1500)) + [61440 + d for d in range(-3, 500)] + [rng.randrange(1, 1 << 27) for _ in range(3000)] + [(1 << 26) + d for d in (-1, 0, 1, 14)]
-    for demod in (0, 1):
-        step = 239 if demod else 240
-        for count in counts:
-            ns, nw = C.c_int(), C.c_int()
-            lib.sdrhip_debug_systolic_plan(count, demod, C.byref(ns), C.byref(nw))
-            ns, nw = ns.value, nw.value
-            avail = (count - 1) * 8 + 128                       # samples of the launch
-            assert 0 <= nw <= ns and ns >= 1
-            # coverage: the last strip reaches the last output (demod: outputs step*t + 1 .. step*t + 239 are a strip's own)
-            last_covered = step * (ns - 1) + 239
-            assert last_covered >= count - 1, (demod, count, ns)
-            if ns > 1:
-                assert step * (ns - 2) + 239 < count - 1 or demod, (demod, count, ns)      # no strip is superfluous
-            if nw > 0:
-                t = nw - 1
-                assert step * t + 239 <= count - 1, (demod, count, nw)                     # all 240 outputs of a whole strip exist
-                assert 8 * step * t + 2048 <= avail, (demod, count, nw)                    # and all 2048 samples it loads
-            if nw < ns:
-                t = nw
-                ragged = step * t + 239 > count - 1 or 8 * step * t + 2048 > avail
-                assert ragged, (demod, count, nw)
-
-
-def test_resampler_systolic_strip_plan(L):
-    """The 3/10 systolic resampler's strips: 248 polyphase cycles each, 2560 inputs read, whole strips inside the cycles and inputs."""
-    import random
-    lib = L.lib
-    lib.sdrhip_debug_resample_systolic_plan.argtypes = [C.c_int, C.c_longlong, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    lib.sdrhip_debug_resample_systolic_plan.restype = None
-    rng = random.Random(9)
-    for ncyc in list(range(1, 1200)) + [rng.randrange(1, 1 << 24) for _ in range(2000)]:
-        avail = (ncyc - 1) * 10 + 7 + 64
+    for count in counts:
         ns, nw = C.c_int(), C.c_int()
-        lib.sdrhip_debug_resample_systolic_plan(ncyc, avail, C.byref(ns), C.byref(nw))
+        lib.sdrhip_debug_systolic_plan(count, C.byref(ns), C.byref(nw))
         ns, nw = ns.value, nw.value
-        assert 0 <= nw <= ns and 248 * ns >= ncyc > 248 * (ns - 1)
-        if nw:
-            assert 248 * nw <= ncyc and 2480 * (nw - 1) + 2560 <= avail
+        avail = (count - 1) * 8 + 128                       # samples of the launch
+        assert 0 <= nw <= ns and ns >= 1
+        assert 240 * (ns - 1) + 239 >= count - 1, (count, ns)                           # the last strip reaches the last output
+        if ns > 1:
+            assert 240 * (ns - 2) + 239 < count - 1, (count, ns)                        # no strip is superfluous
+        if nw > 0:
+            t = nw - 1
+            assert 240 * t + 239 <= count - 1, (count, nw)                              # all 240 outputs of a whole strip exist
+            assert 1920 * t + 2048 <= avail, (count, nw)                                # and all 2048 samples it loads
         if nw < ns:
-            assert 248 * (nw + 1) > ncyc or 2480 * nw + 2560 > avail
+            t = nw
+            assert 240 * t + 239 > count - 1 or 1920 * t + 2048 > avail, (count, nw)    # the first guarded strip is really ragged
 
 
-def test_stream_kernel_plan_covers_every_cycle():
-    """Host arithmetic of the streaming fmDemod + resampler's cut (kernels_resample_stream.hip; no device call): every tile belongs to
-    exactly one workgroup, for any run length and CU count; and the staging size of the batched halo exchange (round 5)."""
-    import ctypes as C
+def test_halo_staging_size():
+    """The staging size of the batched halo exchange (sdrhip_fm_chain_halo_exchange_batch)."""
     import sdr_amd.lib as L
-    for ncycles in (1, 255, 256, 257, 1000, 419431, 6710886, 20132659):
-        for cus in (1, 8, 256, 304):
-            nt, per, grid = C.c_int(), C.c_int(), C.c_int()
-            L.lib.sdrhip_debug_resample_demod_stream_plan(ncycles, cus, C.byref(nt), C.byref(per), C.byref(grid))
-            assert nt.value == (ncycles + 255) // 256
-            assert per.value * grid.value >= nt.value > per.value * (grid.value - 1)
     import signals as S
     ch = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, 8192)
     h = ch.halo_samples()

@@ -436,9 +436,6 @@ def test_fused_tail_equals_stage_kernels(hip, oracle, block):
         ch.set_fused_tail(1)
         got = _run(hip, ch, d, 0, total, a, b)
         assert_bit_equal(got, ref, f"fused tail, block {block}, outputs [{a},{b})")
-        ch.set_fused_tail(3)              # fmDemod as its own kernel, resampler + filter fused
-        got = _run(hip, ch, d, 0, total, a, b)
-        assert_bit_equal(got, ref, f"fmDemod + fused resampler/filter, block {block}, outputs [{a},{b})")
     if block == B:
         exp = _model(oracle, u8, nblk)
         ch.set_fused_tail(1)
@@ -728,82 +725,3 @@ def test_two_runs_in_flight_equal_the_single_stream(hip, nblk):
     chain.set_overlap(False)
     again = _run(hip, chain, inputs[1], 0, total, q0, q1)
     assert np.array_equal(again.view(np.int32), refs[1].cpu().numpy().view(np.int32))
-
-
-def test_decimator_demod_fusion_matches_pipes(hip, oracle):
-    """Round 4: fmDemod in the systolic decimator's epilogue (the decimated stream never reaches HBM).  300 source blocks on the
-    stage kernels (the one-kernel chain, which takes runs up to ~900 blocks on its own since round 5, is switched off) against
-    the restated Pipes."""
-    nblk = 300
-    u8 = S.iq_u8(nblk * B)
-    exp = _model(oracle, u8, nblk)
-    chain = _chain(hip)
-    chain.set_small_chain(0)
-    chain.set_decim_demod_fusion(True)          # off by default (measured slower than the two kernels, chain.cpp)
-    total = nblk * B
-    q0, q1, _ = chain.plan(0, total, total)
-    before = hip.lib.sdrhip_debug_systolic_launches()
-    hip.lib.sdrhip_debug_set_systolic(1)        # the fusion lives in the systolic kernel (SDRHIP_SYSTOLIC=0 soak runs switch it off)
-    try:
-        got = _run(hip, chain, to_dev(u8), 0, total, 0, q1)
-    finally:
-        hip.lib.sdrhip_debug_set_systolic(int(__import__("os").environ.get("SDRHIP_SYSTOLIC", "1")))
-    assert hip.lib.sdrhip_debug_systolic_launches() == before + 1
-    assert exp.size >= 8 * B
-    assert_bit_equal(got[: exp.size], exp, "fused decimate + fmDemod vs pipes")
-
-
-@pytest.mark.parametrize("kind", ["noise", "silence with bursts", "fm"])
-def test_decimator_demod_fusion_on_equals_off(hip, kind):
-    """The same chain with the fusion switched off (decimator, then fmDemod as its own kernel): whole stream from its first sample,
-    shards that start in the middle (a predecessor output instead of the stream's zero), ragged ends, every seam."""
-    n = (1 << 23) + 8 * 1237
-    gen = torch.Generator(device="cuda").manual_seed(23)
-    if kind == "noise":
-        u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda", generator=gen)
-    elif kind == "fm":
-        u8 = to_dev(S.iq_u8_fm(n))
-    else:
-        # long runs of exact zeros (u8 128): decimator outputs that are exactly 0 (phase of 0 is 0, Demod.hs) next to live ones
-        u8 = torch.full((2 * n,), 128, dtype=torch.uint8, device="cuda")
-        for a in range(0, n, 1 << 18):
-            u8[2 * a: 2 * (a + 3000)] = torch.randint(0, 256, (6000,), dtype=torch.uint8, device="cuda", generator=gen)
-    chain = _chain(hip)
-    q0, q1, _ = chain.plan(0, n, n)
-    ranges = [(0, n, q0, q1)]
-    # a shard in the middle of the stream: its own samples plus the halo it needs
-    s0 = 3 * B * 37
-    qa, qb, halo = chain.plan(s0, s0 + (1 << 22), n)
-    ranges.append((s0, (1 << 22) + halo, qa, qb))
-    ranges.append((s0, (1 << 22) + halo, qa + 1234, qb - 4321))
-    for (a, cnt, qa_, qb_) in ranges:
-        outs = []
-        for on in (True, False):
-            chain.set_decim_demod_fusion(on)
-            ws_bytes = chain.workspace_bytes(cnt)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
-            out = torch.full((qb_ - qa_ + 16,), float("nan"), device="cuda")
-            chain.run(ptr(u8) + 2 * a, a, cnt, ptr(out), qa_, qb_, ptr(ws), ws_bytes)
-            torch.cuda.synchronize()
-            outs.append(out)
-        chain.set_decim_demod_fusion(False)
-        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (kind, a, cnt, qa_, qb_)
-        assert not torch.isnan(outs[0][: qb_ - qa_]).any()
-
-
-def test_chain_with_the_systolic_resampler_equals_the_tile_kernel(hip):
-    """kernels_resample_systolic.hip inside the chain (optional, off by default): the same audio, bit for bit, on a full-size pass cut
-    at the places the chain cuts it (launch starts that are and are not 16-byte aligned)."""
-    n = (1 << 24) + 8 * 4099
-    u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda")
-    chain = _chain(hip)
-    chain.set_demod_fusion(False)          # the systolic resampler reads the demodulated stream (no fmDemod in its loader)
-    q0, q1, _ = chain.plan(0, n, n)
-    outs = []
-    before = hip.lib.sdrhip_debug_resample_systolic_launches()
-    for on in (1, 0):
-        hip.lib.sdrhip_debug_set_resample_systolic(on)
-        outs.append(torch.from_numpy(_run(hip, chain, u8, 0, n, q0, q1)))
-    hip.lib.sdrhip_debug_set_resample_systolic(0)
-    assert hip.lib.sdrhip_debug_resample_systolic_launches() > before
-    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))

@@ -19,52 +19,34 @@ TOTAL_LOG2 = int(os.environ.get("SDRHIP_EXHAUSTIVE_LOG2", "32"))
 CHUNK_LOG2 = 25            # pairs per launch: 2^26 complex samples, 512 MiB of input
 
 
-def _sweep(hip, oracle, kind, form):
+def _sweep(hip, oracle, kind):
     total = 1 << TOTAL_LOG2
     chunk = min(total, 1 << CHUNK_LOG2)
-    hip.lib.sdrhip_debug_set_demod_form(form)
-    assert hip.lib.sdrhip_debug_demod_form() == form
     out = torch.empty(2 * chunk, dtype=torch.float32, device="cuda")
     last = (0.0, 0.0)
     bad_total, first_bad = 0, None
-    try:
-        for idx0 in range(0, total, chunk):
-            iq = oracle.demod_sweep_fill(kind, idx0, chunk)
-            d_in = torch.from_numpy(iq).cuda()
-            hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, 2 * chunk, last[0], last[1]))
-            got = out.cpu().numpy()
-            bad, first = oracle.demod_sweep_check(kind, idx0, chunk, idx0 == 0, got)
-            if bad and first_bad is None:
-                first_bad = first
-            bad_total += bad
-            last = (float(iq[-2]), float(iq[-1]))
-    finally:
-        hip.lib.sdrhip_debug_set_demod_form(3)
-    assert bad_total == 0, f"kind {kind}, form {form}: {bad_total} of {2 * total} phases differ from the spec, first at output {first_bad}"
+    for idx0 in range(0, total, chunk):
+        iq = oracle.demod_sweep_fill(kind, idx0, chunk)
+        d_in = torch.from_numpy(iq).cuda()
+        hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, 2 * chunk, last[0], last[1]))
+        got = out.cpu().numpy()
+        bad, first = oracle.demod_sweep_check(kind, idx0, chunk, idx0 == 0, got)
+        if bad and first_bad is None:
+            first_bad = first
+        bad_total += bad
+        last = (float(iq[-2]), float(iq[-1]))
+    assert bad_total == 0, f"kind {kind}: {bad_total} of {2 * total} phases differ from the spec, first at output {first_bad}"
 
 
 def test_every_float_as_the_argument_of_atanf(hip, oracle):
     """y[2i+1] = atan2(q_i, 1) = atanf(q_i) with q_i = the float of bit pattern i, for all i; y[2i] = atan2(-q_(i-1), 1)."""
-    _sweep(hip, oracle, 0, 3)
+    _sweep(hip, oracle, 0)
 
 
 def test_two_to_the_32_pseudo_random_pairs_through_atan2(hip, oracle):
     """(x_i, y_i) two permutations of all bit patterns (odd indices with moderate exponents): every clause of GHC's atan2, products
     that overflow, cancel, underflow; the wave vote of the common-case form takes both exits."""
-    _sweep(hip, oracle, 1, 3)
-
-
-@pytest.mark.parametrize("form", [0, 1, 2, 4])
-def test_the_other_forms_on_a_sixteenth_of_the_sweeps(hip, oracle, form, monkeypatch):
-    """Ternaries, selects, common case + vote without the table, the packed pair form: 2^28 indices of each sweep."""
-    global TOTAL_LOG2
-    keep = TOTAL_LOG2
-    TOTAL_LOG2 = min(TOTAL_LOG2, 28)
-    try:
-        _sweep(hip, oracle, 1, form)
-        _sweep(hip, oracle, 0, form)
-    finally:
-        TOTAL_LOG2 = keep
+    _sweep(hip, oracle, 1)
 
 
 def test_this_box_libm_against_the_model_on_every_float(oracle):

@@ -193,29 +193,6 @@ def test_example_real_taps_chain(hip, oracle):
     assert_bit_equal(got[: exp.size], exp, "the example's own taps, host-block stream")
 
 
-def test_chain_pipelining_is_invisible(hip):
-    """The internal two-stream software pipelining (nsub sub-batches) must not change a bit, and the
-    caller's stream must see the finished result without any extra synchronisation."""
-    n = 1 << 25
-    u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda")
-    chain = hip.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, B)
-    ws = torch.empty(chain.workspace_bytes(n), dtype=torch.uint8, device="cuda")
-    q0, q1, _ = chain.plan(0, n, n)
-    outs = []
-    st = torch.cuda.Stream()
-    for nsub in (1, 8, 3, 16):
-        chain.set_pipelining(nsub)
-        out = dev_empty_f32(q1)
-        with torch.cuda.stream(st):
-            for _ in range(3):     # back-to-back runs reuse the workspace: exercises the cross-run ordering
-                chain.run(ptr(u8), 0, n, ptr(out), 0, q1, ptr(ws), ws.numel(), stream=st.cuda_stream)
-            res = out.clone()      # ordinary stream-ordered consumer, no explicit sync with the internal stream
-        st.synchronize()
-        outs.append(res)
-    for o in outs[1:]:
-        assert torch.equal(outs[0].view(torch.int32), o.view(torch.int32))
-
-
 @pytest.mark.parametrize("kind", ["noise", "patchy"])
 @pytest.mark.parametrize("start_blocks", [0, 37])
 def test_chain_demod_fusion_is_invisible(hip, start_blocks, kind):
@@ -241,7 +218,6 @@ def test_chain_demod_fusion_is_invisible(hip, start_blocks, kind):
         chain = hip.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, block)
         chain.set_fused_tail(0)                                    # the stage kernels, whatever the environment asks for
         chain.set_small_chain(0)
-        chain.set_decim_demod_fusion(False)                        # (round 4's fusion of fmDemod into the DECIMATOR has its own tests)
         ws = torch.empty(chain.workspace_bytes(n), dtype=torch.uint8, device="cuda")
         s0 = start_blocks * B
         q0, q1, _ = chain.plan(s0, s0 + n, s0 + n)
@@ -260,18 +236,3 @@ def test_chain_demod_fusion_is_invisible(hip, start_blocks, kind):
             outs.append(out)
         assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), f"block {block}: fused differs"
         assert torch.equal(outs[0].view(torch.int32), outs[2].view(torch.int32))
-        # ... and the decimator-side fusion gives the same audio as all of them
-        chain.set_demod_fusion(False)
-        chain.set_decim_demod_fusion(True)
-        hip.lib.sdrhip_debug_set_systolic(1)                       # that fusion lives in the systolic kernel (soak runs may switch it off)
-        ws.fill_(0x5A)
-        out = dev_empty_f32(q1 - q0)
-        chain.enable_timing(True)
-        chain.run(ptr(u8), s0, n, ptr(out), q0, q1, ptr(ws), ws.numel())
-        torch.cuda.synchronize()
-        stage_ms, _ = chain.read_timing()
-        chain.enable_timing(False)
-        assert stage_ms["fm_demod"] == 0.0 and stage_ms["decimate"] > 0.0, "fmDemod in the decimator's epilogue is booked under `decimate`"
-        assert torch.equal(outs[0].view(torch.int32), out.view(torch.int32)), f"block {block}: decimator-side fusion differs"
-        chain.set_decim_demod_fusion(False)
-        hip.lib.sdrhip_debug_set_systolic(int(__import__("os").environ.get("SDRHIP_SYSTOLIC", "1")))

@@ -220,26 +220,21 @@ def test_fm_demod_random_bit_patterns(hip, oracle):
     nan_e = np.isnan(exp)
     ok = ~nan_e
     assert ok.sum() > n // 4
-    # every restatement of the arithmetic the library holds (demod.hpp): ternaries, selects, common case + wave vote
-    try:
-        for form in (1, 0, 2, 3, 4):
-            hip.lib.sdrhip_debug_set_demod_form(form)
-            assert hip.lib.sdrhip_debug_demod_form() == form, "the setter must select the form it is given (round 4 clamped 3 to 0)"
-            out = dev_empty_f32(n)
-            hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
-            got = to_host(out)
-            nan_g = np.isnan(got)
-            assert np.array_equal(nan_e, nan_g), f"form {form}: NaN pattern differs at {np.nonzero(nan_e != nan_g)[0][:5]}"
-            assert_bit_equal(got[ok], exp[ok], f"fmDemod on random bit patterns, form {form}")
-    finally:
-        hip.lib.sdrhip_debug_set_demod_form(3)
+    # the stand-alone kernel: the common case per lane, a wave vote, the full select form behind it (demod.hpp) -- on this input
+    # nearly every wave takes the full form
+    out = dev_empty_f32(n)
+    hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
+    got = to_host(out)
+    nan_g = np.isnan(got)
+    assert np.array_equal(nan_e, nan_g), f"NaN pattern differs at {np.nonzero(nan_e != nan_g)[0][:5]}"
+    assert_bit_equal(got[ok], exp[ok], "fmDemod on random bit patterns")
     got2 = hip.DropIn.fm_demod(x)
     assert np.array_equal(np.isnan(got2), nan_e)
     assert_bit_equal(got2[ok], exp[ok], "fmDemodF (drop-in) on random bit patterns")
 
 
-def test_fm_demod_forms_on_ordinary_and_awkward_signals(hip, oracle):
-    """The three restatements of fmDemod's arithmetic on what a receiver sees (an FM signal, noise) and on the inputs that
+def test_fm_demod_on_ordinary_and_awkward_signals(hip, oracle):
+    """fmDemod on what a receiver sees (an FM signal, noise) and on the inputs that
     leave the common case: zeros of either sign, the axes, denormals, ratios beyond 2^25 and below 2^-29, repeated samples --
     alone in a wave of ordinary samples and in runs longer than a wave."""
     rng = np.random.default_rng(4242)
@@ -256,18 +251,12 @@ def test_fm_demod_forms_on_ordinary_and_awkward_signals(hip, oracle):
     x[2 * 62000: 2 * 62400: 2] = 0.0                                # on the imaginary axis
     exp = oracle.fm_demod(x)
     d_in = to_dev(x)
-    try:
-        for form in (0, 1, 2, 3, 4):
-            hip.lib.sdrhip_debug_set_demod_form(form)
-            assert hip.lib.sdrhip_debug_demod_form() == form
-            out = dev_empty_f32(n)
-            hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
-            assert_bit_equal(to_host(out), exp, f"fmDemod, form {form}")
-    finally:
-        hip.lib.sdrhip_debug_set_demod_form(3)
+    out = dev_empty_f32(n)
+    hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
+    assert_bit_equal(to_host(out), exp, "fmDemod")
 
 
-def test_fm_demod_forms_on_dense_argument_ranges(hip, oracle):
+def test_fm_demod_on_dense_argument_ranges(hip, oracle):
     """atan2's ratio swept on purpose: every second sample is 1 + 0i, so the phases are atan2(+-y, x) of the samples in between.
     Ratios log-uniform over [2^-30, 2^26] (all five argument ranges of fdlibm's atanf, in every quadrant, with power-of-two and
     with random-mantissa denominators), then every range threshold and every ratio that makes a reduced numerator vanish
@@ -300,15 +289,9 @@ def test_fm_demod_forms_on_dense_argument_ranges(hip, oracle):
     exp = oracle.fm_demod(iq)
     d_in = to_dev(iq)
     n = iq.size // 2
-    try:
-        for form in (0, 1, 2, 3, 4):
-            hip.lib.sdrhip_debug_set_demod_form(form)
-            assert hip.lib.sdrhip_debug_demod_form() == form
-            out = dev_empty_f32(n)
-            hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
-            assert_bit_equal(to_host(out), exp, f"fmDemod on swept ratios, form {form}")
-    finally:
-        hip.lib.sdrhip_debug_set_demod_form(3)
+    out = dev_empty_f32(n)
+    hip.check(hip.lib.sdrhip_fm_demod_run(None, ptr(d_in), 0, ptr(out), 0, n, 0.0, 0.0))
+    assert_bit_equal(to_host(out), exp, "fmDemod on swept ratios")
 
 
 @pytest.mark.parametrize("factor", [8, 4, 16])

@@ -23,10 +23,10 @@ def _dup(h):
 
 @pytest.fixture
 def counted(hip):
-    hip.lib.sdrhip_debug_set_systolic(1)
+    hip.lib.sdrhip_debug_set_systolic(1)             # 1 = the systolic kernel wherever its shape fits (2, the default, also looks at the launch size)
     before = hip.lib.sdrhip_debug_systolic_launches()
     yield lambda: hip.lib.sdrhip_debug_systolic_launches() - before
-    hip.lib.sdrhip_debug_set_systolic(1)
+    hip.lib.sdrhip_debug_set_systolic(2)             # back to the library's own choice by launch size
 
 
 @pytest.mark.parametrize("extra", [0, 1, 3, 239, 240, 247, 4 * 240 + 5, 38563])
@@ -96,34 +96,6 @@ def test_same_bits_as_the_tile_kernel_at_2_to_the_24(hip, counted, u8):
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
 
 
-@pytest.mark.parametrize("nblk", [61, 62, 100])
-def test_resampler_3_10_systolic_matches_pipes(hip, oracle, nblk):
-    """kernels_resample_systolic.hip: the FM chain's 3/10 resampler (191 taps) on launches that are not launch-bound -- against the
-    restated firResampler Pipe with 8192-float seams (seamed launches of up to 65536 outputs stay on the one-launch route), the stream
-    cut at outputs that leave the later launches unaligned (those fall back to the tile kernel) and aligned."""
-    x = S.real_block(nblk * B)
-    taps = S.taps_resamp191()
-    model = PM.ResamplerModel(oracle, 3, 10, taps, PM.ORDER_AVX, False)
-    blocks, _ = PM.fir_resampler_pipe(model, [x[i * B:(i + 1) * B] for i in range(nblk)], 4096)
-    exp = np.concatenate(blocks)
-    K = exp.size
-    r = hip.Resampler(3, 10, taps, hip.ORDER_AVX, False)
-    d_in = to_dev(x)
-    before = hip.lib.sdrhip_debug_resample_systolic_launches()
-    hip.lib.sdrhip_debug_set_resample_systolic(1)            # off by default (measured no faster than the tile kernel)
-    for cuts in ([], [12], [3, 48003]):
-        out = dev_empty_f32(K + 16)
-        out.fill_(float("nan"))
-        edges = [0] + cuts + [K]
-        for a, b in zip(edges[:-1], edges[1:]):
-            r.run(ptr(d_in), 0, ptr(out) + 4 * a, a, b, B, out_block=4096)
-        got = to_host(out)
-        assert_bit_equal(got[:K], exp, f"cuts {cuts}")
-        assert np.isnan(got[K:]).all()
-    hip.lib.sdrhip_debug_set_resample_systolic(0)
-    assert hip.lib.sdrhip_debug_resample_systolic_launches() >= before + 2, "the systolic resampler never ran"
-
-
 def test_random_launch_geometry_equals_the_tile_kernel(hip):
     """Seeded sweep: random first output, output count, seam block (0, 8192, other multiples of 8 above the filter length) and input
     type -- the systolic kernel against the LDS-tiled kernel on the very same launch (the tile kernel is pinned to the oracle by the
@@ -155,7 +127,7 @@ def test_random_launch_geometry_equals_the_tile_kernel(hip):
             (dec.run_u8 if u8 else dec.run)(ptr(d_u8 if u8 else d_cf), 0, ptr(out), k0, k0 + count, seam)
             torch.cuda.synchronize()
             outs.append(out)
-        hip.lib.sdrhip_debug_set_systolic(1)
+        hip.lib.sdrhip_debug_set_systolic(2)
         took += hip.lib.sdrhip_debug_systolic_launches() - before
         assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (trial, u8, count, k0, seam)
         assert torch.isnan(outs[0][2 * count:]).all()

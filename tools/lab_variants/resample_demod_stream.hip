@@ -25,8 +25,8 @@
 #include <atomic>
 #include <stdlib.h>
 #include <type_traits>
-#include "kernels.hpp"
-#include "demod.hpp"
+#include "lab.hpp"
+#include "demod_forms.hpp"
 
 #ifndef SDRHIP_RSTREAM_MINW
 #define SDRHIP_RSTREAM_MINW 3          // waves per SIMD the register budget is set for (= workgroups per CU)

@@ -11,36 +11,87 @@
 //
 // Arithmetic contract as in kernels_generic.hip (-ffp-contract=off, lane orders of the
 // AVX variants: resampleAVXRR resample.c:70-87, filterAVXSymmetricRR filter.c:60-68).
+#include <atomic>
 #include "kernels.hpp"
 #include "crossfix.hpp"
 #include "demod.hpp"
+
+#ifndef SDRHIP_LOADER_SEL
+#define SDRHIP_LOADER_SEL 1
+#endif
+#ifndef SDRHIP_LOADER_FLAT
+#define SDRHIP_LOADER_FLAT 1
+#endif
+#ifndef SDRHIP_RESAMP_DEMOD_NT
+#define SDRHIP_RESAMP_DEMOD_NT 256
+#endif
+#ifndef SDRHIP_RESAMP_MINB
+#define SDRHIP_RESAMP_MINB 6   // (HIP: minimum WAVES per SIMD) 78 VGPRs, six waves per SIMD: fused kernel 0.232 -> 0.227 ms per pass (same-box A/B, 4 / 5 / 6)
+#endif
+#ifndef SDRHIP_LOADER_ILP
+#define SDRHIP_LOADER_ILP 1
+#endif
+#ifndef SDRHIP_LOADER_TABLE
+#define SDRHIP_LOADER_TABLE 1
+#endif
+#ifndef SDRHIP_LOADER_PAIR
+#define SDRHIP_LOADER_PAIR 0   // round 5: two samples per step with packed arithmetic (demod.hpp: fm_phase_common_tbl2): same bits, 97 instructions
+                               // per pair instead of 140 -- and SLOWER (0.207 against 0.198 ms, five waves per SIMD instead of six): a scalar operation
+                               // issued next to a packed one costs a packed one's four cycles (tools/k4lab/issue_bench.hip)
+#endif
+#ifndef SDRHIP_LOADER_COMMON
+#define SDRHIP_LOADER_COMMON 1
+#endif
 
 namespace sdrhip {
 
 namespace {
 
-// K3 stand-alone: the common case of fmDemod (demod.hpp: fm_phase_common_tbl, atanf's argument reduction looked up in an LDS table)
-// for every lane, a wave vote, and the full select form behind it for a wave that holds anything else -- the fused loader's form.
-// (Rounds 1-5 measured four other restatements of the same arithmetic -- ternaries, selects, the vote without the table, packed
-// pairs -- all bit-equal and slower: tools/lab_variants/, LABNOTES.)
+// FORM 3 (the default): form 2 with atanf's argument reduction looked up in an LDS table (demod.hpp: fm_phase_common_tbl; the fused
+// loader's form): 0.141 ms per 2^26 samples against 0.164 for form 2.
+// FORM 0: nested ternaries (control flow per argument range; rounds 1-3's stand-alone form); 1: selects; 2: the common-case form
+// with a wave vote and the select form behind it (round 4: per 2^26
+// samples 0.161 ms against 0.172 for the ternaries and 0.183 for the selects).  All three: same bits
+// (tests/test_gpu_stream.py::test_fm_demod_random_bit_patterns runs every form over arbitrary bit patterns).
+template <int FORM>
 __device__ __forceinline__ float4 fm_phase_quad(float2 prev, float2 s0, float2 s1, float2 s2, float2 s3, const float* atbl)
 {
-    const float2 v[5] = {prev, s0, s1, s2, s3};
-    float y[4];
-    bool rare = false;
+    float4 r;
+    if constexpr (FORM == 4) {
+        // the packed pair form (demod.hpp: fm_phase_common_tbl2; round 5, measured slower, kept under the same tests)
+        bool q0, q1;
+        const float2 a = fm_phase_common_tbl2(s0, prev, s1, s0, q0, atbl), b = fm_phase_common_tbl2(s2, s1, s3, s2, q1, atbl);
+        r = make_float4(a.x, a.y, b.x, b.y);
+        if (__any(q0 | q1)) r = make_float4(fm_phase_sel(s0, prev), fm_phase_sel(s1, s0), fm_phase_sel(s2, s1), fm_phase_sel(s3, s2));
+    } else if constexpr (FORM == 3) {
+        const float2 v[5] = {prev, s0, s1, s2, s3};
+        float y[4];
+        bool rare = false;
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        bool q;
-        y[e] = fm_phase_common_tbl(v[e + 1], v[e], q, atbl);
-        rare |= q;
-    }
-    if (__any(rare)) {
+        for (int e = 0; e < 4; e++) {
+            bool q;
+            y[e] = fm_phase_common_tbl(v[e + 1], v[e], q, atbl);
+            rare |= q;
+        }
+        if (__any(rare)) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) y[e] = fm_phase_sel(v[e + 1], v[e]);
+            for (int e = 0; e < 4; e++) y[e] = fm_phase_sel(v[e + 1], v[e]);
+        }
+        r = make_float4(y[0], y[1], y[2], y[3]);
+    } else if constexpr (FORM == 0) {
+        r.x = fm_phase_tern(s0, prev); r.y = fm_phase_tern(s1, s0); r.z = fm_phase_tern(s2, s1); r.w = fm_phase_tern(s3, s2);
+    } else if constexpr (FORM == 1) {
+        r.x = fm_phase_sel(s0, prev); r.y = fm_phase_sel(s1, s0); r.z = fm_phase_sel(s2, s1); r.w = fm_phase_sel(s3, s2);
+    } else {
+        const float2 v[5] = {prev, s0, s1, s2, s3};
+        float y[4];
+        fm_phase_voted<4>(v, y);
+        r = make_float4(y[0], y[1], y[2], y[3]);
     }
-    return make_float4(y[0], y[1], y[2], y[3]);
+    return r;
 }
 
+template <int FORM>
 __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__ in, float* __restrict__ out, int64_t count,
                                                         int has_prev, float last_re, float last_im, int out_vec)
 {
@@ -49,9 +100,11 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
     const float2* in2 = reinterpret_cast<const float2*>(in);
     const int64_t nquad = count >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    __shared__ __attribute__((aligned(16))) float atbl[kAtanRows * kAtanRowFloats];
-    atan_table_fill(atbl, threadIdx.x);
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) float atbl[FORM >= 3 ? kAtanRows * kAtanRowFloats : 4];
+    if constexpr (FORM >= 3) {
+        atan_table_fill(atbl, threadIdx.x);
+        __syncthreads();
+    }
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += stride) {
         // (round 4, measured and not kept: 16-byte loads for interior quads 0.164 ms against 0.159 for these five 8-byte loads per
         // 2^26 samples, non-temporal 0.185 -- the decimator's output is still partly in the last-level cache when this kernel reads it)
@@ -59,7 +112,7 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
         float2 prev;
         if (q > 0 || has_prev) prev = in2[4 * q - 1];
         else prev = make_float2(last_re, last_im);
-        const float4 r = fm_phase_quad(prev, s0, s1, s2, s3, atbl);
+        const float4 r = fm_phase_quad<FORM>(prev, s0, s1, s2, s3, atbl);
         if (out_vec) {
             reinterpret_cast<float4*>(out)[q] = r;
         } else {
@@ -73,7 +126,7 @@ __global__ void __launch_bounds__(256) k_fm_demod_fast(const float* __restrict__
         float2 prev;
         if (i > 0 || has_prev) prev = in2[i - 1];
         else prev = make_float2(last_re, last_im);
-        out[i] = fm_phase_sel(cur, prev);
+        out[i] = fm_phase_tern(cur, prev);
     }
 }
 
@@ -367,9 +420,8 @@ __device__ __forceinline__ void demod_edges(const float* __restrict__ in, const 
 // instructions of the scalar walk.  A group whose window starts at an odd float (PRE = 7) pairs the partials (1,2) (3,4) (5,6) (7,0)
 // instead, so that its sample pairs are the same aligned register pairs; taps 0 and 63 are then single operations.  Every partial
 // still adds its products in increasing tap order from +0: same bits.
-// __launch_bounds__(NT, 6) (HIP: minimum WAVES per SIMD): 78 VGPRs, six waves per SIMD -- fused kernel 0.232 -> 0.227 ms per pass (same-box A/B, 4 / 5 / 6)
 template <int NG, int NLOOP, int INC0, int INC1, int INC2, int NT, bool DEMOD = false, int L = 8, bool PK = false>
-__global__ void __launch_bounds__(NT, 6) k_resample3_fast(const float* __restrict__ in, int64_t pos0, int ncycles,
+__global__ void __launch_bounds__(NT, SDRHIP_RESAMP_MINB) k_resample3_fast(const float* __restrict__ in, int64_t pos0, int ncycles,
                                                         int64_t avail_total, const float* __restrict__ groups,
                                                         int row_stride, float* __restrict__ out, DemodSide dm)
 {
@@ -395,10 +447,12 @@ __global__ void __launch_bounds__(NT, 6) k_resample3_fast(const float* __restric
         const int m0 = dm.yseam > 0 ? (int)((dm.y_abs0 + base) % dm.yseam) : 0;      // one 64-bit modulo per workgroup
         float2 cur[NP], prv[NP];
         const bool interior = avail >= SPAN && (base > 0 || dm.has_prev);
+#if SDRHIP_LOADER_TABLE
         // atanf's argument reduction as a table in LDS (demod.hpp: fm_phase_common_tbl): 81 rows written by the first 81 threads,
         // visible after a barrier that waits for LDS only -- the global loads below stay in flight across it
         __shared__ __attribute__((aligned(16))) float atbl[kAtanRows * kAtanRowFloats];
         if (interior) atan_table_fill(atbl, threadIdx.x);
+#endif
         if (interior) {
             // interior tile: branch-free loads (a conditional load costs a wait at its join: eleven HBM round trips in a row)
 #pragma unroll
@@ -419,26 +473,51 @@ __global__ void __launch_bounds__(NT, 6) k_resample3_fast(const float* __restric
                 }
             }
         }
-        if (interior) {
+        if (SDRHIP_LOADER_FLAT && interior) {
             // ... and branch-free arithmetic: the phases of a thread's NP - 1 whole rounds as ONE basic block (fmDemod's constants
             // stay in registers across the samples instead of being re-materialised inside eleven guarded blocks, and the samples'
             // dependent chains interleave); only the last, partial round (SPAN - (NP - 1) * NT inputs: part of one wave) is guarded
             static_assert((NP - 1) * NT <= SPAN, "rounds 0 .. NP - 2 are whole");
             float y[NP];
-            // the common case of fmDemod (demod.hpp: fm_phase_common_tbl) for everyone; a sample that is not -- zero or non-finite
+#if SDRHIP_LOADER_COMMON
+            // the common case of fmDemod (demod.hpp: fm_phase_common) for everyone; a sample that is not -- zero or non-finite
             // product, a ratio outside [2^-29, 2^25) -- sends its WAVE through the full form
             bool rare = false;
+#if SDRHIP_LOADER_TABLE
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // `interior` is uniform over the workgroup
+#endif
+#if SDRHIP_LOADER_TABLE && SDRHIP_LOADER_PAIR
+            // round 5: two samples per step, packed (demod.hpp: fm_phase_common_tbl2) -- fmDemod here is issue-bound, and the pair
+            // form issues 97 instructions where two single samples issue 140
+#pragma unroll
+            for (int i = 0; i + 1 < NP - 1; i += 2) {
+                bool q;
+                const float2 yp = fm_phase_common_tbl2(cur[i], prv[i], cur[i + 1], prv[i + 1], q, atbl);
+                y[i] = yp.x; y[i + 1] = yp.y;
+                rare |= q;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if ((NP - 1) % 2) {
+                bool q;
+                y[NP - 2] = fm_phase_common_tbl(cur[NP - 2], prv[NP - 2], q, atbl);
+                rare |= q;
+            }
+#else
 #pragma unroll
             for (int i = 0; i < NP - 1; i++) {
                 bool q;
+#if SDRHIP_LOADER_TABLE
                 y[i] = fm_phase_common_tbl(cur[i], prv[i], q, atbl);
+#else
+                y[i] = fm_phase_common(cur[i], prv[i], q);
+#endif
                 rare |= q;
-                // sample after sample, not ten interleaved: every sample keeps three lane masks (SGPR pairs) alive from its first
-                // compare to its last select, and the machine scheduler left alone mixes all ten (measured, fused kernel per pass:
-                // 0.231 ms one at a time, 0.238 in pairs, 0.244 all ten; 0.256 for the select form)
-                __builtin_amdgcn_sched_barrier(0);
+                // sample after sample (SDRHIP_LOADER_ILP = 1), not ten interleaved: every sample keeps three lane masks (SGPR pairs)
+                // alive from its first compare to its last select, and the machine scheduler left alone mixes all ten (measured,
+                // fused kernel per pass: 0.231 ms one at a time, 0.238 in pairs, 0.244 all ten; 0.256 for the select form)
+                if (i % SDRHIP_LOADER_ILP == SDRHIP_LOADER_ILP - 1) __builtin_amdgcn_sched_barrier(0);
             }
+#endif
             // stored before the vote: with the phases needed only after it, the compiler moves most of the arithmetic behind the
             // branch and keeps thirty lane masks alive across it (48 v_writelane + as many v_readlane per thread)
 #pragma unroll
@@ -450,6 +529,12 @@ __global__ void __launch_bounds__(NT, 6) k_resample3_fast(const float* __restric
                     lds[threadIdx.x + i * NT] = y[i];
                 }
             }
+#else
+#pragma unroll
+            for (int i = 0; i < NP - 1; i++) y[i] = fm_phase_sel(cur[i], prv[i]);
+#pragma unroll
+            for (int i = 0; i < NP - 1; i++) lds[threadIdx.x + i * NT] = y[i];
+#endif
             y[NP - 1] = 0.0f;
             if ((int)threadIdx.x + (NP - 1) * NT < SPAN) {
                 y[NP - 1] = fm_phase_sel(cur[NP - 1], prv[NP - 1]);
@@ -471,7 +556,7 @@ __global__ void __launch_bounds__(NT, 6) k_resample3_fast(const float* __restric
             for (int i = 0; i < NP; i++) {
                 const int p = threadIdx.x + i * NT;
                 if (p < SPAN) {
-                    const float y = p < avail ? fm_phase_sel(cur[i], prv[i]) : 0.0f;
+                    const float y = p < avail ? (SDRHIP_LOADER_SEL ? fm_phase_sel(cur[i], prv[i]) : fm_phase_tern(cur[i], prv[i])) : 0.0f;
                     lds[p] = y;
                     if (dm.yseam > 0 && p < avail) {
                         int m = m0 + p;                              // position inside the seam grid: SPAN <= yseam (launcher)
@@ -536,7 +621,7 @@ __global__ void __launch_bounds__(NT, 6) k_resample3_fast(const float* __restric
         for (int g = 0; g < 3; g++) {
             const float* c = groups + g * row_stride;
             float acc[8];
-            {
+            if constexpr (true) {
                 if (PRE[g] % 2 == 0) {
                     f2 A[4];
 #pragma unroll
@@ -590,6 +675,9 @@ __global__ void __launch_bounds__(NT, 6) k_resample3_fast(const float* __restric
 }
 
 
+// which restatement of fmDemod's arithmetic the stand-alone kernel runs (SDRHIP_DEMOD_FORM / sdrhip_debug_set_demod_form)
+std::atomic<int> g_demod_form{getenv("SDRHIP_DEMOD_FORM") ? atoi(getenv("SDRHIP_DEMOD_FORM")) : 3};
+
 }  // namespace
 
 void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int64_t count, bool has_prev, float last_re,
@@ -601,10 +689,15 @@ void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int
     if (blocks < 1) blocks = 1;
     // grid-stride over at most this many workgroups (measured on 2^26 samples: 1024 / 2048 / 4096 / 8192 / 16384 / 65536 workgroups
     // 199 / 188 / 177 / 174 / 171 / 176 us)
-    constexpr int64_t cap = 256 * 64;
+    static const int64_t cap = getenv("SDRHIP_DEMOD_BLOCKS") ? atoll(getenv("SDRHIP_DEMOD_BLOCKS")) : 256 * 64;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(k_fm_demod_fast, dim3((int)blocks), dim3(256), 0, s, d_in_iq, d_out, count, has_prev ? 1 : 0, last_re, last_im, out_vec);
+    const int form = g_demod_form.load(std::memory_order_relaxed);
+    auto k = form == 4 ? k_fm_demod_fast<4> : form == 3 ? k_fm_demod_fast<3> : form == 2 ? k_fm_demod_fast<2> : form == 1 ? k_fm_demod_fast<1> : k_fm_demod_fast<0>;
+    hipLaunchKernelGGL(k, dim3((int)blocks), dim3(256), 0, s, d_in_iq, d_out, count, has_prev ? 1 : 0, last_re, last_im, out_vec);
 }
+
+void set_demod_form(int form) { g_demod_form.store(form < 0 || form > 4 ? 0 : form, std::memory_order_relaxed); }
+int demod_form() { return g_demod_form.load(std::memory_order_relaxed); }
 
 bool launch_fir_real8_fast(hipStream_t s, const Geom& g, bool sym, const float* d_taps, int nk, const float* d_cross_taps,
                           const float* d_in, float* d_out, float gain, bool apply_gain, int lanes)
@@ -681,6 +774,13 @@ bool launch_filter_cplx4_fast(hipStream_t s, const Geom& g, const float* d_dup_t
 // output whose phase step is input p of this launch (y_count of them), d_in is then the y BUFFER, which this call fills
 // only where other kernels read it: the first and last kEdge inputs (stand-alone fmDemod launches: the few outputs before the
 // first / after the last whole polyphase cycle) and the neighbourhood of every seam (written by the tile kernel).
+// SDRHIP_RESAMP_PK=0/1: the packed-pair walk of k_resample3_fast (A/B; same bits)
+static bool resample_pk_enabled()
+{
+    static const bool on = getenv("SDRHIP_RESAMP_PK") ? atoi(getenv("SDRHIP_RESAMP_PK")) != 0 : true;
+    return on;
+}
+
 bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& t, const int* increments,
                                const float* d_groups, const float* d_plain_taps, const float* d_in, float* d_out,
                                const float* d_iq, bool iq_has_prev, int64_t y_count, int lanes)
@@ -725,14 +825,25 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
             dm.ykeep = kKeep;
             dm.nedge = kEdge;
             dm.y_count = y_count;
-            // (workgroup size of the fused form, same-box A/B: 128 / 256 / 512 threads 0.197 / 0.196 / 0.2015 ms)
-            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, true, 8, true>), dim3(blocks), dim3(NT), 0, s, d_iq, pos, ncycles,
+            if (launch_resample3_demod_stream(s, d_iq, pos, ncycles, iq_has_prev, y_count, d_groups, t.row_stride, d_out + lead,
+                                              const_cast<float*>(d_in), g.in_base, dm.yseam, kKeep, kEdge)) {
+                // round 5: the streaming form took the whole cycles
+            } else {
+            constexpr int NTD = SDRHIP_RESAMP_DEMOD_NT;          // workgroup size of the fused form (same-box A/B: 128 / 256 / 512 threads 0.197 / 0.196 / 0.2015 ms)
+            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NTD, true, 8, true>), dim3((ncycles + NTD - 1) / NTD), dim3(NTD), 0, s, d_iq, pos, ncycles,
                                avail_total, d_groups, t.row_stride, d_out + lead, dm);
+            }
         } else if (lanes == 4)
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, false, 4>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);
-        else if (t.nloop == 64)         // the packed-pair walk (round 4)
+        else if (t.nloop == 64 && lanes == 8 &&
+                 launch_resample3_systolic(s, d_in, pos, ncycles, avail_total, d_groups, t.row_stride, d_out + lead)) {
+            // round 4: the register-resident systolic walk took the whole cycles (16-byte aligned input, runs that are not launch-bound)
+        } else if (t.nloop == 64 && resample_pk_enabled())
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, false, 8, true>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
+                               d_groups, t.row_stride, d_out + lead, dm);
+        else if (t.nloop == 64)
+            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);
         else
             hipLaunchKernelGGL((k_resample3_fast<3, 16, 4, 3, 3, NT>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,

@@ -22,7 +22,7 @@
 #include <type_traits>
 #include <utility>
 
-#include "kernels.hpp"
+#include "lab.hpp"
 
 namespace sdrhip {
 namespace {

@@ -26,8 +26,8 @@ def main():
     xf = torch.rand(2 * nmax, device="cuda") * 2 - 1
     xu = torch.randint(0, 256, (2 * nmax,), dtype=torch.uint8, device="cuda")
     out = torch.empty(2 * (nmax // 8) + 64, device="cuda")
-    for kind in ("cfloat", "u8"):
-        print(f"== {kind}: B  nwg(systolic)  rounds  systolic_us  tile_us  auto_us  auto_route  auto/best")
+    for kind in (("cfloat", "u8") if len(sys.argv) < 3 else sys.argv[2:]):
+        print(f"== {kind}: B  nwg(systolic)  rounds  systolic(mode 1: non-temporal loads)_us  tile_us  auto_us  auto_route  auto/best")
         for b in sizes:
             n = b * BLOCK
             K = (n - 128) // 8 + 1
