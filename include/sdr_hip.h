@@ -365,8 +365,10 @@ long long sdrhip_debug_resample_cycle_launches(void);
 /* launches of the real decimator kernel for factors 2 / 4 / 8 / 16 (kernels_decimate_real.hip), process-wide */
 long long sdrhip_debug_decimate_real16_launches(void);
 /* Which kernel serves the decimate-by-8, 128-tap, AVX-order first stage: 0 = the LDS-tiled kernel everywhere, 1 = the
- * register-resident systolic kernel (kernels_systolic.hip) wherever its shape fits, 2 (default; SDRHIP_SYSTOLIC sets the initial
- * value) = by launch size and input kind, as measured (tools/route_sweep_fine.py).  Results are identical.
+ * register-resident systolic kernel (kernels_systolic.hip) wherever its shape fits, in its round-5 form (non-temporal loads, seam
+ * fix-up as a second launch), 2 (default; SDRHIP_SYSTOLIC sets the initial value) = the library's own choice: the systolic kernel
+ * with the seam fix-up's workgroups inside its launch and plain / non-temporal loads by launch size (tools/route_sweep_fine.py).
+ * Results are identical.
  * sdrhip_debug_systolic_launches: launches the systolic kernel has served, process-wide; sdrhip_debug_systolic_plan: the strip cut of a
  * launch of `count` outputs (host arithmetic only): strips [0, nwhole) take the unguarded body. */
 void sdrhip_debug_set_systolic(int mode);

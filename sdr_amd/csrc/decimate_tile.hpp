@@ -394,23 +394,27 @@ __global__ void __launch_bounds__(NT) k_decimate_c4(const void* __restrict__ in,
 // windows that overlap almost entirely, so a group of PER threads stages their union
 // (Lp + (PER-1)*D samples, converted once) in LDS with coalesced loads and each
 // thread then walks its own window.  SPW seams per workgroup.
+// layout of the staged union: one float2 of padding after every 8 samples (candidate c then starts at 9c float2 = 18c
+// dwords: 16 distinct bank pairs), rows 16 (mod 32) float2 apart (the two seams of a 32-lane group
+// land on complementary banks): ds_read_b64 conflict-free.
+template <int D, int LP, int PER>
+constexpr int crossfix_row_float2() { return ((LP + (PER - 1) * D + (LP + (PER - 1) * D) / 8 + 31) / 32) * 32 + 16; }
+
+// The work of ONE workgroup of PER * SPW threads: seams [wg * SPW, wg * SPW + SPW) of the launch, `lds` = SPW rows of
+// crossfix_row_float2 float2.  A kernel of its own below (k_decimate_c_crossfix); round 6: also the body of the fix-up
+// workgroups interleaved into the systolic decimator's launch (kernels_systolic.hip).
 template <bool U8, int D, int LP, int PER, int SPW, bool RT = false>
-__global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const float* __restrict__ xtaps,
-                                                                   const void* __restrict__ in, float* __restrict__ out,
-                                                                   int64_t first_seam, int nseams)
+__device__ __forceinline__ void decimate_c_crossfix_wg(float2* __restrict__ lds, int wg, const Geom& g, const float* __restrict__ xtaps,
+                                                       const void* __restrict__ in, float* __restrict__ out, int64_t first_seam, int nseams)
 {
     // RT: the filter has g.Lp <= LP taps (run-time); the staging layout is still the one of LP taps
     const int lp = RT ? g.Lp : LP;
     static_assert(D == 8 && PER == 16 && LP <= 128, "LDS layout below is worked out for 16 candidate slots 8 samples apart");
     constexpr int UNI = LP + (PER - 1) * D;          // samples in the union of one seam's windows
-    // layout: one float2 of padding after every 8 samples (candidate c then starts at 9c float2 = 18c
-    // dwords: 16 distinct bank pairs), rows 16 (mod 32) float2 apart (the two seams of a 32-lane group
-    // land on complementary banks): ds_read_b64 conflict-free.
-    constexpr int ROW = ((UNI + UNI / 8 + 31) / 32) * 32 + 16;
+    constexpr int ROW = crossfix_row_float2<D, LP, PER>();
     static_assert(UNI <= PER * SPW, "one staging pass per seam");
-    __shared__ float2 lds[SPW * ROW];
     const int tid = threadIdx.x;
-    const int seam0 = blockIdx.x * SPW;
+    const int seam0 = wg * SPW;
     const int64_t lo = g.k_begin * D - g.in_base, hi = (g.k_begin + g.count - 1) * (int64_t)D + lp - g.in_base;
     {
         // staging: the PER lanes of a seam load its union with 16-byte vectors, all seams of the
@@ -550,6 +554,15 @@ __global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const
         }
     }
     *reinterpret_cast<float2*>(out + 2 * (m - g.k_begin)) = make_float2(re, im);
+}
+
+template <bool U8, int D, int LP, int PER, int SPW, bool RT = false>
+__global__ void __launch_bounds__(PER * SPW) k_decimate_c_crossfix(Geom g, const float* __restrict__ xtaps,
+                                                                   const void* __restrict__ in, float* __restrict__ out,
+                                                                   int64_t first_seam, int nseams)
+{
+    __shared__ float2 lds[SPW * crossfix_row_float2<D, LP, PER>()];
+    decimate_c_crossfix_wg<U8, D, LP, PER, SPW, RT>(lds, (int)blockIdx.x, g, xtaps, in, out, first_seam, nseams);
 }
 
 // inline_cross: the kernel computes the Cross outputs itself (no fix-up launch); *inlined tells whether the geometry allowed

@@ -186,8 +186,10 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
                              const void* d_in, bool in_is_u8, float* d_out, bool last_tap_zero = false);
 // kernels_systolic.hip (round 4): the One outputs of a decimate-by-8, 128-tap, AVX-order launch by the register-resident systolic
 // walk (d_taps: plain taps, pre-scaled by 1/128 for u8 input).  false = not this shape / too small, nothing launched.
+// seams_done (with d_cross_taps, the plain taps of the sequential outputs): set when the launch also computed its Cross outputs
+// (fix-up workgroups interleaved into the same launch, round 6) -- the caller then skips its fix-up launch.
 bool launch_decimate_c4_systolic(hipStream_t s, const Geom& g, const float* d_taps, int P, const void* d_in, bool in_is_u8, float* d_out,
-                                 bool last_tap_zero);
+                                 bool last_tap_zero, const float* d_cross_taps = nullptr, bool* seams_done = nullptr);
 void systolic_plan(int count, int* nstrips, int* nwhole);   // host arithmetic of the strip cut (CPU-testable)
 void set_systolic(int mode);        // 0 = the tile kernel everywhere, 1 = the systolic kernel wherever its shape fits, 2 (default) = by launch size
 long long systolic_launch_count();  // diagnostics

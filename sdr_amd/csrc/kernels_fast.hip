@@ -74,7 +74,7 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
         // 127 taps padded to 128 (the FM chain's decimator).  Launches that are not launch-bound take the register-resident
         // systolic kernel (kernels_systolic.hip, round 4: no LDS in the MAC loop; same bits); the padding tap's MACs are skipped
         // on u8 input (decimate_tile.hpp: PSKIP)
-        if (!inl && launch_decimate_c4_systolic(s, g, d_plain_taps, P, d_in, in_is_u8, d_out, in_is_u8 && last_tap_zero)) {
+        if (!inl && launch_decimate_c4_systolic(s, g, d_plain_taps, P, d_in, in_is_u8, d_out, in_is_u8 && last_tap_zero, d_cross_taps, &inlined)) {
         } else if (in_is_u8 && last_tap_zero) launch_c4<8, 128, 2, 256, true, 8, false, 4, 0, 1>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
         else if (in_is_u8) launch_c4<8, 128, 2, 256, true>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
         else launch_c4<8, 128, 2, 256, false>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);

@@ -35,6 +35,7 @@
 #include <utility>
 
 #include "kernels.hpp"
+#include "decimate_tile.hpp"      // decimate_c_crossfix_wg: the seam fix-up's workgroup body (round 6: interleaved into this kernel's launch)
 
 namespace sdrhip {
 namespace {
@@ -151,9 +152,29 @@ __device__ __forceinline__ void load_strip(const void* __restrict__ in, int64_t 
 // skipped -- exact, see decimate_tile.hpp:mac_window.
 // (Round 4 also built fmDemod into this kernel's epilogue -- K2 + K3 in one launch, the decimated stream never written -- bit-equal and
 // slower: the pair 0.91 ms against 0.69 + 0.16.  tools/lab_variants/decimate_demod_systolic.hip, LABNOTES.)
-template <bool U8, int PSKIP, bool WHOLE, bool NTL>
+// FIX (round 6): the launch computes its own Cross outputs.  The 15 outputs in front of every buffer boundary (window straddling a
+// multiple of the reference's block, FilterInternal.hs:397-402: sequential order) used to be rewritten by a fix-up launch AFTER this
+// kernel -- 15 us of load -> barrier -> 128-step dependent chains on an otherwise idle chip (6.7 % of BASELINE configs[1]'s period).
+// Now the fix-up's workgroups are part of THIS launch, spread through it in blocks of 64 (one block every `period_g` groups of 64
+// workgroups: the XCD-aware order of the strips is kept), and run beside the strips; a strip does not store the Cross outputs it
+// computed in SIMD order (which of a strip's outputs are Cross is scalar arithmetic: k mod seamK >= seamK - 15), so the two kinds of
+// workgroup write disjoint outputs and need no order between them.
+struct SystolicFix {
+    Geom g;                 // the launch's geometry as the fix-up kernel takes it
+    const float* xtaps;     // plain taps of the sequential outputs
+    int64_t first_seam;
+    int nseams;
+    int nfix_groups;        // blocks of 64 fix-up workgroups
+    int period_g;           // group G (= blockIdx.x >> 6) is a fix-up block when G % period_g == period_g - 1 and G / period_g < nfix_groups
+    int seamK;              // outputs per buffer (seam_block / 8), >= 256
+    int k0mod;              // k_begin mod seamK
+};
+constexpr int kFixPer = 16, kFixSpw = 16;      // 16 candidate slots per seam, 16 seams per workgroup (k_decimate_c_crossfix's shape)
+constexpr int kFixLdsFloats = 2 * kFixSpw * crossfix_row_float2<8, 128, kFixPer>();
+
+template <bool U8, int PSKIP, bool WHOLE, bool NTL, bool FIX>
 __device__ __forceinline__ void systolic_strip(const void* __restrict__ in, int64_t x0, int strip, int count, const float* __restrict__ taps,
-                                               float* __restrict__ out, float* __restrict__ wbuf, int lane)
+                                               float* __restrict__ out, float* __restrict__ wbuf, int lane, int seamK, int k0mod)
 {
     f2 S[32];
     const int64_t strip_s0 = x0 + (int64_t)kStripStep * strip;
@@ -200,36 +221,67 @@ __device__ __forceinline__ void systolic_strip(const void* __restrict__ in, int6
 #pragma unroll
     for (int i = 0; i < 4; i++) res[i] = (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
     res[0] = f2{dpp_shr1(res[0].x), dpp_shr1(res[0].y)};           // output 0 of the group sat one lane below
+    // FIX: position of the strip's first output inside its buffer (wave-uniform: scalar arithmetic), and whether any of its 240
+    // outputs is one of the buffer's last 15 (seamK >= 256 > 240: the strip wraps the buffer grid at most once)
+    int km_strip = 0;
+    bool strip_cross = false;
+    if constexpr (FIX) {
+        const int su = __builtin_amdgcn_readfirstlane(strip);
+        km_strip = (int)(((unsigned)k0mod + (unsigned)((kStripOuts * (int64_t)su) % seamK)) % (unsigned)seamK);
+        strip_cross = km_strip + (kStripOuts - 1) >= seamK - 15;
+    }
     if (lane >= 4) {
         const int o = kStripOuts * strip + 4 * (lane - 4);
-        if (WHOLE || o + 4 <= count) {
+        bool cross[4] = {false, false, false, false};
+        bool any_cross = false;
+        if constexpr (FIX) {
+            if (strip_cross) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    int km = km_strip + 4 * (lane - 4) + i;
+                    if (km >= seamK) km -= seamK;
+                    cross[i] = km >= seamK - 15;
+                    any_cross |= cross[i];
+                }
+            }
+        }
+        if ((WHOLE || o + 4 <= count) && !any_cross) {
             float4* dst = reinterpret_cast<float4*>(out + 2 * (int64_t)o);
             dst[0] = make_float4(res[0].x, res[0].y, res[1].x, res[1].y);
             dst[1] = make_float4(res[2].x, res[2].y, res[3].x, res[3].y);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                if (o + i < count) *reinterpret_cast<float2*>(out + 2 * (int64_t)(o + i)) = make_float2(res[i].x, res[i].y);
+                if ((WHOLE || o + i < count) && !cross[i]) *reinterpret_cast<float2*>(out + 2 * (int64_t)(o + i)) = make_float2(res[i].x, res[i].y);
         }
     }
 }
 
-template <bool U8, int PSKIP, bool NTL = true>
+template <bool U8, int PSKIP, bool NTL = true, bool FIX = false>
 __global__ void __launch_bounds__(64 * kWavesPerWg, 4) k_decimate_systolic(const void* __restrict__ in, int64_t x0 /* sample of output 0's window in `in` */,
                                                                           int count, const float* __restrict__ taps, float* __restrict__ out,
-                                                                          int nwhole /* strips [0, nwhole) are whole */, int nstrips)
+                                                                          int nwhole /* strips [0, nwhole) are whole */, int nstrips, SystolicFix fx)
 {
-    __shared__ __attribute__((aligned(16))) float tbuf[U8 ? 4 : kWavesPerWg * kCfWaveDw];
+    constexpr int kStripLds = U8 ? 4 : kWavesPerWg * kCfWaveDw;
+    __shared__ __attribute__((aligned(16))) float tbuf[FIX && kFixLdsFloats > kStripLds ? kFixLdsFloats : kStripLds];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int b = blockIdx.x;
+    if constexpr (FIX) {
+        const int G = b >> 6, q = G / fx.period_g;
+        if (q < fx.nfix_groups && G - q * fx.period_g == fx.period_g - 1) {
+            decimate_c_crossfix_wg<U8, 8, 128, kFixPer, kFixSpw>(reinterpret_cast<float2*>(tbuf), 64 * q + (b & 63), fx.g, fx.xtaps, in, out, fx.first_seam, fx.nseams);
+            return;
+        }
+        b -= 64 * (q < fx.nfix_groups ? q : fx.nfix_groups);          // fix-up blocks in front of this group
+    }
     // XCD-aware order (the tile kernel's): workgroup b runs on XCD b % 8; within every 64 consecutive workgroups XCD x takes 8
     // consecutive ones, so 7 of 8 strip-to-strip overlaps of a workgroup's neighbours hit in the same L2
-    const int b = blockIdx.x;
     const int wg = (b & ~63) + ((b & 7) << 3) + ((b >> 3) & 7);
     const int strip = wg * kWavesPerWg + wave;
     if (strip >= nstrips) return;
     float* wbuf = tbuf + (U8 ? 0 : kCfWaveDw * wave);
-    if (strip < nwhole) systolic_strip<U8, PSKIP, true, NTL>(in, x0, strip, count, taps, out, wbuf, lane);
-    else systolic_strip<U8, PSKIP, false, NTL>(in, x0, strip, count, taps, out, wbuf, lane);
+    if (strip < nwhole) systolic_strip<U8, PSKIP, true, NTL, FIX>(in, x0, strip, count, taps, out, wbuf, lane, fx.seamK, fx.k0mod);
+    else systolic_strip<U8, PSKIP, false, NTL, FIX>(in, x0, strip, count, taps, out, wbuf, lane, fx.seamK, fx.k0mod);
 }
 
 std::atomic<int>& systolic_flag()
@@ -266,10 +318,12 @@ long long systolic_launch_count() { return g_systolic_launches.load(); }
 // lines); below it both forms are within noise of each other and of launch latency.
 constexpr int64_t kPlainLoadMinOutputs = (int64_t)1000 * 1024;      // ~64 MB of cfloat input
 constexpr int64_t kPlainLoadMaxOutputs = (int64_t)4400 * 1024;      // ~285 MB
+constexpr int64_t kFixInsideMaxOutputs = (int64_t)1 << 23;          // the seam fix-up's workgroups inside the launch up to this size
 
 bool launch_decimate_c4_systolic(hipStream_t s, const Geom& g, const float* d_taps, int P, const void* d_in, bool in_is_u8, float* d_out,
-                                 bool last_tap_zero)
+                                 bool last_tap_zero, const float* d_cross_taps, bool* seams_done)
 {
+    if (seams_done) *seams_done = false;
     const int mode = systolic_flag().load(std::memory_order_relaxed);
     if (mode == 0) return false;
     if (g.I != 1 || g.D != 8 || P != 128 || g.Lp != 128 || g.count < 64 * kStripOuts * kWavesPerWg) return false;
@@ -280,15 +334,48 @@ bool launch_decimate_c4_systolic(hipStream_t s, const Geom& g, const float* d_ta
     int nstrips, nwhole;
     systolic_plan(g.count, &nstrips, &nwhole);
     const int nwg = (nstrips + kWavesPerWg - 1) / kWavesPerWg;
-    const dim3 grid(((nwg + 63) / 64) * 64), block(64 * kWavesPerWg);
-    if (in_is_u8) {
-        if (last_tap_zero) hipLaunchKernelGGL((k_decimate_systolic<true, 1>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips);
-        else hipLaunchKernelGGL((k_decimate_systolic<true, 0>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips);
-    } else if (mode == 2 && g.count >= kPlainLoadMinOutputs && g.count <= kPlainLoadMaxOutputs) {
-        hipLaunchKernelGGL((k_decimate_systolic<false, 0, false>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips);
-    } else {
-        hipLaunchKernelGGL((k_decimate_systolic<false, 0, true>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips);
+    int groups = (nwg + 63) / 64;
+    // the launch's own seams (those strictly inside its samples), as the fix-up launch of kernels_fast.hip counts them
+    SystolicFix fx = {};
+    bool fix = false;
+    // Inside the launch up to 2^23 outputs (2^26 samples): there the fix-up is latency -- a second launch, 10-15 us of dependent chains
+    // on an idle chip -- and hiding it gains 3-30 % (2^22 ... 2^25 samples: 15.6 -> 10.8, 24.3 -> 18.0, 34.1 -> 28.6, 59.7 -> 57.9 us
+    // cfloat; u8 13.2 -> 9.8 ... 45.9 -> 42.3).  Past that the chip is issue- and power-bound for the whole launch and the fix-up's
+    // instructions cost the same wherever they run, plus what they disturb: 1.5-4 % SLOWER inside at 2^27 ... 2^29 samples
+    // (profiles/r06/k2_fix_inside_ab_sizes.txt) -- those launches keep the second launch.
+    if (mode == 2 && g.count <= kFixInsideMaxOutputs && seams_done && g.seamBI > 0 && g.seamBI % 8 == 0 && g.seamBI / 8 >= 256 && g.seamBI / 8 < (1 << 30) && d_cross_taps != nullptr) {
+        const int64_t v_lo = g.k_begin * g.D, v_hi = (g.k_begin + g.count - 1) * g.D + g.Lp;
+        const int64_t first = v_lo / g.seamBI + 1, last = (v_hi - 1) / g.seamBI;
+        if (last >= first && last - first + 1 < (int64_t)1 << 30) {
+            fx.g = g;
+            fx.xtaps = d_cross_taps;
+            fx.first_seam = first;
+            fx.nseams = (int)(last - first + 1);
+            fx.nfix_groups = ((fx.nseams + kFixSpw - 1) / kFixSpw + 63) / 64;
+            fx.period_g = (groups + fx.nfix_groups) / fx.nfix_groups;
+            fx.seamK = (int)(g.seamBI / 8);
+            fx.k0mod = (int)(g.k_begin % fx.seamK);
+            fix = fx.period_g >= 2;
+        } else if (last < first) {
+            *seams_done = true;          // no boundary inside the launch: nothing to fix up
+        }
     }
+    if (fix) {
+        groups += fx.nfix_groups;
+        *seams_done = true;
+    }
+    const dim3 grid(groups * 64), block(64 * kWavesPerWg);
+    const bool plain = !in_is_u8 && mode == 2 && g.count >= kPlainLoadMinOutputs && g.count <= kPlainLoadMaxOutputs;
+#define SYS(U8V, PSKIPV, NTLV)                                                                                                                      \
+    do {                                                                                                                                            \
+        if (fix) hipLaunchKernelGGL((k_decimate_systolic<U8V, PSKIPV, NTLV, true>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips, fx); \
+        else hipLaunchKernelGGL((k_decimate_systolic<U8V, PSKIPV, NTLV, false>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips, fx); \
+    } while (0)
+    if (in_is_u8 && last_tap_zero) SYS(true, 1, true);
+    else if (in_is_u8) SYS(true, 0, true);
+    else if (plain) SYS(false, 0, false);
+    else SYS(false, 0, true);
+#undef SYS
     g_systolic_launches.fetch_add(1, std::memory_order_relaxed);
     return true;
 }

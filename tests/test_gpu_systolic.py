@@ -86,14 +86,15 @@ def test_same_bits_as_the_tile_kernel_at_2_to_the_24(hip, counted, u8):
     dec = hip.Decimator(8, taps, hip.ORDER_AVX, complex_=True)
     K = (n - 128) // 8 + 1
     outs = []
-    for on in (1, 0):
+    for on in (1, 0, 2):          # round 5's form (fix-up as a second launch), the tile kernel, the library's own choice (fix-up workgroups inside the launch)
         hip.lib.sdrhip_debug_set_systolic(on)
         out = dev_empty_f32(2 * K)
         (dec.run_u8 if u8 else dec.run)(ptr(d_in), 0, ptr(out), 0, K, B)
         torch.cuda.synchronize()
         outs.append(out)
-    assert counted() == 1
+    assert counted() == 2
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    assert torch.equal(outs[2].view(torch.int32), outs[1].view(torch.int32)), "seam fix-up inside the systolic launch"
 
 
 def test_random_launch_geometry_equals_the_tile_kernel(hip):
@@ -121,7 +122,7 @@ def test_random_launch_geometry_equals_the_tile_kernel(hip):
             k0 = min(k0, (kmax - count) // 2 * 2)
         outs = []
         before = hip.lib.sdrhip_debug_systolic_launches()
-        for on in (1, 0):
+        for on in (1, 0, 2):      # 2: the library's own choice -- seam fix-up inside the launch where the seam is a multiple of 8 of at least 2048 samples
             hip.lib.sdrhip_debug_set_systolic(on)
             out = torch.full((2 * count + 8,), float("nan"), device="cuda")
             (dec.run_u8 if u8 else dec.run)(ptr(d_u8 if u8 else d_cf), 0, ptr(out), k0, k0 + count, seam)
@@ -130,5 +131,6 @@ def test_random_launch_geometry_equals_the_tile_kernel(hip):
         hip.lib.sdrhip_debug_set_systolic(2)
         took += hip.lib.sdrhip_debug_systolic_launches() - before
         assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (trial, u8, count, k0, seam)
-        assert torch.isnan(outs[0][2 * count:]).all()
-    assert took == 24 * scale
+        assert torch.equal(outs[2].view(torch.int32), outs[1].view(torch.int32)), ("in-launch fix-up", trial, u8, count, k0, seam)
+        assert torch.isnan(outs[0][2 * count:]).all() and torch.isnan(outs[2][2 * count:]).all()
+    assert took == 2 * 24 * scale
