@@ -18,6 +18,7 @@
 #include <thread>
 #include <vector>
 
+#include <exception>
 #include "descriptors.hpp"
 
 using namespace sdrhip;
@@ -659,7 +660,12 @@ struct CopyPool {
     std::atomic<size_t> next{0};
     int generation = 0, active = 0;
     bool stop = false;
-    int helpers = getenv("SDRHIP_COPY_THREADS") ? atoi(getenv("SDRHIP_COPY_THREADS")) : 3;
+    // helper threads beside the caller's own (SDRHIP_COPY_THREADS, clamped to 0 .. 16; 0 = plain memcpy)
+    int helpers = [] {
+        const char* e = getenv("SDRHIP_COPY_THREADS");
+        const long v = e ? strtol(e, nullptr, 10) : 3;
+        return (int)(v < 0 ? 0 : v > 16 ? 16 : v);
+    }();
 
     void drain()
     {
@@ -689,8 +695,20 @@ struct CopyPool {
             memcpy(d, s, n);
             return;
         }
-        if (workers.empty())
-            for (int i = 0; i < helpers; i++) workers.emplace_back([this] { worker(); });
+        if (workers.empty()) {
+            // a thread that cannot be started (std::system_error: resource limits) must not unwind through the extern "C" push: the
+            // copy goes on with the helpers that did start, or as a plain memcpy
+            try {
+                for (int i = 0; i < helpers; i++) workers.emplace_back([this] { worker(); });
+            } catch (const std::exception&) {
+                helpers = (int)workers.size();
+            }
+            if (workers.empty()) {
+                helpers = 0;
+                memcpy(d, s, n);
+                return;
+            }
+        }
         {
             std::lock_guard<std::mutex> lk(m);
             dst = d; src = s; bytes = n;

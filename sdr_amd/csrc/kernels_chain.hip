@@ -368,117 +368,128 @@ __device__ __forceinline__ void demod_edges(const float* __restrict__ in, const 
 // instead, so that its sample pairs are the same aligned register pairs; taps 0 and 63 are then single operations.  Every partial
 // still adds its products in increasing tap order from +0: same bits.
 // __launch_bounds__(NT, 6) (HIP: minimum WAVES per SIMD): 78 VGPRs, six waves per SIMD -- fused kernel 0.232 -> 0.227 ms per pass (same-box A/B, 4 / 5 / 6)
+// wave_shr:1 -- lane l takes lane l - 1's `src`; lane 0, which has no source, keeps `old`
+__device__ __forceinline__ float dpp_shr1_or(float old, float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), 0x138, 0xf, 0xf, false));
+}
+
+constexpr int kDemodCycles = 249;   // DEMOD: cycles per workgroup -- 2551 inputs + the predecessor + the 16-byte phase fit five rounds of 256 pairs exactly
+
+// DEMOD loader (round 6; rounds 4-5 loaded every sample and its predecessor by two 8-byte loads, 22 per thread: tools/lab_variants/
+// resample_loader_variants.hip): a wave owns 320 consecutive PAIRS of samples, round i = pairs [64 i, 64 i + 64) of them: one 16-byte
+// load per pair (five per thread), the predecessor of a pair's first sample from the lane below (DPP wave_shr:1), for lane 0 from lane
+// 63 of the round before (v_readlane) -- only round 0 loads it (a wave-uniform address).  The tile is 249 cycles: ten samples per
+// thread, no ragged round.  Same bits; the fused stage 0.1927-0.1941 ms against 0.1965-0.2019 per 2^29-sample pass, alternating in one
+// process (profiles/r06/k4_pair_loader_ab.txt) -- 1.7 %, and with that the kernel is declared final: it sits at 1.4 x its issue floor
+// with its loads hidden behind other workgroups (LABNOTES), and fewer load instructions were the last thing left to take out.
 template <int NG, int NLOOP, int INC0, int INC1, int INC2, int NT, bool DEMOD = false, int L = 8, bool PK = false>
 __global__ void __launch_bounds__(NT, 6) k_resample3_fast(const float* __restrict__ in, int64_t pos0, int ncycles,
                                                         int64_t avail_total, const float* __restrict__ groups,
                                                         int row_stride, float* __restrict__ out, DemodSide dm)
 {
     static_assert(NG == 3, "specialised for three polyphase groups");
+    static_assert(!DEMOD || NT == 256, "the fused fmDemod loader is written for four waves");
     constexpr int PERIOD = INC0 + INC1 + INC2;
     constexpr int PRE[3] = {0, INC0, INC0 + INC1};
     constexpr int WIN = PRE[2] + NLOOP;                 // floats one thread reads
-    constexpr int SPAN = (NT - 1) * PERIOD + WIN;       // floats one workgroup reads
+    constexpr int CYC = DEMOD ? kDemodCycles : NT;      // polyphase cycles per workgroup
+    constexpr int SPAN = (CYC - 1) * PERIOD + WIN;      // floats one workgroup reads
     constexpr int SPAN4 = (SPAN + 3) / 4;
-    __shared__ __attribute__((aligned(16))) float lds[SPAN4 * 4 + 4];
+    // DEMOD: y of sample p (relative to the tile's first input) lives at lds[2 + p], p = -2 .. 2557: every pair is stored unguarded
+    constexpr int LOFF = DEMOD ? 2 : 0;
+    __shared__ __attribute__((aligned(16))) float lds[DEMOD ? 2564 : SPAN4 * 4 + 4];
 
-    const int cyc0 = blockIdx.x * NT;
+    const int cyc0 = blockIdx.x * CYC;
     const int64_t base = pos0 + (int64_t)cyc0 * PERIOD;  // first input of this workgroup, relative to `in`
     const int64_t av64 = avail_total - (int64_t)cyc0 * PERIOD;
     const int avail = av64 > SPAN ? SPAN : (int)av64;
     if constexpr (DEMOD) {
-        // the keep-zone positions below wrap the seam grid at most once (`if (m >= yseam) m -= yseam`): the launcher admits yseam >= 4096
-        static_assert(SPAN <= 4096, "a tile of the fused loader must not be longer than the shortest seam block the launcher admits");
-        // thread t demodulates inputs t, t + NT, ...: two 8-byte loads per input (the sample and its predecessor: the
-        // same cache lines one lane over), all of them in flight before the first phase is computed
-        constexpr int NP = (SPAN + NT - 1) / NT;
+        static_assert(SPAN <= 4096 && SPAN + 9 <= 2560, "five rounds of 256 pairs cover the tile whatever the 16-byte phase");
+        constexpr int R = 5;
         const float2* z = reinterpret_cast<const float2*>(in) + base;
-        const int m0 = dm.yseam > 0 ? (int)((dm.y_abs0 + base) % dm.yseam) : 0;      // one 64-bit modulo per workgroup
-        float2 cur[NP], prv[NP];
-        const bool interior = avail >= SPAN && (base > 0 || dm.has_prev);
-        // atanf's argument reduction as a table in LDS (demod.hpp: fm_phase_common_tbl): 81 rows written by the first 81 threads,
-        // visible after a barrier that waits for LDS only -- the global loads below stay in flight across it
+        const int m0 = dm.yseam > 0 ? (int)((dm.y_abs0 + base) % dm.yseam) : 0;
+        // first pair: starts at the even (16-byte aligned) sample at or below the tile's predecessor sample base - 1
+        const int dd = 1 + (int)(((reinterpret_cast<uintptr_t>(in) >> 3) + (uint64_t)(base - 1)) & 1);     // tile input 0 is sample dd of the pair stream
+        const bool interior = av64 >= SPAN + 12 && base >= 4;
         __shared__ __attribute__((aligned(16))) float atbl[kAtanRows * kAtanRowFloats];
-        if (interior) atan_table_fill(atbl, threadIdx.x);
         if (interior) {
-            // interior tile: branch-free loads (a conditional load costs a wait at its join: eleven HBM round trips in a row)
+            atan_table_fill(atbl, threadIdx.x);
+            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+            const int j0 = 64 * R * wv + ln;                          // this thread's pair in round 0
+            const char* src = reinterpret_cast<const char*>(z - dd);  // sample 0 of the pair stream
+            float4 v[R];
 #pragma unroll
-            for (int i = 0; i < NP; i++) {
-                int p = threadIdx.x + i * NT;
-                p = p < SPAN ? p : SPAN - 1;
-                cur[i] = z[p];
-                prv[i] = z[p - 1];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NP; i++) {
-                const int p = threadIdx.x + i * NT;
-                cur[i] = prv[i] = make_float2(0.0f, 0.0f);
-                if (p < avail) {
-                    cur[i] = z[p];
-                    if (base + p > 0 || dm.has_prev) prv[i] = z[p - 1];
-                }
-            }
-        }
-        if (interior) {
-            // ... and branch-free arithmetic: the phases of a thread's NP - 1 whole rounds as ONE basic block (fmDemod's constants
-            // stay in registers across the samples instead of being re-materialised inside eleven guarded blocks, and the samples'
-            // dependent chains interleave); only the last, partial round (SPAN - (NP - 1) * NT inputs: part of one wave) is guarded
-            static_assert((NP - 1) * NT <= SPAN, "rounds 0 .. NP - 2 are whole");
-            float y[NP];
-            // the common case of fmDemod (demod.hpp: fm_phase_common_tbl) for everyone; a sample that is not -- zero or non-finite
-            // product, a ratio outside [2^-29, 2^25) -- sends its WAVE through the full form
+            for (int i = 0; i < R; i++) v[i] = *reinterpret_cast<const float4*>(src + 16u * (unsigned)(j0 + 64 * i));
+            // the wave's first predecessor: a wave-uniform address that must NOT become a scalar load (SMEM returns out of order: with an
+            // s_load of HBM data outstanding every LDS wait below would be lgkmcnt(0)); the offset goes through a VGPR
+            unsigned po = 16u * (unsigned)(64 * R * wv);
+            asm volatile("" : "+v"(po));
+            const float2 pl = *reinterpret_cast<const float2*>(src + po - 8);
+            auto pred = [&](int i) {
+                float2 o = pl;
+                if (i > 0) o = make_float2(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i - 1].z), 63)),
+                                           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i - 1].w), 63)));
+                return make_float2(dpp_shr1_or(o.x, v[i].z), dpp_shr1_or(o.y, v[i].w));
+            };
+            float2 y[R];
             bool rare = false;
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // `interior` is uniform over the workgroup
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the table; `interior` is uniform over the workgroup
 #pragma unroll
-            for (int i = 0; i < NP - 1; i++) {
-                bool q;
-                y[i] = fm_phase_common_tbl(cur[i], prv[i], q, atbl);
-                rare |= q;
-                // sample after sample, not ten interleaved: every sample keeps three lane masks (SGPR pairs) alive from its first
-                // compare to its last select, and the machine scheduler left alone mixes all ten (measured, fused kernel per pass:
-                // 0.231 ms one at a time, 0.238 in pairs, 0.244 all ten; 0.256 for the select form)
+            for (int i = 0; i < R; i++) {
+                const float2 A = make_float2(v[i].x, v[i].y), B = make_float2(v[i].z, v[i].w);
+                const float2 pv = pred(i);
+                bool q0, q1;
+                y[i].x = fm_phase_common_tbl(A, pv, q0, atbl);
+                __builtin_amdgcn_sched_barrier(0);
+                y[i].y = fm_phase_common_tbl(B, A, q1, atbl);
+                rare |= q0 | q1;
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // stored before the vote: with the phases needed only after it, the compiler moves most of the arithmetic behind the
-            // branch and keeps thirty lane masks alive across it (48 v_writelane + as many v_readlane per thread)
+            float* yl = lds + LOFF - dd;                               // yl[s] = y of pair-stream sample s
+            if (dd == 2) {
 #pragma unroll
-            for (int i = 0; i < NP - 1; i++) lds[threadIdx.x + i * NT] = y[i];
+                for (int i = 0; i < R; i++) *reinterpret_cast<float2*>(yl + 2 * (j0 + 64 * i)) = y[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < R; i++) { yl[2 * (j0 + 64 * i)] = y[i].x; yl[2 * (j0 + 64 * i) + 1] = y[i].y; }
+            }
             if (__any(rare)) {
 #pragma unroll
-                for (int i = 0; i < NP - 1; i++) {
-                    y[i] = fm_phase_sel(cur[i], prv[i]);
-                    lds[threadIdx.x + i * NT] = y[i];
+                for (int i = 0; i < R; i++) {
+                    const float2 A = make_float2(v[i].x, v[i].y), B = make_float2(v[i].z, v[i].w);
+                    const float2 pv = pred(i);
+                    y[i] = make_float2(fm_phase_sel(A, pv), fm_phase_sel(B, A));
+                    yl[2 * (j0 + 64 * i)] = y[i].x;
+                    yl[2 * (j0 + 64 * i) + 1] = y[i].y;
                 }
             }
-            y[NP - 1] = 0.0f;
-            if ((int)threadIdx.x + (NP - 1) * NT < SPAN) {
-                y[NP - 1] = fm_phase_sel(cur[NP - 1], prv[NP - 1]);
-                lds[threadIdx.x + (NP - 1) * NT] = y[NP - 1];
-            }
-            // the y other kernels still read: only a tile that touches a keep zone looks at positions at all (SPAN <= yseam, so
-            // the tile [m0, m0 + SPAN) either starts inside [0, ykeep) or reaches [yseam - ykeep, yseam + ykeep))
             if (dm.yseam > 0 && (m0 < dm.ykeep || m0 + SPAN > dm.yseam - dm.ykeep)) {
 #pragma unroll
-                for (int i = 0; i < NP; i++) {
-                    const int p = threadIdx.x + i * NT;
-                    int m = m0 + p;
-                    if (m >= dm.yseam) m -= dm.yseam;
-                    if (p < SPAN && (m < dm.ykeep || m >= dm.yseam - dm.ykeep)) dm.y_out[base + p] = y[i];
+                for (int i = 0; i < R; i++) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int p = 2 * (j0 + 64 * i) + h - dd;
+                        int m = m0 + p;
+                        if (m >= dm.yseam) m -= dm.yseam;
+                        if (p >= 0 && p < SPAN && (m < dm.ykeep || m >= dm.yseam - dm.ykeep)) dm.y_out[base + p] = h ? y[i].y : y[i].x;
+                    }
                 }
             }
         } else {
-#pragma unroll
-            for (int i = 0; i < NP; i++) {
-                const int p = threadIdx.x + i * NT;
-                if (p < SPAN) {
-                    const float y = p < avail ? fm_phase_sel(cur[i], prv[i]) : 0.0f;
-                    lds[p] = y;
-                    if (dm.yseam > 0 && p < avail) {
-                        int m = m0 + p;                              // position inside the seam grid: SPAN <= yseam (launcher)
+            for (int p = threadIdx.x; p < SPAN; p += NT) {
+                float y = 0.0f;
+                if (p < av64) {
+                    const float2 c = z[p];
+                    const float2 pv = (base + p > 0 || dm.has_prev) ? z[p - 1] : make_float2(0.0f, 0.0f);
+                    y = fm_phase_sel(c, pv);
+                    if (dm.yseam > 0) {
+                        int m = m0 + p;
                         if (m >= dm.yseam) m -= dm.yseam;
                         if (m < dm.ykeep || m >= dm.yseam - dm.ykeep) dm.y_out[base + p] = y;
                     }
                 }
+                lds[LOFF + p] = y;
             }
         }
     } else {
@@ -514,14 +525,14 @@ __global__ void __launch_bounds__(NT, 6) k_resample3_fast(const float* __restric
     __syncthreads();
 
     const int cyc = cyc0 + threadIdx.x;
-    if (cyc >= ncycles) {
+    if ((int)threadIdx.x >= CYC || cyc >= ncycles) {
         if constexpr (DEMOD) demod_edges(in, dm);
         return;
     }
     // window start = 10*t floats: 8-byte aligned, and a 10-dword lane stride is conflict-free
     // for ds_read_b64 (distinct even banks within each 32-lane group)
     static_assert(PERIOD % 2 == 0, "8-byte aligned thread windows");
-    const float* win = lds + threadIdx.x * PERIOD;
+    const float* win = lds + LOFF + threadIdx.x * PERIOD;
     float res[3];
     if constexpr (PK && L == 8) {
         typedef float f2 __attribute__((ext_vector_type(2)));
@@ -726,8 +737,8 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
             dm.nedge = kEdge;
             dm.y_count = y_count;
             // (workgroup size of the fused form, same-box A/B: 128 / 256 / 512 threads 0.197 / 0.196 / 0.2015 ms)
-            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, true, 8, true>), dim3(blocks), dim3(NT), 0, s, d_iq, pos, ncycles,
-                               avail_total, d_groups, t.row_stride, d_out + lead, dm);
+            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, true, 8, true>), dim3((ncycles + kDemodCycles - 1) / kDemodCycles), dim3(NT), 0, s,
+                               d_iq, pos, ncycles, avail_total, d_groups, t.row_stride, d_out + lead, dm);
         } else if (lanes == 4)
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, false, 4>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);

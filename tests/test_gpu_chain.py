@@ -143,7 +143,7 @@ def test_fm_stream_matches_pipes(hip, oracle, blocks_per_push):
 
 
 def test_fm_stream_large_copying_pushes_equal_small_ones(hip):
-    """Round 5: a push of 8 MiB or more from caller memory is copied into the pinned staging buffer by the caller and three helper
+    """Round 5: a push of 4 MiB or more (chain.cpp: CopyPool::kMinBytes) from caller memory is copied into the pinned staging buffer by the caller and three helper
     threads (chain.cpp: CopyPool); the audio must be what 16-block pushes give -- including a push whose length is not a multiple of
     the helpers' 1 MiB pieces, from an unaligned address, and a last short one."""
     nblk = 1536 + 700 + 37
