@@ -12,8 +12,9 @@ P = os.path.join(ROOT, "profiles")
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    tag = args[0] if args else "r05"
-    full = json.loads(open(os.path.join(P, f"{tag}_bench_full.json")).read().strip().splitlines()[-1])
+    tag = args[0] if args else "r06"
+    txt = open(os.path.join(P, f"{tag}_bench_full.json")).read().strip()
+    full = json.loads(txt) if txt.startswith("{\n") or "\n" in txt else json.loads(txt.splitlines()[-1])     # round 6: the extras file (indented); before: one line
     stats = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(P, f"{tag}_kernel_stats.csv")))}
     pmc = {r["kernel"]: r for r in csv.DictReader(open(os.path.join(P, f"{tag}_pmc_summary.csv")))}
     k2t = json.load(open(os.path.join(P, "k2_traffic.json")))
@@ -31,7 +32,7 @@ def main():
     rf = full["roofline"]
     row("K2 roofline (VALU, unfused, 78.6 TFLOP/s)", f"{rf['achieved']} TFLOP/s = **{rf['frac']:.3f}**; HBM view {rf['hbm']['achieved']:.0f} GB/s = {rf['hbm']['frac']:.3f}", B)
     row("K2 HBM traffic per launch (FETCH x 2 + WRITE) / algorithmic", f"{k2t['hbm_bytes_per_launch'] / 1e9:.4f} GB / {k2t['algorithmic_bytes_per_launch'] / 1e9:.4f} GB = {k2t['hbm_bytes_per_launch'] / k2t['algorithmic_bytes_per_launch']:.4f}", "profiles/k2_traffic.json")
-    for k, label in (("k_decimate_systolic<true, 1, false>", "K2 u8 kernel alone"), ("k_resample3_fast<3, 64, 4, 3, 3, 256, true, 8, true>", "fmDemod + resampler kernel alone"),
+    for k, label in (("k_decimate_systolic<true, 1, false>", "K2 u8 kernel alone"), ("k_decimate_systolic<true, 1, true, false>", "K2 u8 kernel alone"), ("k_resample3_fast<3, 64, 4, 3, 3, 256, true, 8, true>", "fmDemod + resampler kernel alone"),
                      ("k_fir_real8_fast<true, 4, 256, 8>", "filter kernel alone"), ("k_decimate_c_crossfix<true, 8, 128, 16, 16, false>", "decimator seam fix-up"),
                      ("k_resample_real_crossfix<20, 135, 32>", "resampler seam fix-up"), ("k_filter_real_crossfix_lds<128>", "filter seam fix-up")):
         if k in stats:
@@ -54,7 +55,10 @@ def main():
         ln = h["link"]
         row("host link of the bench process: pinned H2D / D2H / kernel reading pinned host memory", f"{ln.get('pinned_h2d_GBps')} / {ln.get('pinned_d2h_GBps')} / {ln.get('kernel_reads_pinned_host_GBps')} GB/s", B)
         for name, d in (h.get("link_roofline") or {}).items():
-            row(f"host-streamed `{name}`", f"{d['Msamples_per_s'] / 1e3:.2f} Gsample/s = {d['link_GBps']} GB/s on the link = **{d.get('frac')}** of its ceiling", B)
+            if "Msamples_per_s" in d:
+                row(f"host-streamed `{name}`", f"{d['Msamples_per_s'] / 1e3:.2f} Gsample/s = {d['link_GBps']} GB/s on the link = **{d.get('frac')}** of its ceiling", B)
+            else:       # BASELINE configs[3]: a Pipe of float elements
+                row(f"host-streamed `{name}` (BASELINE configs[3])", f"{d['Melements_per_s'] / 1e3:.2f} G elements/s ({d.get('us_per_push')} µs per 65 536-float push) = {d['link_GBps']} GB/s on the link = **{d.get('frac')}** of its ceiling", B)
         oe = h.get("overlap_efficiency_4096_block_pushes")
         if isinstance(oe, dict):
             row("overlap efficiency of the double-buffered path (4096-block copying pushes)", f"{oe['value']} (copy {oe['copy_ms']} ms, compute {oe['compute_ms']} ms, wall {oe['wall_ms_per_push']} ms)", B)
@@ -64,6 +68,10 @@ def main():
         row("launch-size sweep, full chain: worst `auto_over_best` over the sizes", f"{worst['auto_over_best']} at B = {worst['blocks_per_launch']} blocks ({worst['auto']['route']})", B + " (launch_size_sweep)")
         pts = ", ".join(f"{r['blocks_per_launch']}: {r['auto']['us_per_launch']} µs" for r in sw["full_chain_u8"])
         row("… µs per launch on the library's own route, by blocks per launch", pts, B)
+        w1 = max(sw["config1_cfloat_decimator"], key=lambda r: r["auto_over_best"])
+        row("launch-size sweep, configs[1] (cfloat decimator): worst `auto_over_best`", f"{w1['auto_over_best']} at B = {w1['blocks_per_launch']} blocks", B + " (launch_size_sweep)")
+        pts1 = ", ".join(f"{r['blocks_per_launch']}: {r['auto']['us_per_launch']} µs" + (f" (round 5's systolic form {r['systolic_kernel']['us_per_launch']}, tile kernel {r['tile_kernel']['us_per_launch']})" if r['blocks_per_launch'] in (512, 2048) and 'systolic_kernel' in r else "") for r in sw["config1_cfloat_decimator"])
+        row("… µs per launch, by blocks per launch", pts1, B)
     cpu = full.get("cpu_baseline") or {}
     if cpu:
         row("CPU baseline on the GPU box's host (reference's C kernels, compiled caller)", f"{cpu['value'] / 1e3:.2f} Gsample/s on {cpu['cores']} threads ({cpu.get('physical_cores')} cores); single thread {cpu['single_thread_value']:.0f} Msample/s", B)
