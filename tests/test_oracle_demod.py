@@ -19,6 +19,9 @@ def check_model_against_this_libm(oracle, stride=97):
     so a different libm on the GPU box moves neither the test suite nor what `the reference` means."""
     exact = oracle.libc_version() == SWEPT_LIBC
     bad, first, worst = oracle.atanf_sweep(0, 0xFFFFFFFF, stride)
+    # the count is also the number of arguments on which the DEVICE would differ from a GHC build over this host's libm: the device
+    # equals the model on every float (tests/test_gpu_demod_exhaustive.py)
+    print(f"atanf model vs this host's libm (glibc {oracle.libc_version()}), every {stride}th float: {bad} mismatches, worst {worst} ULP")
     if exact:
         assert bad == 0, f"glibc {SWEPT_LIBC}: first mismatch at {first:#x}, up to {worst} ULP"
     else:
