@@ -458,57 +458,56 @@ static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
     };
     if (c->timing) c->runs++;
 
-    do {
-        float* d_d = (float*)(ws + r.off_d);
-        float* d_y = (float*)(ws + r.off_y);
-        float* d_z = (float*)(ws + r.off_z);
-        hipEvent_t b = nullptr;
-        // K1+K2 on the caller's stream: u8 -> cfloat -> decimate (convert.c:37-50 fused into decimate.c:105-113)
-        if ((rc = begin_span(0, s, &b)) != SDRHIP_OK) return rc;
-        if (c->fused_first_stage()) {
-            if ((rc = fir_run(&c->decim, s, d_in_iq, true, s0, d_d, r.kd0, r.kd1, c->block)) != SDRHIP_OK) return rc;
-        } else {
-            float* d_x = (float*)(ws + r.off_x);
-            launch_convert_u8(s, d_in_iq + 2 * (r.xa - s0), d_x, 2 * (r.xb - r.xa));
-            if ((rc = fir_run(&c->decim, s, d_x, false, r.xa, d_d, r.kd0, r.kd1, c->block)) != SDRHIP_OK) return rc;
+    float* d_d = (float*)(ws + r.off_d);
+    float* d_y = (float*)(ws + r.off_y);
+    float* d_z = (float*)(ws + r.off_z);
+    hipEvent_t b = nullptr;
+    // K1+K2 on the caller's stream: u8 -> cfloat -> decimate (convert.c:37-50 fused into decimate.c:105-113)
+    if ((rc = begin_span(0, s, &b)) != SDRHIP_OK) return rc;
+    if (c->fused_first_stage()) {
+        if ((rc = fir_run(&c->decim, s, d_in_iq, true, s0, d_d, r.kd0, r.kd1, c->block)) != SDRHIP_OK) return rc;
+    } else {
+        float* d_x = (float*)(ws + r.off_x);
+        launch_convert_u8(s, d_in_iq + 2 * (r.xa - s0), d_x, 2 * (r.xb - r.xa));
+        if ((rc = fir_run(&c->decim, s, d_x, false, r.xa, d_d, r.kd0, r.kd1, c->block)) != SDRHIP_OK) return rc;
+    }
+    if ((rc = end_span(0, s, b)) != SDRHIP_OK) return rc;
+    if (c->tail_shape_ok(r.q1 - r.q0)) {
+        if ((rc = c->resamp.ensure_device()) != SDRHIP_OK || (rc = c->audio.ensure_device()) != SDRHIP_OK) return rc;
+        if ((rc = begin_span(4, st, &b)) != SDRHIP_OK) return rc;
+        const bool took = launch_fm_tail_fused(st, d_d, r.kd0, r.kd1, r.ky0, r.ky1, d_audio + (r.q0 - q0), r.q0, r.q1, c->resamp.d_groups,
+                                               c->resamp.row_stride, c->resamp.nloop, c->resamp.increments.data(), c->resamp.num_groups,
+                                               c->resamp.I, c->resamp.D, c->resamp.Lp, c->resamp.d_plain, c->resamp.ntaps, c->audio.d_taps,
+                                               c->audio.ntaps_kernel, c->audio.d_cross, c->gain, c->block);
+        if (took) {
+            if ((rc = end_span(4, st, b)) != SDRHIP_OK) return rc;
+            SDRHIP_CHECK_HIP(hipGetLastError());
+            return SDRHIP_OK;
         }
-        if ((rc = end_span(0, s, b)) != SDRHIP_OK) return rc;
-        if (c->tail_shape_ok(r.q1 - r.q0)) {
-            if ((rc = c->resamp.ensure_device()) != SDRHIP_OK || (rc = c->audio.ensure_device()) != SDRHIP_OK) return rc;
-            if ((rc = begin_span(4, st, &b)) != SDRHIP_OK) return rc;
-            const bool took = launch_fm_tail_fused(st, d_d, r.kd0, r.kd1, r.ky0, r.ky1, d_audio + (r.q0 - q0), r.q0, r.q1, c->resamp.d_groups,
-                                                   c->resamp.row_stride, c->resamp.nloop, c->resamp.increments.data(), c->resamp.num_groups,
-                                                   c->resamp.I, c->resamp.D, c->resamp.Lp, c->resamp.d_plain, c->resamp.ntaps, c->audio.d_taps,
-                                                   c->audio.ntaps_kernel, c->audio.d_cross, c->gain, c->block);
-            if (took) {
-                if ((rc = end_span(4, st, b)) != SDRHIP_OK) return rc;
-                continue;
-            }
-            if (c->timing && c->ev_used > 0) c->ev_used--;      // the span's begin event goes back to the pool
-        }
-        if (c->fuse_demod) {
-            // K3+K4: fmDemod inside the resampler's tile loader on large batches (y never reaches HBM), a stand-alone fmDemod
-            // launch first otherwise; timed as the resample stage
-            if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;
-            if ((rc = resamp_run_demod(&c->resamp, st, d_d + 2 * (r.ky0 - r.kd0), r.ky0 > r.kd0, r.ky1 - r.ky0, d_y, r.ky0, d_z, r.m0, r.m1,
-                                       c->block, c->block, nullptr)) != SDRHIP_OK) return rc;
-            if ((rc = end_span(2, st, b)) != SDRHIP_OK) return rc;
-        } else {
-            // K3: fmDemod; at stream start the carried sample is 0 (Demod.hs:41)
-            if ((rc = begin_span(1, st, &b)) != SDRHIP_OK) return rc;
-            launch_fm_demod_fast(st, d_d + 2 * (r.ky0 - r.kd0), d_y, r.ky1 - r.ky0, r.ky0 > r.kd0, 0.0f, 0.0f);
-            if ((rc = end_span(1, st, b)) != SDRHIP_OK) return rc;
-            // K4: polyphase resample
-            if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;
-            if ((rc = resamp_run(&c->resamp, st, d_y, r.ky0, d_z, r.m0, r.m1, c->block, c->block)) != SDRHIP_OK) return rc;
-            if ((rc = end_span(2, st, b)) != SDRHIP_OK) return rc;
-        }
-        // K5: symmetric audio filter (+ fm.hs:40 `P.map (VG.map (* 0.2))` as the kernel's epilogue: a separate
-        // f32 multiply of the rounded output)
-        if ((rc = begin_span(3, st, &b)) != SDRHIP_OK) return rc;
-        if ((rc = fir_run(&c->audio, st, d_z, false, r.m0, d_audio + (r.q0 - q0), r.q0, r.q1, c->block, c->gain)) != SDRHIP_OK) return rc;
-        if ((rc = end_span(3, st, b)) != SDRHIP_OK) return rc;
-    } while (false);
+        if (c->timing && c->ev_used > 0) c->ev_used--;      // the span's begin event goes back to the pool
+    }
+    if (c->fuse_demod) {
+        // K3+K4: fmDemod inside the resampler's tile loader on large batches (y never reaches HBM), a stand-alone fmDemod
+        // launch first otherwise; timed as the resample stage
+        if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;
+        if ((rc = resamp_run_demod(&c->resamp, st, d_d + 2 * (r.ky0 - r.kd0), r.ky0 > r.kd0, r.ky1 - r.ky0, d_y, r.ky0, d_z, r.m0, r.m1,
+                                   c->block, c->block, nullptr)) != SDRHIP_OK) return rc;
+        if ((rc = end_span(2, st, b)) != SDRHIP_OK) return rc;
+    } else {
+        // K3: fmDemod; at stream start the carried sample is 0 (Demod.hs:41)
+        if ((rc = begin_span(1, st, &b)) != SDRHIP_OK) return rc;
+        launch_fm_demod_fast(st, d_d + 2 * (r.ky0 - r.kd0), d_y, r.ky1 - r.ky0, r.ky0 > r.kd0, 0.0f, 0.0f);
+        if ((rc = end_span(1, st, b)) != SDRHIP_OK) return rc;
+        // K4: polyphase resample
+        if ((rc = begin_span(2, st, &b)) != SDRHIP_OK) return rc;
+        if ((rc = resamp_run(&c->resamp, st, d_y, r.ky0, d_z, r.m0, r.m1, c->block, c->block)) != SDRHIP_OK) return rc;
+        if ((rc = end_span(2, st, b)) != SDRHIP_OK) return rc;
+    }
+    // K5: symmetric audio filter (+ fm.hs:40 `P.map (VG.map (* 0.2))` as the kernel's epilogue: a separate
+    // f32 multiply of the rounded output)
+    if ((rc = begin_span(3, st, &b)) != SDRHIP_OK) return rc;
+    if ((rc = fir_run(&c->audio, st, d_z, false, r.m0, d_audio + (r.q0 - q0), r.q0, r.q1, c->block, c->gain)) != SDRHIP_OK) return rc;
+    if ((rc = end_span(3, st, b)) != SDRHIP_OK) return rc;
     SDRHIP_CHECK_HIP(hipGetLastError());
     return SDRHIP_OK;
 }
