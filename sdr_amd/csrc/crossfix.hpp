@@ -114,18 +114,19 @@ inline void seam_range(const Geom& g, int64_t& first, int64_t& last)
 // taps = stride I (drop filterOffset coeffs) over the UNPADDED taps, sequential -- and with I = 1 the Cross outputs of a real
 // decimator / filter (decimateCrossHighLevel / filterCrossHighLevel, FilterInternal.hs:397-408).  A group of LPG
 // (32 or 64) lanes serves one seam: its <= PER straddlers read a union of <= UNI consecutive inputs, staged in LDS.
+// the work of workgroup `wg` (256 threads): seams [wg * SPW, wg * SPW + SPW).  A kernel of its own below; round 6: also the body of
+// the seam workgroups of kernels_chain.hip's k_resample3_stragglers (seams + lead-in + tail of a 3/10 launch in ONE launch)
 template <int PER, int UNI, int LPG = 32>
-__global__ void __launch_bounds__(256) k_resample_real_crossfix(Geom g, const float* __restrict__ plain, int ntaps,
-                                                                 const float* __restrict__ in, float* __restrict__ out,
-                                                                 int64_t first_seam, int nseams, int64_t in_avail, float gain = 1.0f,
-                                                                 int apply_gain = 0)
+__device__ __forceinline__ void resample_real_crossfix_wg(int wg, const Geom& g, const float* __restrict__ plain, int ntaps,
+                                                          const float* __restrict__ in, float* __restrict__ out,
+                                                          int64_t first_seam, int nseams, int64_t in_avail, float gain, int apply_gain)
 {
     static_assert((LPG == 32 || LPG == 64) && PER <= LPG, "one group of LPG lanes per seam");
     constexpr int SPW = 256 / LPG;                                       // seams per workgroup
     __shared__ float lds[SPW][UNI];
     __shared__ float tl[256];
     const int tid = threadIdx.x, sl = tid / LPG, ci = tid % LPG;
-    const int si = blockIdx.x * SPW + sl;
+    const int si = wg * SPW + sl;
     const bool live = si < nseams;
     int64_t edge = 0, m_lo = 0, p_lo = 0;
     if (live) {
@@ -182,6 +183,15 @@ __global__ void __launch_bounds__(256) k_resample_real_crossfix(Geom g, const fl
     }
     if (apply_gain) r = r * gain;
     out[m - g.k_begin] = r;
+}
+
+template <int PER, int UNI, int LPG = 32>
+__global__ void __launch_bounds__(256) k_resample_real_crossfix(Geom g, const float* __restrict__ plain, int ntaps,
+                                                                 const float* __restrict__ in, float* __restrict__ out,
+                                                                 int64_t first_seam, int nseams, int64_t in_avail, float gain = 1.0f,
+                                                                 int apply_gain = 0)
+{
+    resample_real_crossfix_wg<PER, UNI, LPG>((int)blockIdx.x, g, plain, ntaps, in, out, first_seam, nseams, in_avail, gain, apply_gain);
 }
 
 }  // namespace

@@ -56,6 +56,20 @@ __host__ __device__ inline bool late_output_is_one(int64_t m, int64_t edge, int 
     return first_in * I >= edge;
 }
 
+// Is output m of a seamed stream computed in the reference's sequential ("Cross") order?  One when the window fits the buffer it
+// starts in; else Cross -- unless the Pipe never crosses over at that boundary (seam_has_crossover), or the output is the late
+// first One of an output block.
+__host__ __device__ inline bool is_cross(const Geom& g, int64_t m)
+{
+    if (g.seamBI == 0) return false;
+    if (g.seamBI < 0) return true;   // every output of this launch is a seam straddler
+    const int64_t v = m * (int64_t)g.D;
+    const int64_t edge = (v / g.seamBI + 1) * g.seamBI;
+    if (v + g.Lp <= edge) return false;
+    if (late_output_is_one(m, edge, g.I, g.D, g.outB)) return false;
+    return seam_has_crossover(edge, g.I, g.D, g.Lp);
+}
+
 // Real data ------------------------------------------------------------------
 // taps: `ntaps` floats (multiple of lanes).  sym: taps are the HALF filter.
 // cross_taps: Lp floats used by the sequential "Cross" outputs (may be null when seamBI == 0).

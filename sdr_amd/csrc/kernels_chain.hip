@@ -601,6 +601,57 @@ __global__ void __launch_bounds__(NT, 6) k_resample3_fast(const float* __restric
 }
 
 
+// Everything of a 3/10 launch that is not a whole polyphase cycle, in ONE launch behind the tile kernel (round 6; they were three: a
+// lead-in launch of up to two outputs, a tail launch of up to two, the seam fix-up): workgroups [0, nfixwg) rewrite the Cross outputs
+// (resample_real_crossfix_wg), the last workgroup computes the lead-in and tail outputs, one thread each, in the SIMD lane order
+// (resample.c:70-87) -- unless such an output is itself Cross: the seam workgroup owns it.
+struct Stragglers {
+    int lead, tail;            // outputs before the first whole cycle / after the last
+    int lead_group0;           // polyphase group of output 0
+    int64_t lead_pos[2];       // first input of lead output i, relative to `in`
+    int64_t tail_pos0;         // first input of the tail's cycle (its outputs are groups 0, 1 at + 0, + 4)
+    int done;                  // outputs in front of the tail
+    int nloop, row_stride;
+};
+
+template <int PER, int UNI, int L>
+__global__ void __launch_bounds__(256) k_resample3_stragglers(Geom g, Stragglers st, const float* __restrict__ groups, const float* __restrict__ plain,
+                                                               int ntaps, const float* __restrict__ in, float* __restrict__ out, int64_t first_seam,
+                                                               int nseams, int64_t in_avail)
+{
+    const int nfixwg = (nseams + 7) / 8;
+    if ((int)blockIdx.x < nfixwg) {
+        resample_real_crossfix_wg<PER, UNI, 32>((int)blockIdx.x, g, plain, ntaps, in, out, first_seam, nseams, in_avail, 1.0f, 0);
+        return;
+    }
+    const int tid = threadIdx.x;
+    int o, group;
+    int64_t pos;
+    if (tid < st.lead) {
+        o = tid;
+        group = (st.lead_group0 + tid) % 3;
+        pos = st.lead_pos[tid];
+    } else if (tid >= 32 && tid - 32 < st.tail) {
+        o = st.done + (tid - 32);
+        group = tid - 32;
+        pos = st.tail_pos0 + (tid - 32 == 0 ? 0 : 4);
+    } else {
+        return;
+    }
+    if (is_cross(g, g.k_begin + o)) return;
+    const float* x = in + pos;
+    const float* c = groups + (size_t)group * st.row_stride;
+    float acc[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) acc[l] = 0.0f;
+    for (int j = 0; j < st.nloop; j += L) {
+#pragma unroll
+        for (int l = 0; l < L; l++) acc[l] = acc[l] + c[j + l] * x[j + l];
+    }
+    if constexpr (L == 8) out[o] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    else out[o] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
 }  // namespace
 
 void launch_fm_demod_fast(hipStream_t s, const float* d_in_iq, float* d_out, int64_t count, bool has_prev, float last_re,
@@ -715,8 +766,6 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
     if (lead > g.count) lead = g.count;
     const int ncycles = (g.count - lead) / 3;
     const int tail = g.count - lead - 3 * ncycles;
-    Geom gs = g;
-    gs.seamBI = 0;  // every output as One first; seams are fixed up below
     if (d_iq != nullptr) {
         // the tail's windows must lie inside the last kEdge inputs
         const int64_t tail_pos = t.pos0 + (lead > 0 ? t.pre[lead - 1] + increments[(t.group0 + lead - 1) % 3] : 0) + (int64_t)ncycles * 10;
@@ -749,34 +798,32 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
             hipLaunchKernelGGL((k_resample3_fast<3, 16, 4, 3, 3, NT>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);
     }
-    // (after the tile kernel: with fmDemod fused its first workgroup writes the y these few outputs read)
-    if (lead > 0) {
-        Geom gl = gs;
-        gl.count = lead;
-        launch_resample_real(s, gl, lanes, t, d_groups, d_plain_taps, d_in, d_out);
-    }
-    if (tail > 0) {
-        const int done = lead + 3 * ncycles;
-        Geom gt = gs;
-        gt.k_begin = g.k_begin + done;
-        gt.count = tail;
-        ResampTable tt = t;
-        tt.group0 = 0;
-        tt.pos0 = t.pos0 + (lead > 0 ? t.pre[lead - 1] + increments[(t.group0 + lead - 1) % 3] : 0) + (int64_t)ncycles * 10;
-        tt.pre[0] = 0; tt.pre[1] = 4; tt.pre[2] = 7;
-        launch_resample_real(s, gt, lanes, tt, d_groups, d_plain_taps, d_in, d_out + done);
-    }
-    if (g.seamBI != 0) {
-        int64_t first, last;
-        seam_range(g, first, last);
-        if (last >= first) {
-            const int nseams = (int)(last - first + 1);
+    // (after the tile kernel: with fmDemod fused its first and last workgroup write the y the lead-in / tail outputs read)
+    {
+        int64_t first = 0, last = -1;
+        if (g.seamBI != 0) seam_range(g, first, last);
+        const int nseams = last >= first ? (int)(last - first + 1) : 0;
+        if (nseams > 0 || lead > 0 || tail > 0) {
+            Stragglers sg = {};
+            sg.lead = lead;
+            sg.tail = tail;
+            sg.lead_group0 = t.group0;
+            for (int i = 0; i < lead && i < 2; i++) sg.lead_pos[i] = t.pos0 + t.pre[i];
+            sg.tail_pos0 = t.pos0 + (lead > 0 ? t.pre[lead - 1] + increments[(t.group0 + lead - 1) % 3] : 0) + (int64_t)ncycles * 10;
+            sg.done = lead + 3 * ncycles;
+            sg.nloop = t.nloop;
+            sg.row_stride = t.row_stride;
             // Lp <= 192, D = 10: <= 20 straddlers per seam, 3.33 inputs apart, each reading <= 64 inputs
             constexpr int PER = 20, UNI = 64 + (PER * 10 + 2) / 3 + 4;
             const int64_t last_m = g.k_begin + g.count - 1;
             const int64_t in_avail = (last_m * g.D + g.I - 1) / g.I - g.in_base + t.nloop;          // inputs the caller guarantees
-            hipLaunchKernelGGL((k_resample_real_crossfix<PER, UNI>), dim3((nseams + 7) / 8), dim3(256), 0, s, g, d_plain_taps,
-                               t.ntaps_plain, d_in, d_out, first, nseams, in_avail);
+            const dim3 grid((nseams + 7) / 8 + ((lead > 0 || tail > 0) ? 1 : 0));
+            if (lanes == 8)
+                hipLaunchKernelGGL((k_resample3_stragglers<PER, UNI, 8>), grid, dim3(256), 0, s, g, sg, d_groups, d_plain_taps, t.ntaps_plain, d_in, d_out,
+                                   first, nseams, in_avail);
+            else
+                hipLaunchKernelGGL((k_resample3_stragglers<PER, UNI, 4>), grid, dim3(256), 0, s, g, sg, d_groups, d_plain_taps, t.ntaps_plain, d_in, d_out,
+                                   first, nseams, in_avail);
         }
     }
     return true;

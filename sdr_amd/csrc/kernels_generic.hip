@@ -20,17 +20,6 @@ namespace sdrhip {
 // One / Cross classification of output m (Filter.hs:536-727): virtual window [v, v + Lp), v = m*D, in the upsampled
 // index.  One when the window fits the buffer it starts in; else Cross -- unless the Pipe never crosses over at that
 // boundary (seam_has_crossover, kernels.hpp), in which case the output is the first One of the next buffer.
-__device__ __forceinline__ bool is_cross(const Geom& g, int64_t m)
-{
-    if (g.seamBI == 0) return false;
-    if (g.seamBI < 0) return true;   // every output of this launch is a seam straddler
-    const int64_t v = m * (int64_t)g.D;
-    const int64_t edge = (v / g.seamBI + 1) * g.seamBI;
-    if (v + g.Lp <= edge) return false;
-    if (late_output_is_one(m, edge, g.I, g.D, g.outB)) return false;
-    return seam_has_crossover(edge, g.I, g.D, g.Lp);
-}
-
 template <int L>
 __device__ __forceinline__ float tree_r(const float* a)
 {
