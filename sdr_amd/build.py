@@ -16,6 +16,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsdr_hip.so")
+# the measurement utilities of bench.py / tools (include/sdr_hip_bench.h): a library of their own beside the product, linked against it
+CSRC_BENCH = os.path.join(HERE, "csrc_bench")
+LIB_BENCH = os.path.join(LIBDIR, "libsdr_hip_bench.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -40,9 +43,14 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
+def bench_sources():
+    return sorted(os.path.join(CSRC_BENCH, f) for f in os.listdir(CSRC_BENCH) if f.endswith((".hip", ".cpp")))
+
+
 def headers():
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     hs.append(os.path.join(INCLUDE, "sdr_hip.h"))
+    hs.append(os.path.join(INCLUDE, "sdr_hip_bench.h"))
     return hs
 
 
@@ -91,8 +99,28 @@ def build(force=False, save_temps=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    build_bench_lib(force, hdrs, extra)
     build_examples()
     return LIB
+
+
+def build_bench_lib(force=False, hdrs=None, extra=()):
+    """libsdr_hip_bench.so: csrc_bench/*.{hip,cpp} against the product library (rpath $ORIGIN: the two travel together)."""
+    hdrs = hdrs if hdrs is not None else headers()
+    objs, jobs = [], []
+    for src in bench_sources():
+        obj = os.path.join(OBJ, "bench_" + os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src, os.path.abspath(__file__)] + hdrs):
+            jobs.append((src, obj))
+    for src, obj in jobs:
+        _compile(src, obj, list(extra))
+    if jobs or force or _stale(LIB_BENCH, objs + [LIB]):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_BENCH] + objs + [f"-L{LIBDIR}", "-lsdr_hip", "-Wl,-rpath,$ORIGIN"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_BENCH
 
 
 EXAMPLES = os.path.join(os.path.dirname(HERE), "examples")

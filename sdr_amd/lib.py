@@ -171,6 +171,15 @@ lib.sdrhip_decimator_one.argtypes = [_vp, C.c_int, _f32p, _f32p]
 lib.sdrhip_decimator_cross.argtypes = [_vp, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f32p]
 lib.sdrhip_resampler_one.argtypes = [_vp, C.c_int, C.c_int, _f32p, C.c_int, _f32p]
 lib.sdrhip_resampler_cross.argtypes = [_vp, C.c_int, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f32p]
+# ---- measurement utilities (include/sdr_hip_bench.h): libsdr_hip_bench.so, a library of its own beside the product (round 6); bench.py and
+# tools/ reach them as lib.sdrhip_bench_* like everything else, so the names are attached to `lib` here
+BENCH_LIB_PATH = os.path.join(HERE, "lib", "libsdr_hip_bench.so")
+if not os.path.exists(BENCH_LIB_PATH):
+    raise SdrHipError(f"{BENCH_LIB_PATH} not found: build it with `python -m sdr_amd.build`")
+benchlib = C.CDLL(BENCH_LIB_PATH)
+for _n in ("sdrhip_bench_stream_8to1", "sdrhip_bench_copy", "sdrhip_bench_copy2", "sdrhip_bench_fm_stream", "sdrhip_bench_fm_stream_latency",
+           "sdrhip_bench_pipe", "sdrhip_bench_fm_pipes"):
+    setattr(lib, _n, getattr(benchlib, _n))
 lib.sdrhip_bench_stream_8to1.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]
 lib.sdrhip_bench_copy.argtypes = [_vp, _vp, _vp, C.c_size_t]
 lib.sdrhip_bench_copy2.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int]

@@ -23,8 +23,11 @@ resample2RC resampleSSERC resampleAVXRC convertC convertCSSE convertCAVX convert
 convertCAVXBladeRF convertBladeRFTransmit scale scaleSSE scaleAVX""".split()
 
 
-def declared_functions():
-    text = open(HEADER).read()
+BENCH_HEADER = os.path.join(ROOT, "include", "sdr_hip_bench.h")
+
+
+def declared_functions(header=HEADER):
+    text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)
     skip = {"defined", "sizeof", "void"}      # `void (*handler)(...)`: a function-pointer parameter, not a function
@@ -43,8 +46,21 @@ def L():
 def test_library_exports_every_declared_symbol(L):
     names = declared_functions()
     assert len(names) > 80
-    missing = [n for n in names if not hasattr(L.lib, n)]
+    product = C.CDLL(L.LIB_PATH)                       # a handle of its own: sdr_amd.lib attaches the bench library's names to `lib`
+    missing = [n for n in names if not hasattr(product, n)]
     assert not missing, f"declared in sdr_hip.h but not exported: {missing}"
+
+
+def test_measurement_utilities_live_in_their_own_library(L):
+    """Round 6: libsdr_hip.so is the product; bench.py's ceilings and C timing loops (include/sdr_hip_bench.h) are
+    libsdr_hip_bench.so, linked against it."""
+    names = declared_functions(BENCH_HEADER)
+    assert len(names) >= 7 and all(n.startswith("sdrhip_bench_") for n in names), names
+    bench = C.CDLL(L.BENCH_LIB_PATH)
+    assert not [n for n in names if not hasattr(bench, n)]
+    product = C.CDLL(L.LIB_PATH)
+    assert not [n for n in names if hasattr(product, n)], "the product library must not export measurement utilities"
+    assert all(hasattr(L.lib, n) for n in names)       # ... and the Python driver reaches them through sdr_amd.lib all the same
 
 
 def test_library_exports_the_reference_native_surface(L):

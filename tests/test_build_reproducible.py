@@ -11,7 +11,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-UNITS = ("scratch_pool.cpp", "kernels_bench.hip")
+UNITS = ("scratch_pool.cpp", "kernels_iir.hip")
 
 
 def _build_in(tmp):
