@@ -259,7 +259,7 @@ def contract_line(result):
             line["roofline_config1"]["over_best_no_arithmetic_stream"] = ce.get("kernel_over_nt_stream")
     if result.get("stage_ms"):
         line["stage_ms"] = result["stage_ms"]
-    for key in ("one_pass_at_a_time", "two_passes_in_flight", "fm_carrier_input"):
+    for key in ("one_pass_at_a_time", "two_passes_in_flight", "fm_carrier_input", "example_taps_chain"):
         v = result.get(key)
         if isinstance(v, dict):
             line[key] = _pick(v, ("value", "ms_per_pass"))
@@ -303,7 +303,7 @@ def contract_line(result):
     if result.get("extras_file"):
         line["extras_file"] = result["extras_file"]
     # never over the limit, whatever a later round adds: drop the companions, least important first
-    for key in ("launch_size_sweep", "host_streamed", "fm_carrier_input", "two_passes_in_flight", "one_pass_at_a_time", "per_rank_ms_per_pass",
+    for key in ("launch_size_sweep", "host_streamed", "example_taps_chain", "fm_carrier_input", "two_passes_in_flight", "one_pass_at_a_time", "per_rank_ms_per_pass",
                 "stage_ms", "roofline_config1"):
         if len(json.dumps(line)) < CONTRACT_LINE_LIMIT:
             break
@@ -318,6 +318,8 @@ def emit(result, args, out=None):
     out = out or sys.stdout
     path = None
     try:
+        if getattr(args, "no_extras", False):        # a profiling run (--no-extras) must not overwrite the full result of the run before it
+            raise OSError("no extras collected")
         d = os.path.join(ROOT, "gpurun_out")
         os.makedirs(d, exist_ok=True)
         path = os.path.join(d, f"bench_extras_{result.get('n_gpus', 1)}gpu.json")
@@ -876,6 +878,46 @@ def main():
                              "what the receiver is fed; the headline `value` is measured on uniform random bytes"}
         dbg("fm input done")
 
+    # The reference example's OWN filters (examples/fm/Coeffs.hs as data: tests/golden/example_taps.npz -- 51 / 31 / 64 taps, SURVEY 8(d)'s
+    # second tap set): the receiver examples/fm/fm.hs actually runs, on the same batch.  Fewer multiply-adds per sample than the
+    # benchmark's 127 / 191 / 128 taps, other kernels (the 52-tap tile decimator, the 16-float-group resampler, the stand-alone fmDemod).
+    example_taps = None
+    if extras and rank == 0 and world == 1:
+        try:
+            chx = L.FmChain(8, S.taps_example_rf_decim(), 3, 10, S.taps_example_audio_resampler(), S.taps_example_audio_filter_half(), gain=0.2, block=BLOCK)
+            S_x = args.blocks * BLOCK
+            plx = sharding.ShardPlan(chx, 0, 1, S_x)
+            bufx = torch.randint(0, 256, (2 * (S_x + plx.halo_cap),), dtype=torch.uint8, device="cuda")
+            audx = torch.empty(plx.q1 - plx.q0, dtype=torch.float32, device="cuda")
+            wsbx = chx.workspace_bytes(S_x + plx.halo_cap)
+            wsx = torch.empty(wsbx, dtype=torch.uint8, device="cuda")
+            runx = lambda: chx.run(bufx.data_ptr(), plx.s0, plx.n_in, audx.data_ptr(), plx.q0, plx.q1, wsx.data_ptr(), wsbx, stream=sptr)
+            for _ in range(20):
+                runx()
+            torch.cuda.synchronize()
+            nx = max(10, main_run["passes"] * max(2, args.steps // 4))
+            t0 = time.perf_counter()
+            for _ in range(nx):
+                runx()
+            torch.cuda.synchronize()
+            tx = (time.perf_counter() - t0) / nx
+            chx.enable_timing(True)
+            for _ in range(10):
+                runx()
+            torch.cuda.synchronize()
+            msx, _ = chx.read_timing()
+            chx.enable_timing(False)
+            example_taps = {"value": round(S_x / tx / 1e6, 1), "unit": "Msamples/s", "ms_per_pass": round(tx * 1e3, 4),
+                            "stage_ms": {k: round(v, 5) for k, v in msx.items() if v},
+                            "hbm_read_GBps_of_the_u8_input": round(2.0 * S_x / tx / 1e9, 1),
+                            "what": "the same pass with the reference FM example's own tap tables (examples/fm/Coeffs.hs:11-154 as data: 51-tap RF decimator, "
+                                    "31-tap 3/10 resampler, 64-tap symmetric audio filter), one pass at a time; bit-exact vs the restated Pipes "
+                                    "(tests/test_gpu_fullsize.py::test_example_real_taps_chain)"}
+            del bufx, audx, wsx
+        except Exception as e:                          # noqa: BLE001
+            example_taps = f"failed: {e!r}"
+        dbg("example taps done")
+
     # The main workload with two passes in flight (two chain objects, workspaces and audio buffers on two HIP streams): what a
     # host that keeps the GPU fed with independent batches gets.  Reported beside `value`, which stays the one-stream figure
     # whose per-kernel durations (roofline, stage_ms, the rocprofv3 summaries) are not blurred by co-resident kernels.
@@ -1267,6 +1309,7 @@ def main():
             **({} if events_in_region else {"stage_ms_from": "a separate short run of the same passes (the timed region of a launch-bound shard carries no event records)"}),
             "tail_ms": round(tail_ms, 5),
             "fm_carrier_input": fm_input,
+            "example_taps_chain": example_taps,
             "two_passes_in_flight": main_two,
             "shard_1M_samples_per_gpu": shard_1m,
             "without_halo_exchange": replicas,
