@@ -43,6 +43,10 @@ def main():
                 except (ValueError, ZeroDivisionError):
                     extra = ""
             row(f"{label} (rocprofv3 kernel trace, avg of {stats[k]['calls']})", f"{float(stats[k]['avg_ns']) / 1e3:.1f} µs ({float(stats[k]['pct']):.1f} % of the pass){extra}", f"profiles/{tag}_kernel_stats.csv, {tag}_pmc_summary.csv")
+    ex = full.get("example_taps_chain")
+    if isinstance(ex, dict):
+        row("the same pass with the reference example's OWN taps (51 / 31 / 64: `examples/fm/Coeffs.hs` as data)", f"{ex['value'] / 1e3:.1f} Gsample/s, {ex['ms_per_pass']:.4f} ms per pass "
+            f"(stages {' / '.join(f'{k} {v:.3f}' for k, v in ex['stage_ms'].items())} ms: the 52-tap tile decimator, stand-alone fmDemod + 16-float-group resampler, 32-half-tap filter -- parity path, not tuned)", B)
     c1 = full["roofline_config1_cfloat_decimate"]
     row("BASELINE configs[1]: cfloat ÷8, 2^27 samples, 8192-sample seams", f"{c1['avg_launch_ms']:.4f} ms per launch: read-only **{c1['read_only_frac']:.3f}** of 8 TB/s ({c1['frac']:.3f} incl. writes); "
         f"{c1['ceilings_same_process']['kernel_over_nt_stream']:.3f} of the best no-arithmetic stream of that shape in the same process", B)
