@@ -752,7 +752,7 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
     if (d_iq != nullptr) {
         // the fused form serves the FM chain's shape only; anything else: the caller demodulates first
         const int64_t yseam = g.seamBI > 0 ? g.seamBI / g.I : 0;
-        if (t.nloop != 64 || g.I != 3 || y_count < 4 * kEdge || t.pos0 + 96 > kEdge) return false;
+        if (!(t.nloop == 64 || t.nloop == 16) || g.I != 3 || y_count < 4 * kEdge || t.pos0 + 96 > kEdge) return false;
         if (g.seamBI > 0 && (g.seamBI % g.I != 0 || yseam < 4096 || yseam > (1 << 30))) return false;
     }
     // specialised for the FM chain's resampler: 3 groups, increments {4,3,3}, 64-float rows, AVX order
@@ -786,8 +786,12 @@ bool launch_resample_3_10_fast(hipStream_t s, const Geom& g, const ResampTable& 
             dm.nedge = kEdge;
             dm.y_count = y_count;
             // (workgroup size of the fused form, same-box A/B: 128 / 256 / 512 threads 0.197 / 0.196 / 0.2015 ms)
-            hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, true, 8, true>), dim3((ncycles + kDemodCycles - 1) / kDemodCycles), dim3(NT), 0, s,
-                               d_iq, pos, ncycles, avail_total, d_groups, t.row_stride, d_out + lead, dm);
+            if (t.nloop == 64)
+                hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, true, 8, true>), dim3((ncycles + kDemodCycles - 1) / kDemodCycles), dim3(NT), 0, s,
+                                   d_iq, pos, ncycles, avail_total, d_groups, t.row_stride, d_out + lead, dm);
+            else        // 16-float groups: the reference example's own 31-tap resampler (examples/fm/Coeffs.hs)
+                hipLaunchKernelGGL((k_resample3_fast<3, 16, 4, 3, 3, NT, true, 8, true>), dim3((ncycles + kDemodCycles - 1) / kDemodCycles), dim3(NT), 0, s,
+                                   d_iq, pos, ncycles, avail_total, d_groups, t.row_stride, d_out + lead, dm);
         } else if (lanes == 4)
             hipLaunchKernelGGL((k_resample3_fast<3, 64, 4, 3, 3, NT, false, 4>), dim3(blocks), dim3(NT), 0, s, d_in, pos, ncycles, avail_total,
                                d_groups, t.row_stride, d_out + lead, dm);

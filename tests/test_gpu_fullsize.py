@@ -162,6 +162,33 @@ def test_example_shaped_taps_chain(hip, oracle):
     assert_bit_equal(to_host(out)[: exp.size], exp, "example-shaped chain")
 
 
+@pytest.mark.parametrize("block", [B, 0])
+def test_example_real_taps_full_size_fused_equals_stage_kernels(hip, block):
+    """The reference example's own taps at a size where the chain takes its large-batch routes (2^24 samples: the 52-tap tile decimator,
+    fmDemod inside the 16-float-group resampler's loader since round 6): the same audio as with fmDemod as a kernel of its own, from the
+    stream start and from the middle of a stream."""
+    n = 1 << 24
+    u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda")
+    chain = hip.FmChain(8, S.taps_example_rf_decim(), 3, 10, S.taps_example_audio_resampler(), S.taps_example_audio_filter_half(), 0.2, block)
+    ws = torch.empty(chain.workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    for s0 in (0, 53 * B):
+        q0, q1, _ = chain.plan(s0, s0 + n, s0 + n)
+        outs = []
+        for fused in (False, True):
+            chain.set_demod_fusion(fused)
+            ws.fill_(0x5A)
+            out = dev_empty_f32(q1 - q0)
+            chain.enable_timing(True)
+            chain.run(ptr(u8), s0, n, ptr(out), q0, q1, ptr(ws), ws.numel())
+            torch.cuda.synchronize()
+            stage_ms, _ = chain.read_timing()
+            chain.enable_timing(False)
+            assert (stage_ms["fm_demod"] == 0.0) == fused, "the fused form books the pair under `resample`"
+            outs.append(out)
+        chain.set_demod_fusion(True)
+        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), f"block {block}, s0 {s0}"
+
+
 def test_example_real_taps_chain(hip, oracle):
     """The reference FM example's OWN filters (examples/fm/Coeffs.hs:11-154 as data: tests/golden/example_taps.npz -- Octave remez
     designs, 51 / 31 / 32 half-taps) through the whole receiver of examples/fm/fm.hs:34-41, against the restated Pipes, device-resident
