@@ -67,8 +67,10 @@ bool launch_decimate_c4_fast(hipStream_t s, const Geom& g, const float* d_plain_
         else { if (P % 8 == 0) GUARDED(8, 256, 8); else GUARDED(8, 256, 4); }
 #undef GUARDED
     } else if (P == 52) {
-        // the tap count of the reference FM example's RF decimation filter (51 -> 52)
-        if (in_is_u8) launch_c4<8, 52, 2, 256, true>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
+        // the tap count of the reference FM example's RF decimation filter (51 -> 52): u8 launches that are not launch-bound take the
+        // systolic kernel's 64-tap instantiation (round 6)
+        if (in_is_u8 && !inl && launch_decimate_c4_systolic(s, g, d_plain_taps, P, d_in, true, d_out, false, d_cross_taps, &inlined)) {
+        } else if (in_is_u8) launch_c4<8, 52, 2, 256, true>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
         else launch_c4<8, 52, 2, 256, false>(s, g, d_plain_taps, d_in, d_out, inl, &inlined);
     } else {
         // 127 taps padded to 128 (the FM chain's decimator).  Launches that are not launch-bound take the register-resident

@@ -43,10 +43,19 @@ namespace {
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f8 __attribute__((ext_vector_type(8)));
 
-constexpr int kStripOuts = 240;        // outputs per wave-strip
-constexpr int kStripStep = 1920;       // samples between strips (= 8 * 240)
+// PT = rows of 8 taps (16: the 128-tap filter this file was written for; 8: up to 64 taps -- round 6, the reference example's own
+// 51 -> 52-tap RF decimator with the 12 taps of padding skipped).  A group's partial sums travel (PT + 2) / 4 stages, so that many
+// lanes at the bottom of a wave only warm the pipe up.
+template <int PT>
+struct Sys {
+    static_assert(PT == 16 || PT == 8, "tap rows: a multiple of four (output 0 of a group then completes one stage before the others)");
+    static constexpr int kWarm = (PT + 2) / 4;              // 4 / 2 lanes without a finished group
+    static constexpr int kOuts = 4 * (64 - kWarm);          // outputs per wave-strip: 240 / 248
+    static constexpr int kStep = 8 * kOuts;                 // samples between strips: 1920 / 1984
+    static constexpr int kM = PT + 3;                       // m = 4t + c = 0 .. PT + 2
+};
+constexpr int kStripOuts = Sys<16>::kOuts;      // the 128-tap kernel's figures (host arithmetic, tests)
 constexpr int kStripSpan = 2048;       // samples a strip reads
-constexpr int kM = 19;                 // m = 4t + c = 0 .. 18
 constexpr int kWavesPerWg = 4;
 
 __device__ __forceinline__ float dpp_shr1(float v)
@@ -168,35 +177,44 @@ struct SystolicFix {
     int period_g;           // group G (= blockIdx.x >> 6) is a fix-up block when G % period_g == period_g - 1 and G / period_g < nfix_groups
     int seamK;              // outputs per buffer (seam_block / 8), >= 256
     int k0mod;              // k_begin mod seamK
+    int nx;                 // Cross outputs in front of a boundary: (Lp - 1) / 8 = 15 for 128 taps, 6 for 52
+    int lp;                 // the filter's own length (128, or 52 on the 64-tap instantiation): the launch's samples end at (count - 1) * 8 + lp
 };
 constexpr int kFixPer = 16, kFixSpw = 16;      // 16 candidate slots per seam, 16 seams per workgroup (k_decimate_c_crossfix's shape)
 constexpr int kFixLdsFloats = 2 * kFixSpw * crossfix_row_float2<8, 128, kFixPer>();
 
-template <bool U8, int PSKIP, bool WHOLE, bool NTL, bool FIX>
+template <bool U8, int PSKIP, bool WHOLE, bool NTL, bool FIX, int PT>
 __device__ __forceinline__ void systolic_strip(const void* __restrict__ in, int64_t x0, int strip, int count, const float* __restrict__ taps,
-                                               float* __restrict__ out, float* __restrict__ wbuf, int lane, int seamK, int k0mod)
+                                               float* __restrict__ out, float* __restrict__ wbuf, int lane, const SystolicFix& fx)
 {
+    constexpr int kOuts = Sys<PT>::kOuts, kStep = Sys<PT>::kStep, kWarm = Sys<PT>::kWarm;
+    const int seamK = fx.seamK, k0mod = fx.k0mod, nx = fx.nx;
     f2 S[32];
-    const int64_t strip_s0 = x0 + (int64_t)kStripStep * strip;
-    // samples of the launch: (count - 1) * 8 + 128 from x0 on
-    const int64_t avail = WHOLE ? kStripSpan : ((int64_t)(count - 1) * 8 + 128) - (int64_t)kStripStep * strip;
+    const int64_t strip_s0 = x0 + (int64_t)kStep * strip;
+    // samples of the launch: (count - 1) * 8 + lp from x0 on
+    const int64_t avail = WHOLE ? kStripSpan : ((int64_t)(count - 1) * 8 + fx.lp) - (int64_t)kStep * strip;
     load_strip<U8, WHOLE, NTL>(in, strip_s0, avail, wbuf, lane, S);
 
     f2 acc[4][4];
-    f8 tc[16];
+    f8 tc[PT];
     tc[0] = load_tap_row(taps, 0);
     auto do_m = [&](auto mc) {
         constexpr int m = decltype(mc)::value, t = m >> 2, c = m & 3;
-        if constexpr (m + 1 < 16) tc[m + 1] = load_tap_row(taps, m + 1);
+        if constexpr (m + 1 < PT) tc[m + 1] = load_tap_row(taps, m + 1);
         else asm volatile("" ::: "memory");
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int k = r & 3;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int b = (m - i) & 15;                        // tap row of output i (only used when m - i is in 0 .. 15)
-                if (m - i < 0 || m - i > 15) continue;
-                if (PSKIP && 8 * b + r >= 128 - PSKIP) continue;
+                const int b = (m - i) & (PT - 1);                  // tap row of output i (only used when m - i is in 0 .. PT - 1)
+                if (m - i < 0 || m - i > PT - 1) continue;
+                if (PSKIP && 8 * b + r >= 8 * PT - PSKIP) {
+                    // a skipped tap at a stage's entry: the partial sum still has to move up a lane (only the 64-tap instantiation
+                    // skips that far into a row: taps 56 .. 59 of output 1 meet m = 8)
+                    if (t > 0 && c == 0 && r < 4) acc[i][k] = f2{dpp_shr1(acc[i][k].x), dpp_shr1(acc[i][k].y)};
+                    continue;
+                }
                 const f2 p = S[8 * c + r] * tc[b][r];
                 if (b == 0 && r < 4) {
                     acc[i][k] = f2{0.f, 0.f} + p;                  // the first addition of the partial: +0 + product
@@ -208,7 +226,7 @@ __device__ __forceinline__ void systolic_strip(const void* __restrict__ in, int6
             }
         }
     };
-    for_each_m(std::make_integer_sequence<int, kM>{}, do_m);
+    for_each_m(std::make_integer_sequence<int, Sys<PT>::kM>{}, do_m);
 
     // the last stage's arithmetic must not sink into the `lane >= 4` block below: its first additions carry the DPP move, which
     // needs every lane -- sunk, each becomes a v_mov_dpp outside plus an addition inside (26 extra instructions per strip; measured
@@ -221,26 +239,26 @@ __device__ __forceinline__ void systolic_strip(const void* __restrict__ in, int6
 #pragma unroll
     for (int i = 0; i < 4; i++) res[i] = (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
     res[0] = f2{dpp_shr1(res[0].x), dpp_shr1(res[0].y)};           // output 0 of the group sat one lane below
-    // FIX: position of the strip's first output inside its buffer (wave-uniform: scalar arithmetic), and whether any of its 240
-    // outputs is one of the buffer's last 15 (seamK >= 256 > 240: the strip wraps the buffer grid at most once)
+    // FIX: position of the strip's first output inside its buffer (wave-uniform: scalar arithmetic), and whether any of its 240 (248)
+    // outputs is one of the buffer's last nx (seamK >= 256 > 248: the strip wraps the buffer grid at most once)
     int km_strip = 0;
     bool strip_cross = false;
     if constexpr (FIX) {
         const int su = __builtin_amdgcn_readfirstlane(strip);
-        km_strip = (int)(((unsigned)k0mod + (unsigned)((kStripOuts * (int64_t)su) % seamK)) % (unsigned)seamK);
-        strip_cross = km_strip + (kStripOuts - 1) >= seamK - 15;
+        km_strip = (int)(((unsigned)k0mod + (unsigned)((kOuts * (int64_t)su) % seamK)) % (unsigned)seamK);
+        strip_cross = km_strip + (kOuts - 1) >= seamK - nx;
     }
-    if (lane >= 4) {
-        const int o = kStripOuts * strip + 4 * (lane - 4);
+    if (lane >= kWarm) {
+        const int o = kOuts * strip + 4 * (lane - kWarm);
         bool cross[4] = {false, false, false, false};
         bool any_cross = false;
         if constexpr (FIX) {
             if (strip_cross) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    int km = km_strip + 4 * (lane - 4) + i;
+                    int km = km_strip + 4 * (lane - kWarm) + i;
                     if (km >= seamK) km -= seamK;
-                    cross[i] = km >= seamK - 15;
+                    cross[i] = km >= seamK - nx;
                     any_cross |= cross[i];
                 }
             }
@@ -257,7 +275,7 @@ __device__ __forceinline__ void systolic_strip(const void* __restrict__ in, int6
     }
 }
 
-template <bool U8, int PSKIP, bool NTL = true, bool FIX = false>
+template <bool U8, int PSKIP, bool NTL = true, bool FIX = false, int PT = 16>
 __global__ void __launch_bounds__(64 * kWavesPerWg, 4) k_decimate_systolic(const void* __restrict__ in, int64_t x0 /* sample of output 0's window in `in` */,
                                                                           int count, const float* __restrict__ taps, float* __restrict__ out,
                                                                           int nwhole /* strips [0, nwhole) are whole */, int nstrips, SystolicFix fx)
@@ -269,7 +287,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, 4) k_decimate_systolic(const
     if constexpr (FIX) {
         const int G = b >> 6, q = G / fx.period_g;
         if (q < fx.nfix_groups && G - q * fx.period_g == fx.period_g - 1) {
-            decimate_c_crossfix_wg<U8, 8, 128, kFixPer, kFixSpw>(reinterpret_cast<float2*>(tbuf), 64 * q + (b & 63), fx.g, fx.xtaps, in, out, fx.first_seam, fx.nseams);
+            decimate_c_crossfix_wg<U8, 8, (PT == 16 ? 128 : 52), kFixPer, kFixSpw>(reinterpret_cast<float2*>(tbuf), 64 * q + (b & 63), fx.g, fx.xtaps, in, out, fx.first_seam, fx.nseams);
             return;
         }
         b -= 64 * (q < fx.nfix_groups ? q : fx.nfix_groups);          // fix-up blocks in front of this group
@@ -280,8 +298,8 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, 4) k_decimate_systolic(const
     const int strip = wg * kWavesPerWg + wave;
     if (strip >= nstrips) return;
     float* wbuf = tbuf + (U8 ? 0 : kCfWaveDw * wave);
-    if (strip < nwhole) systolic_strip<U8, PSKIP, true, NTL, FIX>(in, x0, strip, count, taps, out, wbuf, lane, fx.seamK, fx.k0mod);
-    else systolic_strip<U8, PSKIP, false, NTL, FIX>(in, x0, strip, count, taps, out, wbuf, lane, fx.seamK, fx.k0mod);
+    if (strip < nwhole) systolic_strip<U8, PSKIP, true, NTL, FIX, PT>(in, x0, strip, count, taps, out, wbuf, lane, fx);
+    else systolic_strip<U8, PSKIP, false, NTL, FIX, PT>(in, x0, strip, count, taps, out, wbuf, lane, fx);
 }
 
 std::atomic<int>& systolic_flag()
@@ -296,13 +314,14 @@ std::atomic<long long> g_systolic_launches{0};
 // How a launch of `count` outputs is cut into wave-strips (host arithmetic, testable without a GPU: sdrhip_debug_systolic_plan).
 // Strip t covers outputs 240 t .. 240 t + 239 and reads samples 1920 t .. 1920 t + 2047.  Strips [0, nwhole) have all their
 // outputs wanted and all their samples inside the launch's (count - 1) * 8 + 128.
-void systolic_plan(int count, int* nstrips, int* nwhole)
+static void systolic_plan_for(int count, int outs, int lp, int* nstrips, int* nwhole)
 {
-    *nstrips = (count + kStripOuts - 1) / kStripOuts;
-    int w = count / kStripOuts;
-    while (w > 0 && (int64_t)kStripStep * (w - 1) + kStripSpan > (int64_t)(count - 1) * 8 + 128) w--;
+    *nstrips = (count + outs - 1) / outs;
+    int w = count / outs;
+    while (w > 0 && (int64_t)8 * outs * (w - 1) + kStripSpan > (int64_t)(count - 1) * 8 + lp) w--;
     *nwhole = w;
 }
+void systolic_plan(int count, int* nstrips, int* nwhole) { systolic_plan_for(count, kStripOuts, 128, nstrips, nwhole); }
 
 void set_systolic(int mode) { systolic_flag().store(mode); }
 long long systolic_launch_count() { return g_systolic_launches.load(); }
@@ -326,17 +345,22 @@ bool launch_decimate_c4_systolic(hipStream_t s, const Geom& g, const float* d_ta
     if (seams_done) *seams_done = false;
     const int mode = systolic_flag().load(std::memory_order_relaxed);
     if (mode == 0) return false;
-    if (g.I != 1 || g.D != 8 || P != 128 || g.Lp != 128 || g.count < 64 * kStripOuts * kWavesPerWg) return false;
+    // 128 taps (either input), or -- u8 input, the library's own choice only -- the reference example's 52-tap filter on the 64-tap
+    // instantiation (12 taps of padding skipped; cfloat input and other lengths stay on the tile kernel)
+    const bool p52 = in_is_u8 && mode == 2 && P == 52 && g.Lp == 52;
+    if (g.I != 1 || g.D != 8 || !((P == 128 && g.Lp == 128) || p52) || g.count < 64 * kStripOuts * kWavesPerWg) return false;
     const int64_t x0 = g.k_begin * g.D - g.in_base;
     const uintptr_t base = reinterpret_cast<uintptr_t>(d_in);
     if (((base + (in_is_u8 ? 2 : 8) * (uintptr_t)x0) & 15) != 0 || (reinterpret_cast<uintptr_t>(d_out) & 15) != 0) return false;
     // strip n is whole when its 240 outputs are wanted and its 2048 samples exist: 1920 n + 2048 <= (count - 1) * 8 + 128
     int nstrips, nwhole;
-    systolic_plan(g.count, &nstrips, &nwhole);
+    systolic_plan_for(g.count, p52 ? Sys<8>::kOuts : Sys<16>::kOuts, g.Lp, &nstrips, &nwhole);
     const int nwg = (nstrips + kWavesPerWg - 1) / kWavesPerWg;
     int groups = (nwg + 63) / 64;
     // the launch's own seams (those strictly inside its samples), as the fix-up launch of kernels_fast.hip counts them
     SystolicFix fx = {};
+    fx.lp = g.Lp;
+    fx.nx = (g.Lp - 1) / 8;
     bool fix = false;
     // Inside the launch up to 2^23 outputs (2^26 samples): there the fix-up is latency -- a second launch, 10-15 us of dependent chains
     // on an idle chip -- and hiding it gains 3-30 % (2^22 ... 2^25 samples: 15.6 -> 10.8, 24.3 -> 18.0, 34.1 -> 28.6, 59.7 -> 57.9 us
@@ -371,7 +395,10 @@ bool launch_decimate_c4_systolic(hipStream_t s, const Geom& g, const float* d_ta
         if (fix) hipLaunchKernelGGL((k_decimate_systolic<U8V, PSKIPV, NTLV, true>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips, fx); \
         else hipLaunchKernelGGL((k_decimate_systolic<U8V, PSKIPV, NTLV, false>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips, fx); \
     } while (0)
-    if (in_is_u8 && last_tap_zero) SYS(true, 1, true);
+    if (p52) {
+        if (fix) hipLaunchKernelGGL((k_decimate_systolic<true, 12, true, true, 8>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips, fx);
+        else hipLaunchKernelGGL((k_decimate_systolic<true, 12, true, false, 8>), grid, block, 0, s, d_in, x0, g.count, d_taps, d_out, nwhole, nstrips, fx);
+    } else if (in_is_u8 && last_tap_zero) SYS(true, 1, true);
     else if (in_is_u8) SYS(true, 0, true);
     else if (plain) SYS(false, 0, false);
     else SYS(false, 0, true);

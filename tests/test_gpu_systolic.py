@@ -134,3 +134,46 @@ def test_random_launch_geometry_equals_the_tile_kernel(hip):
         assert torch.equal(outs[2].view(torch.int32), outs[1].view(torch.int32)), ("in-launch fix-up", trial, u8, count, k0, seam)
         assert torch.isnan(outs[0][2 * count:]).all() and torch.isnan(outs[2][2 * count:]).all()
     assert took == 2 * 24 * scale
+
+
+def test_the_example_52_tap_filter_on_the_64_tap_instantiation(hip, oracle):
+    """Round 6: the reference example's own RF decimation filter (51 taps -> 52, examples/fm/Coeffs.hs as data) takes the systolic kernel's
+    64-tap instantiation on u8 input (12 taps of padding skipped; strips of 248 outputs, 6 Cross outputs per boundary): against the tile
+    kernel on random launch geometries -- seams 0 / 8192 / odd multiples of 8, launches inside and past the in-launch fix-up's range -- and
+    against the oracle's decimateAVXRC on one whole-stream launch."""
+    import os
+    scale = max(1, int(os.environ.get("SDRHIP_SWEEP_SCALE", "1")))
+    rng = np.random.default_rng(5206 + int(os.environ.get("SDRHIP_SWEEP_SEED", "0")))
+    taps = S.taps_example_rf_decim()
+    dec = hip.Decimator(8, taps, hip.ORDER_AVX, complex_=True)
+    n = 1 << 23
+    g = torch.Generator(device="cuda").manual_seed(52)
+    d_u8 = torch.randint(0, 256, (2 * n,), dtype=torch.uint8, device="cuda", generator=g)
+    kmax = (n - 52) // 8 + 1
+    took = 0
+    for trial in range(16 * scale):
+        count = int(rng.integers(MIN, 8 * MIN))
+        seam = int(rng.choice([0, B, B, 8 * int(rng.integers(40, 3000))]))
+        if seam and count <= 5 * 32768:
+            count = 5 * 32768 + 2 * int(rng.integers(1, 5000))
+        k0 = 2 * int(rng.integers(0, (kmax - count) // 2))
+        outs = []
+        before = hip.lib.sdrhip_debug_systolic_launches()
+        for mode in (2, 0):
+            hip.lib.sdrhip_debug_set_systolic(mode)
+            out = torch.full((2 * count + 8,), float("nan"), device="cuda")
+            dec.run_u8(ptr(d_u8), 0, ptr(out), k0, k0 + count, seam)
+            torch.cuda.synchronize()
+            outs.append(out)
+        hip.lib.sdrhip_debug_set_systolic(2)
+        took += hip.lib.sdrhip_debug_systolic_launches() - before
+        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), (trial, count, k0, seam)
+        assert torch.isnan(outs[0][2 * count:]).all()
+    assert took == 16 * scale, "the 64-tap systolic instantiation did not take the launches"
+    K = MIN + 777
+    nn = 8 * (K - 1) + 52
+    raw = S.iq_u8(nn)
+    out = dev_empty_f32(2 * K)
+    dec.run_u8(ptr(to_dev(raw)), 0, ptr(out), 0, K, 0)
+    h = np.concatenate([taps, np.zeros(1, np.float32)])
+    assert_bit_equal(to_host(out), oracle.decimate_rc(4, K, 8, _dup(h), oracle.convert_u8(raw)), "52-tap systolic vs the oracle's decimateAVXRC")
