@@ -32,7 +32,7 @@ def main():
     rf = full["roofline"]
     row("K2 roofline (VALU, unfused, 78.6 TFLOP/s)", f"{rf['achieved']} TFLOP/s = **{rf['frac']:.3f}**; HBM view {rf['hbm']['achieved']:.0f} GB/s = {rf['hbm']['frac']:.3f}", B)
     row("K2 HBM traffic per launch (FETCH x 2 + WRITE) / algorithmic", f"{k2t['hbm_bytes_per_launch'] / 1e9:.4f} GB / {k2t['algorithmic_bytes_per_launch'] / 1e9:.4f} GB = {k2t['hbm_bytes_per_launch'] / k2t['algorithmic_bytes_per_launch']:.4f}", "profiles/k2_traffic.json")
-    for k, label in (("k_decimate_systolic<true, 1, false>", "K2 u8 kernel alone"), ("k_decimate_systolic<true, 1, true, false>", "K2 u8 kernel alone"), ("k_resample3_fast<3, 64, 4, 3, 3, 256, true, 8, true>", "fmDemod + resampler kernel alone"),
+    for k, label in (("k_decimate_systolic<true, 1, false>", "K2 u8 kernel alone"), ("k_decimate_systolic<true, 1, true, false>", "K2 u8 kernel alone"), ("k_decimate_systolic<true, 1, true, false, 16>", "K2 u8 kernel alone"), ("k_resample3_fast<3, 64, 4, 3, 3, 256, true, 8, true>", "fmDemod + resampler kernel alone"),
                      ("k_fir_real8_fast<true, 4, 256, 8>", "filter kernel alone"), ("k_decimate_c_crossfix<true, 8, 128, 16, 16, false>", "decimator seam fix-up"),
                      ("k_resample_real_crossfix<20, 135, 32>", "resampler seam fix-up"), ("k_resample3_stragglers<20, 135, 8>", "resampler seam fix-up + lead-in + tail (one launch)"), ("k_filter_real_crossfix_lds<128>", "filter seam fix-up")):
         if k in stats:
