@@ -8,10 +8,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sdr_amd import build as B
 
-KERNELS = [("kernels_systolic.hip", "k_decimate_systolicILb1ELi1ELb1ELb0EE", "k_decimate_systolic<u8, zero tap skipped> (chain K2, fix-up as a second launch: launches past 2^26 samples)"),
-           ("kernels_systolic.hip", "k_decimate_systolicILb1ELi1ELb1ELb1EE", "k_decimate_systolic<u8, zero tap skipped, seam fix-up workgroups inside> (launches up to 2^26 samples)"),
-           ("kernels_systolic.hip", "k_decimate_systolicILb0ELi0ELb1ELb0EE", "k_decimate_systolic<cfloat, non-temporal loads> (BASELINE configs[1] at 2^27 samples)"),
-           ("kernels_systolic.hip", "k_decimate_systolicILb0ELi0ELb0ELb1EE", "k_decimate_systolic<cfloat, plain loads, seam fix-up workgroups inside> (64 ... 285 MB of input)"),
+KERNELS = [("kernels_systolic.hip", "k_decimate_systolicILb1ELi1ELb1ELb0ELi16EE", "k_decimate_systolic<u8, zero tap skipped> (chain K2, fix-up as a second launch: launches past 2^26 samples)"),
+           ("kernels_systolic.hip", "k_decimate_systolicILb1ELi1ELb1ELb1ELi16EE", "k_decimate_systolic<u8, zero tap skipped, seam fix-up workgroups inside> (launches up to 2^26 samples)"),
+           ("kernels_systolic.hip", "k_decimate_systolicILb0ELi0ELb1ELb0ELi16EE", "k_decimate_systolic<cfloat, non-temporal loads> (BASELINE configs[1] at 2^27 samples)"),
+           ("kernels_systolic.hip", "k_decimate_systolicILb0ELi0ELb0ELb1ELi16EE", "k_decimate_systolic<cfloat, plain loads, seam fix-up workgroups inside> (64 ... 285 MB of input)"),
+           ("kernels_systolic.hip", "k_decimate_systolicILb1ELi12ELb1ELb0ELi8EE", "k_decimate_systolic<u8, 64-tap instantiation, 12 padding taps skipped> (the reference example's 52-tap RF filter)"),
            ("kernels_chain.hip", "k_resample3_fastILi3ELi64ELi4ELi3ELi3ELi256ELb1ELi8ELb1EE", "k_resample3_fast<.., DEMOD, 8 lanes, packed pairs> (fmDemod + 3/10 resampler)"),
            ("kernels_chain.hip", "k_fir_real8_fastILb1ELi4ELi256ELi8EE", "k_fir_real8_fast<symmetric, 8 lanes> (audio filter + gain)")]
 
