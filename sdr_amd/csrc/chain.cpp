@@ -74,6 +74,7 @@ struct sdrhip_fm_chain {
     int small_chain = getenv("SDRHIP_SMALL_CHAIN") ? atoi(getenv("SDRHIP_SMALL_CHAIN")) : 2;
     int64_t small_chain_max = getenv("SDRHIP_SMALL_CHAIN_MAX") ? atoll(getenv("SDRHIP_SMALL_CHAIN_MAX")) : kSmallChainAutoOutputs;
     int small_chain_tile = getenv("SDRHIP_SMALL_CHAIN_TILE") ? atoi(getenv("SDRHIP_SMALL_CHAIN_TILE")) : 0;
+    bool input_over_link = false;   // set by the host-block operator around its in-place pushes: the input is pinned HOST memory
     bool small_chain_ok(int64_t n_out) const
     {
         if (small_chain == 0 || (small_chain == 2 && n_out > small_chain_max)) return false;
@@ -387,7 +388,8 @@ static int chain_run_on(sdrhip_fm_chain* c, void* stream, const uint8_t* d_in_iq
         const bool took = launch_fm_chain_small(s, d_in_iq, s0, n_in, d_audio, q0, q1, c->decim.factor, c->decim.Lp, c->decim.d_scaled, last_zero,
                                                 c->resamp.d_groups, c->resamp.row_stride, c->resamp.nloop, c->resamp.increments.data(),
                                                 c->resamp.num_groups, c->resamp.I, c->resamp.D, c->resamp.Lp, c->resamp.d_plain, c->resamp.ntaps,
-                                                c->audio.d_taps, c->audio.ntaps_kernel, c->audio.d_cross, c->gain, c->block, c->small_chain_tile);
+                                                c->audio.d_taps, c->audio.ntaps_kernel, c->audio.d_cross, c->gain, c->block,
+                                                c->small_chain_tile != 0 ? c->small_chain_tile : (c->input_over_link ? -1 : 0));
         if (took) {
             if (c->timing) {
                 if ((rc2 = c->new_event(&e)) != SDRHIP_OK) return rc2;
@@ -927,8 +929,11 @@ static int stream_submit(sdrhip_fm_stream* st)
     if (direct) {
         // zero-copy: the kernels read the pinned staging buffer and write the pinned result buffer themselves
         if (n_out > 0) {
-            if ((rc = sdrhip_fm_chain_run(c, (void*)cs, (const uint8_t*)sl.hin.dev_ptr(first), keep_from, tail + n,
-                                          (float*)sl.hout.dev, st->q_done, q_new, wsb_buf.p, wsb_buf.cap)) != SDRHIP_OK) return rc;
+            c->input_over_link = true;
+            rc = sdrhip_fm_chain_run(c, (void*)cs, (const uint8_t*)sl.hin.dev_ptr(first), keep_from, tail + n,
+                                     (float*)sl.hout.dev, st->q_done, q_new, wsb_buf.p, wsb_buf.cap);
+            c->input_over_link = false;
+            if (rc != SDRHIP_OK) return rc;
             sl.n_out = n_out;
             sl.busy = true;
         }

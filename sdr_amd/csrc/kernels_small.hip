@@ -488,7 +488,10 @@ bool launch_fm_chain_small(hipStream_t s, const uint8_t* d_in, int64_t s0, int64
     if (seam != 0 && (seam < 192 || seam > (1 << 26))) return false;       // 32-bit seam arithmetic; a stage's window meets one boundary at most
     if ((reinterpret_cast<uintptr_t>(d_in) & 15) != 0 || (s0 & 7) != 0) return false;   // 16-byte aligned tile loads
     if (q1 <= q0) return true;
-    int A = tile_outputs > 0 ? tile_outputs : fm_chain_small_tile_outputs(q1 - (q0 / 3) * 3);
+    // tile_outputs < 0: the largest tile -- for input that is read over PCIe (the host-block operators' in-place pushes): a tile's
+    // ~4000-sample overlap is READ once per tile, and on the link that traffic, not the number of workgroups, is what a push costs
+    // (round 6, tools/stream_tile_probe.py: 16 blocks per push 22.1 -> 14.6 us with 159 instead of 96 outputs per tile)
+    int A = tile_outputs > 0 ? tile_outputs : tile_outputs < 0 ? SM_A_MAX : fm_chain_small_tile_outputs(q1 - (q0 / 3) * 3);
     A = A / 3 * 3;
     if (A < 3) A = 3;
     if (A > SM_A_MAX) A = SM_A_MAX;
