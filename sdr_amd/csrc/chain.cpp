@@ -758,7 +758,9 @@ struct sdrhip_fm_stream {
     bool direct_ok = getenv("SDRHIP_NO_DIRECT_STREAM") == nullptr;
     // [tail | new] up to this many samples is read in place over PCIe (tunable for experiments: SDRHIP_DIRECT_SAMPLES)
     int64_t direct_samples = getenv("SDRHIP_DIRECT_SAMPLES") ? atoll(getenv("SDRHIP_DIRECT_SAMPLES")) : kDirectSamples;
-    static constexpr int64_t kDirectSamples = 33 * 8192;   // measured: 16 blocks per push 66 -> 46 us in place; 256 blocks are better off on the copy engines
+    // round 6 (tools/stream_direct_threshold_probe.py, after the in-place pushes got the largest tile): in place 11.1 / 11.7 / 12.2 Gsample/s
+    // at 48 / 64 / 96 blocks per push against 8.2 / 10.5 / 13.4 through the copy engines (zero-copy pushes; memcpy pushes cross at ~110 blocks)
+    static constexpr int64_t kDirectSamples = 80 * 8192;
     struct Slot {
         PinBuf hin, hout;
         DevBuf dout;
