@@ -1135,13 +1135,13 @@ def main():
             try:
                 sps, _ = H.fm_stream_rate(L, chain, bpp * BLOCK, pushes, zc, co)
                 host[name] = round(sps / 1e6, 1)
-                host.setdefault("link_roofline", {})[name] = annotate(sps, bpp * BLOCK <= 79 * BLOCK)
+                host.setdefault("link_roofline", {})[name] = annotate(sps, bpp * BLOCK <= 199 * BLOCK)
                 dbg(f"host {name} done")
             except Exception as e:                      # noqa: BLE001
                 host[name] = f"failed: {e!r}"
         host["link_roofline_what"] = ("per host-streamed line: the bytes it moves over the link per second (2 B of u8 IQ up + 0.15 B of audio down per "
                                       "input sample) against the ceiling measured above -- the in-place read rate for pushes the kernels read in place "
-                                      "(up to 80 source blocks), the pinned hipMemcpyAsync rate for the ones that go through the copy engines.  Small "
+                                      "(up to 200 source blocks), the pinned hipMemcpyAsync rate for the ones that go through the copy engines.  Small "
                                       "pushes are bound by launch latency, not by the link: their frac says how far")
         # the double-buffered path (4096-block pushes: upload of push i over compute of i-1 over download of i-2): what overlaps
         try:

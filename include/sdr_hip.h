@@ -440,8 +440,10 @@ int sdrhip_fm_chain_halo_exchange_batch(const sdrhip_fm_chain *chain, sdrhip_com
  * each or a whole multiple), audio blocks of exactly block_size_out floats out -- the five middle
  * stages of examples/fm/fm.hs:34-41 as ONE operator with every intermediate resident in HBM.  Pinned
  * staging in slots = submissions in flight: two when max_block_samples is too large to run in place (results lag one push;
- * H2D / compute / D2H on three HIP streams), four when even the largest push runs in place -- up to 80 source blocks: the
- * kernels read and write the pinned buffers over PCIe, one compute stream per slot, a push of a few blocks is ONE kernel --
+ * H2D / compute / D2H on three HIP streams), four when even the largest push runs on one stream -- up to 200 source blocks: one compute
+ * stream per slot; a lone source block is read by the kernel straight from the pinned buffer over PCIe, anything larger (a push of several
+ * blocks, or pushes that piled up while the GPU was busy) crosses the link ONCE by a copy on the slot's stream and is then ONE kernel on
+ * device memory; the audio is written to the pinned result buffer by the kernel either way (SDRHIP_STAGE_SAMPLES moves the bound) --
  * and results lag three pushes (flush drains; SDRHIP_STREAM_SLOTS=2..4 overrides the count).
  * The chain must outlive the stream and must not be run concurrently by another caller. */
 typedef struct sdrhip_fm_stream sdrhip_fm_stream;

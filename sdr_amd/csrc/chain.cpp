@@ -760,7 +760,11 @@ struct sdrhip_fm_stream {
     int64_t direct_samples = getenv("SDRHIP_DIRECT_SAMPLES") ? atoll(getenv("SDRHIP_DIRECT_SAMPLES")) : kDirectSamples;
     // round 6 (tools/stream_direct_threshold_probe.py, after the in-place pushes got the largest tile): in place 11.1 / 11.7 / 12.2 Gsample/s
     // at 48 / 64 / 96 blocks per push against 8.2 / 10.5 / 13.4 through the copy engines (zero-copy pushes; memcpy pushes cross at ~110 blocks)
-    static constexpr int64_t kDirectSamples = 80 * 8192;
+    // ... and with the slot-stream staging copy (below) 19-24 Gsample/s from 2 to 160 blocks per push against 13-17 through the three-stream
+    // copy path at 96 ... 128 blocks; the two meet at ~256 blocks (21.7 either way)
+    static constexpr int64_t kDirectSamples = 200 * 8192;
+    // pushes (or piled-up batches) of at least this many samples are copied to device memory on their slot's stream before the chain runs
+    int64_t stage_samples = getenv("SDRHIP_STAGE_SAMPLES") ? atoll(getenv("SDRHIP_STAGE_SAMPLES")) : 2 * 8192;
     struct Slot {
         PinBuf hin, hout;
         DevBuf dout;
@@ -931,10 +935,22 @@ static int stream_submit(sdrhip_fm_stream* st)
     if (direct) {
         // zero-copy: the kernels read the pinned staging buffer and write the pinned result buffer themselves
         if (n_out > 0) {
-            c->input_over_link = true;
-            rc = sdrhip_fm_chain_run(c, (void*)cs, (const uint8_t*)sl.hin.dev_ptr(first), keep_from, tail + n,
-                                     (float*)sl.hout.dev, st->q_done, q_new, wsb_buf.p, wsb_buf.cap);
-            c->input_over_link = false;
+            if (tail + n >= st->stage_samples) {
+                // ONE pass over the link into device memory on the slot's own compute stream, then the chain on device memory (round 6):
+                // read in place, the one-kernel chain fetches every sample ~1.95 times over PCIe (each tile re-reads its overlap),
+                // and the link is what such a push costs -- 8 ... 64 blocks per push 10-11 -> 19-24 Gsample/s.  No second stream, no
+                // event: the copy and the kernels of a slot are ordered by its stream.
+                DevBuf& dbuf = st->din[si];
+                if ((rc = dbuf.ensure((size_t)(tail + n) * 2 + 64)) != SDRHIP_OK) return rc;
+                SDRHIP_CHECK_HIP(hipMemcpyAsync(dbuf.p, first, (size_t)(tail + n) * 2, hipMemcpyHostToDevice, cs));
+                rc = sdrhip_fm_chain_run(c, (void*)cs, (const uint8_t*)dbuf.p, keep_from, tail + n, (float*)sl.hout.dev, st->q_done, q_new, wsb_buf.p, wsb_buf.cap);
+            } else {
+                // a lone source block (a paced real-time source: the GPU is idle when it arrives): the kernel reads the pinned buffer itself
+                c->input_over_link = true;
+                rc = sdrhip_fm_chain_run(c, (void*)cs, (const uint8_t*)sl.hin.dev_ptr(first), keep_from, tail + n,
+                                         (float*)sl.hout.dev, st->q_done, q_new, wsb_buf.p, wsb_buf.cap);
+                c->input_over_link = false;
+            }
             if (rc != SDRHIP_OK) return rc;
             sl.n_out = n_out;
             sl.busy = true;

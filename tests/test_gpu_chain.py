@@ -586,16 +586,17 @@ def test_chain_run_as_hipgraph(hip, oracle):
 
 
 def test_fm_stream_crosses_the_in_place_threshold(hip, oracle):
-    """sdrhip_fm_stream: pushes of 1 block (in place, fused tail), 7, 16 and 79 blocks (in place, one-kernel chain: the limit is
-    80 blocks including the carried tail), 80 and 100 blocks (copy engines) in one stream, against one device-resident run."""
-    pattern = [1, 1, 7, 80, 1, 16, 1, 79, 100, 7, 1, 2, 80, 1]
+    """sdrhip_fm_stream: pushes of 1 block (the kernel reads the pinned buffer in place), 7, 16 and 199 blocks (one pass over the link on
+    the slot's own stream, then the one-kernel chain on device memory: the limit is 200 blocks including the carried tail), 200 and 230
+    blocks (three-stream copy path, stage kernels) in one stream, against one device-resident run."""
+    pattern = [1, 1, 7, 200, 1, 16, 1, 199, 230, 7, 1, 2, 200, 1]
     nblk = sum(pattern) * 3
     total = nblk * B
     u8 = S.iq_u8_fm(total)
     chain = _chain(hip)
     _, q1, _ = chain.plan(0, total, total)
     full = _run(hip, chain, to_dev(u8), 0, total, 0, q1)
-    st = hip.FmStream(chain, 100 * B, B)
+    st = hip.FmStream(chain, 230 * B, B)
     got, pos = [], 0
     for rep in range(3):
         for k, n in enumerate(pattern):
@@ -654,11 +655,11 @@ def test_fm_stream_save_and_restore(hip, oracle, blocks_per_push):
 
 def test_fm_stream_many_mixed_pushes(hip):
     """A long stream of pushes of mixed sizes -- one block (fused tail, in place), a few (stage kernels, in place, the two
-    compute streams in turn), 80 and 100 blocks (copy engines) -- zero-copy and memcpy pushes interleaved: every audio sample
+    compute streams in turn), 200 and 230 blocks (copy engines) -- zero-copy and memcpy pushes interleaved: every audio sample
     equals the device-resident run over the whole stream.  (What a race between consecutive pushes on the two compute streams,
     or a stale workspace / history, would break.)"""
     rng = np.random.default_rng(515 + SWEEP_SEED)
-    choices = np.array([1, 1, 1, 2, 3, 7, 16, 80, 100, 1, 2])
+    choices = np.array([1, 1, 1, 2, 3, 7, 16, 80, 200, 230, 1, 2])
     pattern = rng.choice(choices, size=min(300 * SWEEP_SCALE, 6000))
     nblk = int(pattern.sum())
     total = nblk * B
@@ -666,7 +667,7 @@ def test_fm_stream_many_mixed_pushes(hip):
     chain = _chain(hip)
     _, q1, _ = chain.plan(0, total, total)
     ref = _run(hip, chain, u8.cuda(), 0, total, 0, q1)
-    st = hip.FmStream(_chain(hip), 100 * B, B)
+    st = hip.FmStream(_chain(hip), 230 * B, B)
     host = u8.numpy()
     got, pos = [], 0
     for k, n in enumerate(pattern):

@@ -7,7 +7,7 @@ import sdr_amd.lib as L
 import signals as S
 import host_stream_native as H
 B = 8192
-for bpp in (8, 16, 24, 32, 48, 64, 96, 128, 256):
+for bpp in [int(x) for x in os.environ.get("PROBE_BPP", "8,16,24,32,48,64,96,128,256").split(",")]:
     for zc in (True, False):
         chain = L.FmChain(8, S.taps_decim127(), 3, 10, S.taps_resamp191(), S.taps_audio_half64(), 0.2, B)
         sps, _ = H.fm_stream_rate(L, chain, bpp * B, max(60, 24000 // bpp), zc)
