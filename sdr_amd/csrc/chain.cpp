@@ -856,6 +856,10 @@ int sdrhip_fm_stream_create(sdrhip_fm_stream** out, sdrhip_fm_chain* chain, int 
         const char* env = getenv("SDRHIP_STREAM_ADAPTIVE");
         const int64_t unit = chain->block > 0 ? chain->block : 8;
         int64_t cap = (st->direct_samples - st->head_cap) / unit;
+        // ... but no more than 64 source blocks' worth (or two of the caller's largest pushes): the one-stream route is within 10 % of its full rate
+        // with batches of that size (32: 13-15, 64: 18-21, 199: 20-22 Gsample/s), and what piles up beyond only adds to the push-to-audio lag
+        const int64_t enough = std::max<int64_t>((64 * (int64_t)8192 + unit - 1) / unit, 2 * (((int64_t)max_block_samples + unit - 1) / unit));
+        if (cap > enough) cap = enough;
         if (env && atoll(env) < cap) cap = atoll(env);
         cap *= unit;
         if (cap >= 2 * (int64_t)max_block_samples && cap <= (1 << 30)) st->adaptive = (int)cap;
